@@ -1,0 +1,192 @@
+/*
+ * fcosdet.h — C-ABI of libfcosdet_hip.so, the MI355X (gfx950) FCOS / HISFCOS hot path.
+ *
+ * Every entry point replaces a stock ATen / cuDNN / torchvision call the reference makes on its
+ * detection hot path (citations are file:line under the reference repo root).  Conventions:
+ *   - plain C, no torch types: every pointer is a DEVICE pointer owned by the caller
+ *     (tensor.data_ptr()), sizes are int32, the last argument is the hipStream_t to enqueue on
+ *     (torch.cuda.current_stream().cuda_stream on ROCm);
+ *   - the library never allocates or frees user-visible memory; scratch comes from a caller
+ *     workspace whose size the matching fd_*_workspace_bytes() call returns;
+ *   - every call only enqueues work (no hidden synchronisation) and returns FD_OK or a negative
+ *     error code; the message is available through fd_last_error() (thread local);
+ *   - activations are fp32 NHWC ("rows x channels"): row m of a level is pixel
+ *     (n, h, w) = (m / (H*W), (m / W) % H, m % W); a tensor may be a channel slice of a wider
+ *     buffer, described by (ptr, channel stride cs, channel offset co):  elem = ptr[m*cs + co + c].
+ *   - a pyramid (the 5 FCOS levels sharing head weights) is ONE buffer, levels concatenated along
+ *     the row axis and described by fd_segs; a plain feature map is a pyramid with one segment.
+ */
+#ifndef FCOSDET_H_
+#define FCOSDET_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FD_OK 0
+#define FD_E_INVAL (-1)       /* bad argument (shape, alignment, null pointer)        */
+#define FD_E_UNSUPPORTED (-2) /* valid request this build has no kernel for            */
+#define FD_E_LAUNCH (-3)      /* hipLaunch / hipGetLastError failure                   */
+
+#define FD_MAX_SEG 8
+
+/* activation ids for conv / depthwise / groupnorm epilogues */
+#define FD_ACT_NONE 0
+#define FD_ACT_RELU 1
+#define FD_ACT_SILU 2
+#define FD_ACT_EXP 3 /* exp(v * seg_param[level])  — ScaleExp, reference model/modules/modules.py:170-176 */
+#define FD_ACT_SIGMOID 4
+
+typedef void* fd_stream_t; /* hipStream_t */
+
+/* Pyramid-level table.  Rows of level s are [m_start[s], m_start[s+1]); m_start[s+1]-m_start[s] = batch*H[s]*W[s]. */
+typedef struct fd_segs {
+    int32_t nseg;
+    int32_t batch;
+    int32_t H[FD_MAX_SEG];
+    int32_t W[FD_MAX_SEG];
+    int32_t m_start[FD_MAX_SEG + 1];
+} fd_segs;
+
+/* ------------------------------------------------------------------------------------------- */
+/* library                                                                                       */
+int32_t fd_version(void);
+const char* fd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Convolution = implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), fused epilogue
+ *     y = act( conv(x, w) * scale[c] + shift[c] + res )
+ * replaces nn.Conv2d + (frozen) nn.BatchNorm2d + ReLU/SiLU (+ residual add) of
+ *   torchvision resnet50 bottlenecks (reference model/backbone/resnet50.py:68-80),
+ *   HalfInvertedStageFPN / HisBlock (model/od/HISFcos.py:77-179), HISFCOSHead (HISFcos.py:182-229),
+ *   FeaturePyramidNetwork / HeadFCOS (model/od/Fcos.py:61-133).
+ * w is packed [Cout][KH][KW][Cin] (K contiguous).  Cin % 32 == 0, x_cs % 4 == 0, x_co % 4 == 0.
+ * in.nseg > 1 requires stride 1 and "same" padding (pad == dil*(K-1)/2).
+ * mode FD_CONV_STEM: x is [N][H][W][4] (3 channels + zero pad), 7x7 stride 2 pad 3,
+ *   w packed [Cout][7][8][4] (zeros at kw=7 and c=3).
+ */
+#define FD_CONV_GENERIC 0
+#define FD_CONV_STEM 1
+
+typedef struct fd_conv_params {
+    const float* x;
+    const float* w;
+    const float* scale; /* [Cout] or NULL (=1) */
+    const float* shift; /* [Cout] or NULL (=0) */
+    const float* res;   /* optional residual in output geometry, or NULL */
+    float* y;
+    int32_t x_cs, x_co;
+    int32_t res_cs, res_co;
+    int32_t y_cs, y_co;
+    int32_t Cin, Cout, KH, KW, stride, pad, dil;
+    int32_t act;    /* FD_ACT_* applied to output channels >= act_c0; channels below get identity */
+    int32_t act_c0;
+    int32_t mode;   /* FD_CONV_GENERIC | FD_CONV_STEM */
+    float seg_param[FD_MAX_SEG]; /* per-level scalar for FD_ACT_EXP */
+    fd_segs in;     /* input geometry */
+} fd_conv_params;
+
+int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
+
+/* [N][3][H][W] fp32 (NCHW, the reference's input layout, dataset/voc.py:141-173) -> [N][H][W][4] (c=3 zero) */
+int32_t fd_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, fd_stream_t stream);
+/* NHWC rows -> NCHW copy (only for callers that insist on contiguous NCHW) */
+int32_t fd_nhwc_to_nchw(const float* x, int32_t x_cs, int32_t x_co, float* y, int32_t N, int32_t HW,
+                        int32_t C, fd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Bandwidth-bound layer ops                                                                     */
+
+/* nn.MaxPool2d(k, s, pad) on NHWC; k=3,s=2,pad=1 is the ResNet stem pool, k=2,s=2,pad=0 the FPN
+ * down_sample{1..6} (HISFcos.py:131-136); optional fused "+ add" of a tensor in output geometry
+ * (torch.add(p5_2, p4), HISFcos.py:168-177). */
+int32_t fd_maxpool_nhwc(const float* x, int32_t x_cs, int32_t x_co, float* y, int32_t y_cs, int32_t y_co,
+                        const float* add, int32_t add_cs, int32_t add_co, int32_t N, int32_t H, int32_t W,
+                        int32_t C, int32_t k, int32_t s, int32_t pad, fd_stream_t stream);
+
+/* y = nearest_upsample_x2(x) + lat      (nn.Upsample(scale_factor=2) + torch.add, HISFcos.py:155-165) */
+int32_t fd_upsample2x_add_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* lat, int32_t lat_cs,
+                               int32_t lat_co, float* y, int32_t y_cs, int32_t y_co, int32_t N, int32_t H,
+                               int32_t W, int32_t C, fd_stream_t stream);
+
+/* Depthwise 3x3, stride 1, pad 1 (DepthWiseConv2d, modules.py:40-49): y = act(dw(x)*scale + shift).
+ * w packed [9][C]. */
+int32_t fd_dwconv3x3_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w, const float* scale,
+                          const float* shift, float* y, int32_t y_cs, int32_t y_co, int32_t C, int32_t act,
+                          const fd_segs* segs, fd_stream_t stream);
+
+/* GroupNorm(G, C) + activation (nn.GroupNorm in HISFCOSHead / HeadFCOS, HISFcos.py:190-204, Fcos.py:102-109).
+ * Two launches: partial moments (fp64 accumulation, fixed order) then normalise+affine+act.
+ * workspace: fd_groupnorm_workspace_bytes(segs, G). x and y may alias. */
+int64_t fd_groupnorm_workspace_bytes(const fd_segs* segs, int32_t G);
+int32_t fd_groupnorm_act_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* gamma, const float* beta,
+                              float* y, int32_t y_cs, int32_t y_co, int32_t C, int32_t G, float eps, int32_t act,
+                              const fd_segs* segs, void* workspace, fd_stream_t stream);
+
+/* Squeeze-excitation (SEBlock, modules.py:107-121): y = x * sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2).
+ * w1 [Cr][C], w2 [C][Cr].  workspace: fd_se_workspace_bytes(N, HW, C). */
+int64_t fd_se_workspace_bytes(int32_t N, int32_t HW, int32_t C);
+int32_t fd_se_scale_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w1, const float* b1,
+                         const float* w2, const float* b2, float* y, int32_t y_cs, int32_t y_co, int32_t N,
+                         int32_t HW, int32_t C, int32_t Cr, void* workspace, fd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Detection post-processing (reference model/modules/head.py:8-102,152-162, utill/utills.py:58-73)   */
+
+/* Per location: score = sqrt(max_c sigmoid(cls) * sigmoid(cnt)), class = argmax_c + 1 (first max),
+ * box = (cx - l, cy - t, cx + r, cy + b), (cx, cy) = (x*s + s/2, y*s + s/2).
+ * cls/cnt/reg are pyramid buffers (rows x C / 1 / 4 with channel strides).  Outputs are per image,
+ * levels concatenated in segment order, row-major inside a level: scores [N][L], classes [N][L]
+ * (int32), boxes [N][L][4], L = sum H*W. */
+int32_t fd_fcos_decode(const float* cls, int32_t cls_cs, int32_t cls_co, const float* cnt, int32_t cnt_cs,
+                       int32_t cnt_co, const float* reg, int32_t reg_cs, int32_t reg_co, int32_t num_classes,
+                       const fd_segs* segs, const int32_t* strides, float* scores, int32_t* classes,
+                       float* boxes, fd_stream_t stream);
+
+/* torch.topk(score, K, dim=1, largest=True, sorted=True) + gathers (head.py:69-80).  Ties: lower
+ * location index first.  Outputs [N][K]; top_idx (int32 location index) may be NULL. */
+int64_t fd_topk_workspace_bytes(int32_t N, int32_t L, int32_t K);
+int32_t fd_fcos_topk(const float* scores, const int32_t* classes, const float* boxes, int32_t N, int32_t L,
+                     int32_t K, float* top_scores, int64_t* top_classes, float* top_boxes, int32_t* top_idx,
+                     void* workspace, fd_stream_t stream);
+
+/* score >= score_thr mask + torchvision.ops.batched_nms (coordinate-offset trick) + gathers
+ * (FCOSHead.post_process, head.py:84-102).  Input rows must be score-descending (fd_fcos_topk
+ * output).  Greedy rule: suppress j when (double)iou(i,j) > iou_thr, iou on class-offset boxes
+ * without the "+1" pixel convention.  Outputs padded to [N][K] (rows >= counts[n] zero-filled),
+ * keep_idx[n][r] = index into the K input rows.  K <= 1024. */
+int32_t fd_batched_nms(const float* scores, const int64_t* classes, const float* boxes, int32_t N, int32_t K,
+                       float score_thr, double iou_thr, float* out_scores, int64_t* out_classes,
+                       float* out_boxes, int32_t* keep_idx, int32_t* counts, fd_stream_t stream);
+
+/* Class-agnostic greedy NMS with the "+1" pixel convention, keep while ovr <= (float)thr
+ * (DataEncoder._box_nms, utill/utills.py:221-255; mode 0 = 'union', 1 = 'min').
+ * One problem per call-row: boxes [N][K][4], scores [N][K] (any order; sorted internally,
+ * ties by lower index), n_valid [N] or NULL (=K).  keep_idx [N][K] (original indices, score
+ * descending), counts [N].  K <= 1024. */
+int32_t fd_box_nms_plus1(const float* boxes, const float* scores, const int32_t* n_valid, int32_t N, int32_t K,
+                         float thr, int32_t mode, int32_t* keep_idx, int32_t* counts, fd_stream_t stream);
+
+/* Pairwise IoU [Na][Nb]; plus_one=1: DataEncoder._box_iou (utills.py:201-218); 0: test.py:23-53 */
+int32_t fd_pairwise_iou(const float* a, const float* b, int32_t Na, int32_t Nb, int32_t plus_one, float* out,
+                        fd_stream_t stream);
+
+/* ClipBoxes (head.py:152-162): clamp(min 0), x <= W-1, y <= H-1, in place on [n_boxes][4] */
+int32_t fd_clip_boxes(float* boxes, int64_t n_boxes, int32_t img_h, int32_t img_w, fd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* LTRB IoU / GIoU regression loss (reference model/loss.py:116-177), fused masked forward + backward.
+ * pred/target [B][L][4], mask [B][L] (uint8, positives).  mode 0 = 'iou', 1 = 'giou'.
+ * loss_per_image [B] = sum over positives (NOT yet divided by num_pos), num_pos [B] int32.
+ * backward: grad_pred [B][L][4] = d(sum_b loss_b * gscale[b]) / d pred  (gscale = upstream/num_pos). */
+int32_t fd_ltrb_iou_loss_fwd(const float* pred, const float* target, const uint8_t* mask, int32_t B, int32_t L,
+                             int32_t mode, float* loss_per_image, int32_t* num_pos, fd_stream_t stream);
+int32_t fd_ltrb_iou_loss_bwd(const float* pred, const float* target, const uint8_t* mask, const float* gscale,
+                             int32_t B, int32_t L, int32_t mode, float* grad_pred, fd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCOSDET_H_ */

@@ -1,0 +1,47 @@
+// fd_common.h — shared host/device helpers for libfcosdet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/fcosdet.h"
+
+void fd_set_error(const char* fmt, ...);
+
+#define FD_REQUIRE(cond, code, ...)      \
+    do {                                 \
+        if (!(cond)) {                   \
+            fd_set_error(__VA_ARGS__);   \
+            return (code);               \
+        }                                \
+    } while (0)
+
+#define FD_CHECK_LAUNCH(name)                                                      \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            fd_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));   \
+            return FD_E_LAUNCH;                                                    \
+        }                                                                          \
+    } while (0)
+
+static inline int fd_segs_ok(const fd_segs* s) {
+    if (!s || s->nseg < 1 || s->nseg > FD_MAX_SEG || s->batch < 1 || s->m_start[0] != 0) return 0;
+    for (int i = 0; i < s->nseg; ++i) {
+        if (s->H[i] < 1 || s->W[i] < 1) return 0;
+        if (s->m_start[i + 1] - s->m_start[i] != s->batch * s->H[i] * s->W[i]) return 0;
+    }
+    return 1;
+}
+
+__device__ __forceinline__ float fd_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__device__ __forceinline__ float fd_act(float v, int act, float p) {
+    switch (act) {
+        case FD_ACT_RELU: return v > 0.f ? v : 0.f;
+        case FD_ACT_SILU: return v / (1.0f + expf(-v));
+        case FD_ACT_EXP: return expf(v * p);
+        case FD_ACT_SIGMOID: return fd_sigmoid(v);
+        default: return v;
+    }
+}

@@ -1,0 +1,520 @@
+// fd_postproc.hip — FCOS detection post-processing on gfx950 (wave64):
+//   decode (sigmoid / max / sqrt / LTRB->xyxy)  ->  per-image radix-select top-k + bitonic sort
+//   ->  score mask + class-offset batched NMS (bitmask in LDS, wave-level serial scan)  ->  clip.
+// Restates reference model/modules/head.py:8-102,152-162 and utill/utills.py:58-73,201-255.
+// Compiled with -ffp-contract=off: IoU arithmetic must round exactly like the CPU reference.
+#include "fd_common.h"
+
+// --------------------------------------------------------------------------------------------
+// decode
+// --------------------------------------------------------------------------------------------
+struct DecodeArgs {
+    const float* cls; const float* cnt; const float* reg;
+    int cls_cs, cls_co, cnt_cs, cnt_co, reg_cs, reg_co;
+    int C, L;
+    int loc_start[FD_MAX_SEG + 1];
+    int stride[FD_MAX_SEG];
+    fd_segs segs;
+    float* scores; int* classes; float* boxes;
+};
+
+__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
+    const int n = blockIdx.y;
+    const int loc = blockIdx.x * 256 + threadIdx.x;
+    if (loc >= a.L) return;
+    int s = 0;
+#pragma unroll
+    for (int t = 1; t < FD_MAX_SEG; ++t)
+        if (t < a.segs.nseg && loc >= a.loc_start[t]) s = t;
+    const int pix = loc - a.loc_start[s];
+    const int W = a.segs.W[s];
+    const int hw = a.segs.H[s] * W;
+    const long m = (long)a.segs.m_start[s] + (long)n * hw + pix;
+    const int py = pix / W, px = pix - py * W;
+
+    // max_c sigmoid(cls), first maximal index (torch.max semantics, head.py:62)
+    const float* cp = a.cls + m * a.cls_cs + a.cls_co;
+    float best = -1.0f;
+    int besti = 0;
+    const bool vec = ((a.cls_cs | a.cls_co | a.C) & 3) == 0;
+    if (vec) {
+        const float4* c4 = reinterpret_cast<const float4*>(cp);
+        for (int c = 0; c < a.C / 4; ++c) {
+            const float4 v = c4[c];
+            const float s0 = fd_sigmoid(v.x), s1 = fd_sigmoid(v.y), s2 = fd_sigmoid(v.z), s3 = fd_sigmoid(v.w);
+            if (s0 > best) { best = s0; besti = 4 * c; }
+            if (s1 > best) { best = s1; besti = 4 * c + 1; }
+            if (s2 > best) { best = s2; besti = 4 * c + 2; }
+            if (s3 > best) { best = s3; besti = 4 * c + 3; }
+        }
+    } else {
+        for (int c = 0; c < a.C; ++c) {
+            const float sv = fd_sigmoid(cp[c]);
+            if (sv > best) { best = sv; besti = c; }
+        }
+    }
+    const float cen = fd_sigmoid(a.cnt[m * a.cnt_cs + a.cnt_co]);
+    const float score = sqrtf(best * cen);
+
+    const float* rp = a.reg + m * a.reg_cs + a.reg_co;
+    const float l = rp[0], t = rp[1], r = rp[2], b = rp[3];
+    const int st = a.stride[s];
+    const float cx = (float)(px * st) + (float)(st / 2);
+    const float cy = (float)(py * st) + (float)(st / 2);
+    const long o = (long)n * a.L + loc;
+    a.scores[o] = score;
+    a.classes[o] = besti + 1;
+    reinterpret_cast<float4*>(a.boxes)[o] = make_float4(cx - l, cy - t, cx + r, cy + b);
+}
+
+extern "C" int32_t fd_fcos_decode(const float* cls, int32_t cls_cs, int32_t cls_co, const float* cnt,
+                                  int32_t cnt_cs, int32_t cnt_co, const float* reg, int32_t reg_cs,
+                                  int32_t reg_co, int32_t num_classes, const fd_segs* segs,
+                                  const int32_t* strides, float* scores, int32_t* classes, float* boxes,
+                                  fd_stream_t stream) {
+    FD_REQUIRE(cls && cnt && reg && scores && classes && boxes && strides, FD_E_INVAL, "fd_fcos_decode: null pointer");
+    FD_REQUIRE(fd_segs_ok(segs), FD_E_INVAL, "fd_fcos_decode: bad segment table");
+    FD_REQUIRE(num_classes >= 1, FD_E_INVAL, "fd_fcos_decode: num_classes < 1");
+    FD_REQUIRE(((uintptr_t)boxes & 15) == 0, FD_E_INVAL, "fd_fcos_decode: boxes not 16-byte aligned");
+    DecodeArgs a;
+    a.cls = cls; a.cnt = cnt; a.reg = reg;
+    a.cls_cs = cls_cs; a.cls_co = cls_co; a.cnt_cs = cnt_cs; a.cnt_co = cnt_co; a.reg_cs = reg_cs; a.reg_co = reg_co;
+    a.C = num_classes;
+    a.segs = *segs;
+    int L = 0;
+    for (int s = 0; s < segs->nseg; ++s) {
+        a.loc_start[s] = L;
+        a.stride[s] = strides[s];
+        L += segs->H[s] * segs->W[s];
+    }
+    for (int s = segs->nseg; s < FD_MAX_SEG; ++s) { a.loc_start[s] = L; a.stride[s] = 1; }
+    a.loc_start[FD_MAX_SEG] = L;
+    a.L = L;
+    a.scores = scores; a.classes = classes; a.boxes = boxes;
+    dim3 grid((L + 255) / 256, segs->batch);
+    hipLaunchKernelGGL(decode_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    FD_CHECK_LAUNCH("fd_fcos_decode");
+    return FD_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// top-k: radix select of the K-th largest key, ordered compaction of ties, bitonic sort in LDS
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned fd_order_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// descending bitonic sort of 1024 u64 in LDS by 1024 threads
+__device__ __forceinline__ void bitonic_desc_1024(unsigned long long* c, int tid) {
+    for (int k = 2; k <= 1024; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int ixj = tid ^ j;
+            if (ixj > tid) {
+                const unsigned long long x = c[tid], y = c[ixj];
+                const bool desc = (tid & k) == 0;
+                if (desc ? (x < y) : (x > y)) { c[tid] = y; c[ixj] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ scores, const int* __restrict__ classes,
+                                                     const float* __restrict__ boxes, int L, int K,
+                                                     float* top_scores, long long* top_classes, float* top_boxes,
+                                                     int* top_idx) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_prefix, sh_need, sh_gt, sh_eqbase;
+    __shared__ unsigned wave_cnt[16];
+    __shared__ unsigned long long cand[1024];
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* s = scores + (long)n * L;
+
+    // ---- radix select (MSB first) ----
+    unsigned prefix = 0, maskbits = 0, need = (unsigned)K;
+    for (int pass = 3; pass >= 0; --pass) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const int sh = 8 * pass;
+        for (int i = tid; i < L; i += 1024) {
+            const unsigned key = fd_order_key(s[i]);
+            if ((key & maskbits) == prefix) atomicAdd(&hist[(key >> sh) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0, nd = need;
+            int d = 255;
+            for (; d > 0; --d) {
+                const unsigned h = hist[d];
+                if (cum + h >= nd) break;
+                cum += h;
+            }
+            sh_prefix = prefix | ((unsigned)d << sh);
+            sh_need = nd - cum;
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        need = sh_need;
+        maskbits |= 0xFFu << sh;
+        __syncthreads();
+    }
+    const unsigned T = prefix;              // K-th largest key
+    const unsigned n_gt = (unsigned)K - need;  // keys strictly above T; 'need' ties are taken lowest-index-first
+
+    // ---- compaction ----
+    cand[tid] = 0ull;
+    if (tid == 0) { sh_gt = 0; sh_eqbase = 0; }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int base = 0; base < L; base += 1024) {
+        const int i = base + tid;
+        unsigned key = 0;
+        bool gt = false, eq = false;
+        if (i < L) {
+            key = fd_order_key(s[i]);
+            gt = key > T;
+            eq = key == T;
+        }
+        if (gt) {
+            const unsigned slot = atomicAdd(&sh_gt, 1u);
+            cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        }
+        const unsigned long long bal = __ballot(eq);
+        if (lane == 0) wave_cnt[wv] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = sh_eqbase;
+        for (int w = 0; w < wv; ++w) before += wave_cnt[w];
+        const unsigned rank = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        if (eq && rank < need)
+            cand[n_gt + rank] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        __syncthreads();
+        if (tid == 0) {
+            unsigned tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wave_cnt[w];
+            sh_eqbase += tot;
+        }
+        __syncthreads();
+    }
+
+    // ---- sort (score desc, index asc) ----
+    bitonic_desc_1024(cand, tid);
+
+    if (tid < K) {
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(cand[tid] & 0xFFFFFFFFull);
+        const long o = (long)n * K + tid;
+        const long src = (long)n * L + idx;
+        top_scores[o] = s[idx];
+        top_classes[o] = (long long)classes[src];
+        reinterpret_cast<float4*>(top_boxes)[o] = reinterpret_cast<const float4*>(boxes)[src];
+        if (top_idx) top_idx[o] = (int)idx;
+    }
+}
+
+extern "C" int64_t fd_topk_workspace_bytes(int32_t, int32_t, int32_t) { return 0; }
+
+extern "C" int32_t fd_fcos_topk(const float* scores, const int32_t* classes, const float* boxes, int32_t N,
+                                int32_t L, int32_t K, float* top_scores, int64_t* top_classes, float* top_boxes,
+                                int32_t* top_idx, void*, fd_stream_t stream) {
+    FD_REQUIRE(scores && classes && boxes && top_scores && top_classes && top_boxes, FD_E_INVAL,
+               "fd_fcos_topk: null pointer");
+    FD_REQUIRE(N >= 1 && L >= 1 && K >= 1 && K <= L, FD_E_INVAL, "fd_fcos_topk: need 1 <= K <= L (K=%d L=%d)", K, L);
+    FD_REQUIRE(K <= 1024, FD_E_UNSUPPORTED, "fd_fcos_topk: K=%d > 1024 not supported", K);
+    FD_REQUIRE((((uintptr_t)boxes | (uintptr_t)top_boxes) & 15) == 0, FD_E_INVAL, "fd_fcos_topk: boxes not 16-byte aligned");
+    hipLaunchKernelGGL(topk_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, scores, classes, boxes, L, K,
+                       top_scores, (long long*)top_classes, top_boxes, top_idx);
+    FD_CHECK_LAUNCH("fd_fcos_topk");
+    return FD_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// greedy NMS: suppression bitmask (upper triangle) in LDS, then a wave-level serial scan
+// --------------------------------------------------------------------------------------------
+#define NMS_MAXK 1024
+#define NMS_NW (NMS_MAXK / 64)
+
+struct NmsShared {
+    unsigned long long mask[NMS_MAXK * NMS_NW];  // 128 KiB
+    float4 box[NMS_MAXK];                        // 16 KiB (class-offset boxes)
+    float area[NMS_MAXK];                        // 4 KiB
+    unsigned long long remv[NMS_NW];
+    unsigned long long kept[NMS_NW];
+    float red[16];
+    int n_valid;
+};
+
+// PLUS1 = false: torchvision nms rule, suppress when (double)ovr > thr_d
+// PLUS1 = true : DataEncoder._box_nms rule (utills.py:221-255), suppress when ovr > thr_f ; mode 1 = 'min'
+template <bool PLUS1>
+__device__ __forceinline__ void nms_core(NmsShared& sh, int n, double thr_d, float thr_f, int mode, int tid) {
+    const int nw = (n + 63) >> 6;
+    // ---- suppression mask, upper triangle ----
+    for (int idx = tid; idx < n * nw; idx += 1024) {
+        const int i = idx / nw, w = idx - i * nw;
+        if (w < (i >> 6)) continue;
+        const float4 bi = sh.box[i];
+        const float ai = sh.area[i];
+        unsigned long long bits = 0ull;
+        const int j0 = w << 6;
+        const int jend = min(64, n - j0);
+        for (int b = 0; b < jend; ++b) {
+            const int j = j0 + b;
+            if (j <= i) continue;
+            const float4 bj = sh.box[j];
+            const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+            const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+            float ww, hh;
+            if (PLUS1) { ww = fmaxf((xx2 - xx1) + 1.0f, 0.0f); hh = fmaxf((yy2 - yy1) + 1.0f, 0.0f); }
+            else       { ww = fmaxf(0.0f, xx2 - xx1);          hh = fmaxf(0.0f, yy2 - yy1); }
+            const float inter = ww * hh;
+            float ovr;
+            if (PLUS1 && mode == 1) ovr = inter / fminf(sh.area[j], ai);
+            else                    ovr = inter / ((ai + sh.area[j]) - inter);
+            const bool sup = PLUS1 ? (ovr > thr_f) : ((double)ovr > thr_d);
+            if (sup) bits |= 1ull << b;
+        }
+        sh.mask[i * NMS_NW + w] = bits;
+    }
+    if (tid < NMS_NW) { sh.remv[tid] = 0ull; sh.kept[tid] = 0ull; }
+    __syncthreads();
+
+    // ---- serial scan, one 64-box block at a time ----
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int blk = 0; blk < nw; ++blk) {
+        if (wv == 0) {
+            const int row = (blk << 6) + lane;
+            const unsigned long long diag = (row < n) ? sh.mask[row * NMS_NW + blk] : 0ull;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            const unsigned long long cur0 = sh.remv[blk];
+            unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)cur0);
+            unsigned chi = __builtin_amdgcn_readfirstlane((unsigned)(cur0 >> 32));
+            const int nb = min(64, n - (blk << 6));
+            unsigned klo = 0, khi = 0;
+#pragma unroll
+            for (int b = 0; b < 32; ++b) {
+                if (b < nb && !((clo >> b) & 1u)) {
+                    klo |= 1u << b;
+                    clo |= __builtin_amdgcn_readlane(dlo, b);
+                    chi |= __builtin_amdgcn_readlane(dhi, b);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 32; ++b) {
+                if (b + 32 < nb && !((chi >> b) & 1u)) {
+                    khi |= 1u << b;
+                    chi |= __builtin_amdgcn_readlane(dhi, b + 32);
+                }
+            }
+            if (lane == 0) sh.kept[blk] = ((unsigned long long)khi << 32) | klo;
+        }
+        __syncthreads();
+        // OR the rows of the kept boxes of this block into the later words: wave w handles word w
+        if (wv > blk && wv < nw) {
+            const unsigned long long k = sh.kept[blk];
+            const int row = (blk << 6) + lane;
+            unsigned long long v = ((k >> lane) & 1ull) ? sh.mask[row * NMS_NW + wv] : 0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned lo = __shfl_xor((unsigned)v, o);
+                const unsigned hi = __shfl_xor((unsigned)(v >> 32), o);
+                v |= ((unsigned long long)hi << 32) | lo;
+            }
+            if (lane == 0) sh.remv[wv] |= v;
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int nms_rank(const NmsShared& sh, int r) {
+    int rank = 0;
+    const int w = r >> 6;
+    for (int q = 0; q < w; ++q) rank += __popcll(sh.kept[q]);
+    rank += __popcll(sh.kept[w] & ((1ull << (r & 63)) - 1ull));
+    return rank;
+}
+
+__global__ __launch_bounds__(1024) void batched_nms_kernel(const float* __restrict__ scores,
+                                                            const long long* __restrict__ classes,
+                                                            const float* __restrict__ boxes, int K, float score_thr,
+                                                            double iou_thr, float* out_scores, long long* out_classes,
+                                                            float* out_boxes, int* keep_idx, int* counts) {
+    __shared__ NmsShared sh;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const long base = (long)img * K;
+    const int lane = tid & 63, wv = tid >> 6;
+
+    // valid prefix: rows are score-descending, so {score >= thr} is [0, n)
+    float sc = 0.f;
+    bool ok = false;
+    if (tid < K) { sc = scores[base + tid]; ok = sc >= score_thr; }
+    if (tid == 0) sh.n_valid = 0;
+    __syncthreads();
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0 && bal) atomicAdd(&sh.n_valid, __popcll(bal));
+    __syncthreads();
+    const int n = sh.n_valid;
+
+    // boxes.max() over the masked boxes (torchvision _batched_nms_coordinate_trick)
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mx = -INFINITY;
+    if (tid < n) {
+        bx = reinterpret_cast<const float4*>(boxes)[base + tid];
+        mx = fmaxf(fmaxf(bx.x, bx.y), fmaxf(bx.z, bx.w));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) sh.red[wv] = mx;
+    __syncthreads();
+    float maxc = sh.red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) maxc = fmaxf(maxc, sh.red[w]);
+    long long cl = 0;
+    if (tid < n) {
+        cl = classes[base + tid];
+        const float off = (float)cl * (maxc + 1.0f);
+        const float4 ob = make_float4(bx.x + off, bx.y + off, bx.z + off, bx.w + off);
+        sh.box[tid] = ob;
+        sh.area[tid] = (ob.z - ob.x) * (ob.w - ob.y);
+    }
+    __syncthreads();
+
+    if (n > 0) nms_core<false>(sh, n, iou_thr, 0.f, 0, tid);
+
+    // ---- ordered compaction + gathers; rows >= count are zero-filled ----
+    int total = 0;
+    if (n > 0) {
+        const int nw = (n + 63) >> 6;
+        for (int q = 0; q < nw; ++q) total += __popcll(sh.kept[q]);
+    }
+    if (tid < n && ((sh.kept[tid >> 6] >> (tid & 63)) & 1ull)) {
+        const int r = nms_rank(sh, tid);
+        out_scores[base + r] = sc;
+        out_classes[base + r] = cl;
+        reinterpret_cast<float4*>(out_boxes)[base + r] = bx;
+        keep_idx[base + r] = tid;
+    }
+    if (tid < K && tid >= total) {
+        out_scores[base + tid] = 0.f;
+        out_classes[base + tid] = 0;
+        reinterpret_cast<float4*>(out_boxes)[base + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        keep_idx[base + tid] = -1;
+    }
+    if (tid == 0) counts[img] = total;
+}
+
+extern "C" int32_t fd_batched_nms(const float* scores, const int64_t* classes, const float* boxes, int32_t N,
+                                  int32_t K, float score_thr, double iou_thr, float* out_scores,
+                                  int64_t* out_classes, float* out_boxes, int32_t* keep_idx, int32_t* counts,
+                                  fd_stream_t stream) {
+    FD_REQUIRE(scores && classes && boxes && out_scores && out_classes && out_boxes && keep_idx && counts,
+               FD_E_INVAL, "fd_batched_nms: null pointer");
+    FD_REQUIRE(N >= 1 && K >= 1, FD_E_INVAL, "fd_batched_nms: N=%d K=%d", N, K);
+    FD_REQUIRE(K <= NMS_MAXK, FD_E_UNSUPPORTED, "fd_batched_nms: K=%d > %d not supported", K, NMS_MAXK);
+    FD_REQUIRE((((uintptr_t)boxes | (uintptr_t)out_boxes) & 15) == 0, FD_E_INVAL, "fd_batched_nms: boxes not 16-byte aligned");
+    hipLaunchKernelGGL(batched_nms_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, scores,
+                       (const long long*)classes, boxes, K, score_thr, iou_thr, out_scores, (long long*)out_classes,
+                       out_boxes, keep_idx, counts);
+    FD_CHECK_LAUNCH("fd_batched_nms");
+    return FD_OK;
+}
+
+// DataEncoder._box_nms: sort by score (desc, ties lower index), "+1" areas, keep while ovr <= thr
+__global__ __launch_bounds__(1024) void box_nms_plus1_kernel(const float* __restrict__ boxes,
+                                                              const float* __restrict__ scores,
+                                                              const int* __restrict__ n_valid, int K, float thr,
+                                                              int mode, int* keep_idx, int* counts) {
+    __shared__ NmsShared sh;
+    __shared__ unsigned long long order[1024];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const long base = (long)img * K;
+    int n = n_valid ? n_valid[img] : K;
+    n = max(0, min(n, K));
+    order[tid] = (tid < n) ? (((unsigned long long)fd_order_key(scores[base + tid]) << 32) |
+                              (unsigned long long)(0xFFFFFFFFu - (unsigned)tid))
+                           : 0ull;
+    __syncthreads();
+    bitonic_desc_1024(order, tid);
+    int src = -1;
+    if (tid < n) {
+        src = (int)(0xFFFFFFFFu - (unsigned)(order[tid] & 0xFFFFFFFFull));
+        const float4 b = reinterpret_cast<const float4*>(boxes)[base + src];
+        sh.box[tid] = b;
+        sh.area[tid] = ((b.z - b.x) + 1.0f) * ((b.w - b.y) + 1.0f);
+    }
+    __syncthreads();
+    if (n > 0) nms_core<true>(sh, n, 0.0, thr, mode, tid);
+    int total = 0;
+    if (n > 0) {
+        const int nw = (n + 63) >> 6;
+        for (int q = 0; q < nw; ++q) total += __popcll(sh.kept[q]);
+    }
+    if (tid < n && ((sh.kept[tid >> 6] >> (tid & 63)) & 1ull)) keep_idx[base + nms_rank(sh, tid)] = src;
+    if (tid < K && tid >= total) keep_idx[base + tid] = -1;
+    if (tid == 0) counts[img] = total;
+}
+
+extern "C" int32_t fd_box_nms_plus1(const float* boxes, const float* scores, const int32_t* n_valid, int32_t N,
+                                    int32_t K, float thr, int32_t mode, int32_t* keep_idx, int32_t* counts,
+                                    fd_stream_t stream) {
+    FD_REQUIRE(boxes && scores && keep_idx && counts, FD_E_INVAL, "fd_box_nms_plus1: null pointer");
+    FD_REQUIRE(N >= 1 && K >= 1, FD_E_INVAL, "fd_box_nms_plus1: N=%d K=%d", N, K);
+    FD_REQUIRE(K <= NMS_MAXK, FD_E_UNSUPPORTED, "fd_box_nms_plus1: K=%d > %d not supported", K, NMS_MAXK);
+    FD_REQUIRE(mode == 0 || mode == 1, FD_E_INVAL, "fd_box_nms_plus1: mode must be 0 ('union') or 1 ('min')");
+    FD_REQUIRE(((uintptr_t)boxes & 15) == 0, FD_E_INVAL, "fd_box_nms_plus1: boxes not 16-byte aligned");
+    hipLaunchKernelGGL(box_nms_plus1_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, boxes, scores, n_valid,
+                       K, thr, mode, keep_idx, counts);
+    FD_CHECK_LAUNCH("fd_box_nms_plus1");
+    return FD_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// pairwise IoU, clip
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pairwise_iou_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                            int Na, int Nb, int plus_one, float* out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= Nb) return;
+    const float p = plus_one ? 1.0f : 0.0f;
+    const float4 x = a[i], y = b[j];
+    const float ltx = fmaxf(x.x, y.x), lty = fmaxf(x.y, y.y);
+    const float rbx = fminf(x.z, y.z), rby = fminf(x.w, y.w);
+    const float w = fmaxf((rbx - ltx) + p, 0.0f), h = fmaxf((rby - lty) + p, 0.0f);
+    const float inter = w * h;
+    const float a1 = ((x.z - x.x) + p) * ((x.w - x.y) + p);
+    const float a2 = ((y.z - y.x) + p) * ((y.w - y.y) + p);
+    out[(long)i * Nb + j] = inter / ((a1 + a2) - inter);
+}
+
+extern "C" int32_t fd_pairwise_iou(const float* a, const float* b, int32_t Na, int32_t Nb, int32_t plus_one,
+                                   float* out, fd_stream_t stream) {
+    FD_REQUIRE(a && b && out, FD_E_INVAL, "fd_pairwise_iou: null pointer");
+    FD_REQUIRE(Na >= 1 && Nb >= 1 && Na <= 65535, FD_E_INVAL, "fd_pairwise_iou: Na=%d Nb=%d", Na, Nb);
+    FD_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 15) == 0, FD_E_INVAL, "fd_pairwise_iou: boxes not 16-byte aligned");
+    hipLaunchKernelGGL(pairwise_iou_kernel, dim3((Nb + 255) / 256, Na), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)a, (const float4*)b, Na, Nb, plus_one, out);
+    FD_CHECK_LAUNCH("fd_pairwise_iou");
+    return FD_OK;
+}
+
+__global__ __launch_bounds__(256) void clip_kernel(float4* boxes, long n, float xmax, float ymax) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 b = boxes[i];
+    b.x = fminf(fmaxf(b.x, 0.f), xmax);
+    b.y = fminf(fmaxf(b.y, 0.f), ymax);
+    b.z = fminf(fmaxf(b.z, 0.f), xmax);
+    b.w = fminf(fmaxf(b.w, 0.f), ymax);
+    boxes[i] = b;
+}
+
+extern "C" int32_t fd_clip_boxes(float* boxes, int64_t n_boxes, int32_t img_h, int32_t img_w, fd_stream_t stream) {
+    FD_REQUIRE(boxes, FD_E_INVAL, "fd_clip_boxes: null pointer");
+    FD_REQUIRE(((uintptr_t)boxes & 15) == 0, FD_E_INVAL, "fd_clip_boxes: boxes not 16-byte aligned");
+    if (n_boxes <= 0) return FD_OK;
+    hipLaunchKernelGGL(clip_kernel, dim3((unsigned)((n_boxes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (float4*)boxes, (long)n_boxes, (float)(img_w - 1), (float)(img_h - 1));
+    FD_CHECK_LAUNCH("fd_clip_boxes");
+    return FD_OK;
+}

@@ -1,0 +1,138 @@
+"""The oracle (oracle/torch_ref.py + oracle/postproc_ref.c) pinned against golden vectors generated from the
+real reference by tests/golden/make_golden.py.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+
+torch.set_num_threads(4)
+
+
+def _sd(npz, prefix="sd."):
+    return {k[len(prefix):]: torch.from_numpy(npz[k]) for k in npz.files if k.startswith(prefix)}
+
+
+def test_g1_coords(golden):
+    g = golden("g1_coords")
+    for key in [k for k in g.files if not k.endswith("_hw")]:
+        h, w = g[key + "_hw"]
+        stride = int(key.split("_s")[1])
+        np.testing.assert_array_equal(R.coords_fcos(int(h), int(w), stride), g[key])
+
+
+@pytest.mark.parametrize("ncls", [20, 80])
+@pytest.mark.parametrize("tag", ["s5", "s4"])
+def test_g2_decode_topk(golden, ncls, tag):
+    g = golden("g2_decode_topk")
+    strides = [int(s) for s in g[f"c{ncls}_{tag}_strides"]]
+    cls = [torch.from_numpy(g[f"c{ncls}_cls{i}"]) for i in range(5)]
+    cnt = [torch.from_numpy(g[f"c{ncls}_cnt{i}"]) for i in range(5)]
+    reg = [torch.from_numpy(g[f"c{ncls}_reg{i}"]) for i in range(5)]
+    n = len(strides)
+    coords = np.concatenate([R.coords_fcos(c.shape[2], c.shape[3], s) for c, s in zip(cls, strides)], 0)
+    scores, classes, boxes = R.decode(R.flatten_levels(cls, n), R.flatten_levels(cnt, n), R.flatten_levels(reg, n), coords)
+    k = min(100, scores.shape[1])
+    idx = R.topk(scores, k)
+    for b in range(scores.shape[0]):
+        np.testing.assert_allclose(scores[b][idx[b]], g[f"c{ncls}_{tag}_scores"][b], rtol=2e-6, atol=1e-7)
+        np.testing.assert_array_equal(classes[b][idx[b]], g[f"c{ncls}_{tag}_classes"][b])
+        np.testing.assert_array_equal(boxes[b][idx[b]], g[f"c{ncls}_{tag}_boxes"][b])
+
+
+def test_g3_batched_nms_kept_indices(golden):
+    g = golden("g3_nms")
+    for c in range(int(g["n_batched"])):
+        keep = R.batched_nms(g[f"b{c}_boxes"], g[f"b{c}_scores"], g[f"b{c}_classes"], float(g[f"b{c}_thr"]))
+        np.testing.assert_array_equal(keep, g[f"b{c}_keep"], err_msg=f"case {c}")
+    keep = R.batched_nms(g["edge_boxes"], g["edge_scores"], g["edge_classes"], 0.5)
+    np.testing.assert_array_equal(keep, g["edge_keep_0.5"])
+    np.testing.assert_array_equal(keep, [0, 1, 2, 4])  # IoU == 0.5 exactly is kept; duplicates are suppressed
+
+
+def test_g3_box_nms_plus1(golden):
+    g = golden("g3_nms")
+    for c in range(int(g["n_plus1"])):
+        keep = R.box_nms_plus1(g[f"p{c}_boxes"], g[f"p{c}_scores"], float(g[f"p{c}_thr"]),
+                               "union" if int(g[f"p{c}_mode"]) == 0 else "min")
+        np.testing.assert_array_equal(keep, g[f"p{c}_keep"], err_msg=f"case {c}")
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_g3b_head_end_to_end(golden, ci):
+    g = golden("g3b_head_end2end")
+    sthr, thr, maxbox = g[f"e{ci}_cfg"]
+    outs = [[torch.from_numpy(g[f"e{ci}_{n}{i}"]) for i in range(5)] for n in ("cls", "cnt", "reg")]
+    (s, c, b), = R.fcos_detect(outs, [8, 16, 32, 64, 128], float(sthr), float(thr), int(maxbox))
+    np.testing.assert_allclose(s, g[f"e{ci}_scores"][0], rtol=2e-6, atol=1e-7)
+    np.testing.assert_array_equal(c, g[f"e{ci}_classes"][0])
+    np.testing.assert_array_equal(b, g[f"e{ci}_boxes"][0])
+    np.testing.assert_array_equal(R.clip_boxes(b, 128, 128), g[f"e{ci}_clipped"][0])
+
+
+def test_g4_pairwise_iou(golden):
+    g = golden("g4_pairwise_iou")
+    np.testing.assert_array_equal(R.pairwise_iou(g["a"], g["b"], True), g["iou_plus1"])
+
+
+@pytest.mark.parametrize("mode", ["iou", "giou"])
+@pytest.mark.parametrize("P", [0, 1, 257])
+def test_g5_ltrb_loss(golden, mode, P):
+    g = golden("g5_ltrb_loss")
+    p = torch.from_numpy(g[f"P{P}_pred"]).requires_grad_(True)
+    fn = R.iou_loss if mode == "iou" else R.giou_loss
+    l = fn(p, torch.from_numpy(g[f"P{P}_tgt"]))
+    np.testing.assert_allclose(l.detach().numpy(), g[f"P{P}_{mode}_loss"], rtol=1e-6)
+    if P:
+        l.backward()
+        np.testing.assert_allclose(p.grad.numpy(), g[f"P{P}_{mode}_grad"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["voc_his", "voc_fcos"])
+def test_g67_targets_and_loss(golden, name):
+    g = golden("g67_targets_loss")
+    np.testing.assert_allclose(g["kat_cnt_loss"], [0.3133, 0.3133], atol=5e-5)  # reference loss.py:218-221
+    outs = [[torch.from_numpy(g[f"{name}_{n}{i}"]) for i in range(5)] for n in ("cls", "cnt", "reg")]
+    hw = [tuple(o.shape[2:]) for o in outs[0]]
+    tg = R.gen_targets(hw, [int(s) for s in g["strides"]], g[f"{name}_ranges"].tolist(),
+                       torch.from_numpy(g["gt"]), torch.from_numpy(g["labels"]))
+    np.testing.assert_array_equal(tg[0].numpy(), g[f"{name}_cls_t"])
+    np.testing.assert_allclose(tg[1].numpy(), g[f"{name}_cnt_t"], rtol=1e-6)
+    np.testing.assert_array_equal(tg[2].numpy(), g[f"{name}_reg_t"])
+    for mode in ("giou", "iou"):
+        leaves = [[t.clone().requires_grad_(True) for t in grp] for grp in outs]
+        res = R.fcos_loss(leaves, tg, mode)
+        np.testing.assert_allclose([float(r.detach()) for r in res], g[f"{name}_{mode}_losses"], rtol=2e-6)
+        res[3].backward()
+        for i in range(5):
+            np.testing.assert_allclose(leaves[0][i].grad.numpy(), g[f"{name}_{mode}_gcls{i}"], rtol=1e-5, atol=1e-8)
+            np.testing.assert_allclose(leaves[1][i].grad.numpy(), g[f"{name}_{mode}_gcnt{i}"], rtol=1e-5, atol=1e-8)
+            np.testing.assert_allclose(leaves[2][i].grad.numpy(), g[f"{name}_{mode}_greg{i}"], rtol=1e-5, atol=1e-8)
+
+
+def test_g8_tiny_hisfcos(golden):
+    g = golden("g8_tiny_hisfcos")
+    sd = _sd(g)
+    feats = [torch.from_numpy(g[k]) for k in ("c3", "c4", "c5")]
+    with torch.no_grad():
+        ps = R.his_fpn(sd, feats)
+        cls, cnt, reg = R.his_head(sd, ps)
+    for i in range(5):
+        np.testing.assert_allclose(ps[i].numpy(), g[f"p{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(cls[i].numpy(), g[f"cls{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(cnt[i].numpy(), g[f"cnt{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(reg[i].numpy(), g[f"reg{i}"], rtol=1e-5, atol=1e-5)
+
+
+def test_g8_tiny_fcos(golden):
+    g = golden("g8_tiny_fcos")
+    sd = _sd(g)
+    feats = [torch.from_numpy(g[k]) for k in ("c3", "c4", "c5")]
+    with torch.no_grad():
+        ps = R.fcos_fpn(sd, feats)
+        cls, cnt, reg = R.fcos_head(sd, ps)
+    for i in range(5):
+        np.testing.assert_allclose(ps[i].numpy(), g[f"p{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(cls[i].numpy(), g[f"cls{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(cnt[i].numpy(), g[f"cnt{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(reg[i].numpy(), g[f"reg{i}"], rtol=1e-5, atol=1e-5)
