@@ -1,0 +1,101 @@
+"""ctypes binding of libfcosdet_hip.so (include/fcosdet.h).  Loading fails loudly; there is no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+FD_MAX_SEG = 8
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_EXP, ACT_SIGMOID = 0, 1, 2, 3, 4
+CONV_GENERIC, CONV_STEM = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfcosdet_hip.so")
+
+
+class FdError(RuntimeError):
+    pass
+
+
+class Segs(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("batch", C.c_int32), ("H", C.c_int32 * FD_MAX_SEG), ("W", C.c_int32 * FD_MAX_SEG),
+                ("m_start", C.c_int32 * (FD_MAX_SEG + 1))]
+
+    @staticmethod
+    def make(batch: int, hw) -> "Segs":
+        s = Segs()
+        s.nseg, s.batch = len(hw), batch
+        m = 0
+        for i, (h, w) in enumerate(hw):
+            s.H[i], s.W[i], s.m_start[i] = h, w, m
+            m += batch * h * w
+        for i in range(len(hw), FD_MAX_SEG + 1):
+            s.m_start[i] = m
+        return s
+
+    @property
+    def rows(self) -> int:
+        return self.m_start[self.nseg]
+
+    def level_hw(self):
+        return [(self.H[i], self.W[i]) for i in range(self.nseg)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("res", C.c_void_p),
+                ("y", C.c_void_p),
+                ("x_cs", C.c_int32), ("x_co", C.c_int32), ("res_cs", C.c_int32), ("res_co", C.c_int32),
+                ("y_cs", C.c_int32), ("y_co", C.c_int32),
+                ("Cin", C.c_int32), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
+                ("pad", C.c_int32), ("dil", C.c_int32),
+                ("act", C.c_int32), ("act_c0", C.c_int32), ("mode", C.c_int32),
+                ("seg_param", C.c_float * FD_MAX_SEG), ("segs", Segs)]
+
+
+_lib = None
+
+_P, _I, _F, _D, _L = C.c_void_p, C.c_int32, C.c_float, C.c_double, C.c_int64
+_SIGS = {
+    "fd_version": (_I, []),
+    "fd_last_error": (C.c_char_p, []),
+    "fd_conv2d_nhwc_f32": (_I, [C.POINTER(ConvParams), _P]),
+    "fd_nchw3_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _P]),
+    "fd_nhwc_to_nchw": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),
+    "fd_maxpool_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fd_upsample2x_add_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fd_dwconv3x3_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(Segs), _P]),
+    "fd_groupnorm_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
+    "fd_groupnorm_act_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _I, C.POINTER(Segs), _P, _P]),
+    "fd_se_workspace_bytes": (_L, [_I, _I, _I]),
+    "fd_se_scale_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "fd_fcos_decode": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, C.POINTER(Segs), C.POINTER(_I), _P, _P, _P, _P]),
+    "fd_topk_workspace_bytes": (_L, [_I, _I, _I]),
+    "fd_fcos_topk": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "fd_batched_nms": (_I, [_P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P, _P]),
+    "fd_box_nms_plus1": (_I, [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P]),
+    "fd_pairwise_iou": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "fd_clip_boxes": (_I, [_P, _L, _I, _I, _P]),
+    "fd_ltrb_iou_loss_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "fd_ltrb_iou_loss_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib() -> C.CDLL:
+    """Load libfcosdet_hip.so once.  Raises FdError when it has not been built (python __graft_entry__.py / make)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FdError(f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = lib().fd_last_error().decode(errors="replace")
+        raise FdError(f"{what or 'libfcosdet_hip'} failed ({code}): {msg}")

@@ -1,0 +1,262 @@
+// fd_conv.hip — implicit-GEMM convolution for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32).
+//
+//   C[m][n] = sum_k A[m][k] * B[n][k]      m = output pixel (NHWC row), n = output channel,
+//                                          k = (r*KW + q)*Cin + c  (filter tap major, channel minor)
+//   A is gathered on the fly from the NHWC input (zero outside the image), B is the weight tensor packed
+//   [Cout][KH][KW][Cin].  Both operands are staged as [rows][32 k] tiles in LDS (16-byte chunks XOR-swizzled
+//   by (row>>1)&7, conflict-free for ds_read_b128 and ds_write_b128), global->register->LDS double buffered:
+//   the loads of k-tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after.
+//   Each of the 4 waves owns TM x TN sub-tiles of 32x32 (16 accumulator VGPRs each); a ds_read_b128 hands a
+//   lane 4 consecutive k of one row, consumed by 4 MFMAs (lanes 0-31 carry k, lanes 32-63 carry k+4).
+//   Epilogue: y = act(acc*scale[n] + shift[n] + res), columns (n) on lanes -> 128-byte coalesced NHWC stores.
+//
+// Replaces nn.Conv2d(+BatchNorm2d eval)+ReLU/SiLU(+add) of the reference models (see include/fcosdet.h).
+#include "fd_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float* x; const float* w; const float* scale; const float* shift; const float* res; float* y;
+    int x_cs, x_co, res_cs, res_co, y_cs, y_co;
+    int Cin, Cout, KW, stride, pad, dil, act, act_c0;
+    int M, KT, ctiles, Kpacked;
+    int nseg;
+    int H[FD_MAX_SEG], W[FD_MAX_SEG], Ho[FD_MAX_SEG], Wo[FD_MAX_SEG];
+    int m_in[FD_MAX_SEG];        // first input row of the segment
+    int m_out[FD_MAX_SEG + 1];   // first output row of the segment
+    float seg_param[FD_MAX_SEG];
+    int mtiles, ntiles;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+template <int WGM, int WGN, int TM, int TN, bool STEM>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int AP = BM / 32, BP = BN / 32;  // loader passes (32 rows x 8 chunks per pass)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);  // [2][BM*32]
+    float* Bs = As + 2 * BM * 32;                // [2][BN*32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // XCD-aware tile order: blocks dealt round-robin over 8 XCDs -> give each XCD a contiguous tile range
+    const int nblk = a.mtiles * a.ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / a.ntiles, nt = bid - mt * a.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- per-thread A rows: decode (segment, image, ho, wo) once ----
+    const int lrow = tid >> 3, chunk = tid & 7;
+    int a_base[AP], a_hi0[AP], a_wi0[AP], a_H[AP], a_W[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        int s = 0;
+#pragma unroll
+        for (int t = 1; t < FD_MAX_SEG; ++t)
+            if (t < a.nseg && m >= a.m_out[t]) s = t;
+        const int Ho = a.Ho[s], Wo = a.Wo[s], H = a.H[s], W = a.W[s];
+        const int local = m - a.m_out[s];
+        const int hw = Ho * Wo;
+        const int n = local / hw;
+        const int rem = local - n * hw;
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        a_base[i] = a.m_in[s] + n * H * W;
+        a_hi0[i] = ho * a.stride - a.pad;
+        a_wi0[i] = wo * a.stride - a.pad;
+        a_H[i] = (m < a.M) ? H : 0;  // H = 0 makes every tap invalid for rows past M
+        a_W[i] = W;
+    }
+    const float* b_ptr[BP];
+    bool b_ok[BP];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+        const int n = n0 + lrow + 32 * j;
+        b_ok[j] = n < a.Cout;
+        b_ptr[j] = a.w + (size_t)(b_ok[j] ? n : 0) * a.Kpacked + chunk * 4;
+    }
+
+    float4 ra[AP], rb[BP];
+    auto load_tile = [&](int kt) {
+        int r, q, c0;
+        if (STEM) { r = kt; q = chunk; c0 = 0; }
+        else {
+            const int tap = kt / a.ctiles;
+            c0 = (kt - tap * a.ctiles) * 32 + chunk * 4;
+            r = tap / a.KW;
+            q = tap - r * a.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int hi = a_hi0[i] + r * a.dil, wi = a_wi0[i] + q * a.dil;
+            bool ok = (unsigned)hi < (unsigned)a_H[i] && (unsigned)wi < (unsigned)a_W[i];
+            if (STEM) ok = ok && (chunk < 7);
+            const unsigned off = (unsigned)(a_base[i] + hi * a_W[i] + wi) * (unsigned)a.x_cs + (unsigned)(a.x_co + c0);
+            ra[i] = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j)
+            rb[j] = b_ok[j] ? *reinterpret_cast<const float4*>(b_ptr[j] + kt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+            *reinterpret_cast<float4*>(As + buf * BM * 32 + lds_off(lrow + 32 * i, chunk)) = ra[i];
+#pragma unroll
+        for (int j = 0; j < BP; ++j)
+            *reinterpret_cast<float4*>(Bs + buf * BN * 32 + lds_off(lrow + 32 * j, chunk)) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < a.KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < a.KT) load_tile(kt + 1);
+        const float* Ab = As + buf * BM * 32 + (wm * TM * 32) * 32;
+        const float* Bb = Bs + buf * BN * 32 + (wn * TN * 32) * 32;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(Ab + lds_off(i * 32 + l31, 2 * s + lh));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(Bb + lds_off(j * 32 + l31, 2 * s + lh));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < a.KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc reg e of lane l is C[row = (e&3) + 8*(e>>2) + 4*(l>>5)][col = l&31] ----
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + l31;
+        const bool n_ok = n < a.Cout;
+        const float sc = (a.scale && n_ok) ? a.scale[n] : 1.0f;
+        const float sf = (a.shift && n_ok) ? a.shift[n] : 0.0f;
+        const int act = (n >= a.act_c0) ? a.act : FD_ACT_NONE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (n_ok && m < a.M) {
+                    float v = acc[i][j][e] * sc + sf;
+                    if (a.res) v += a.res[(size_t)m * a.res_cs + a.res_co + n];
+                    float p = 0.f;
+                    if (act == FD_ACT_EXP) {
+                        int s = 0;
+#pragma unroll
+                        for (int t = 1; t < FD_MAX_SEG; ++t)
+                            if (t < a.nseg && m >= a.m_out[t]) s = t;
+                        p = a.seg_param[s];
+                    }
+                    a.y[(size_t)m * a.y_cs + a.y_co + n] = fd_act(v, act, p);
+                }
+            }
+        }
+    }
+}
+
+template <int WGM, int WGN, int TM, int TN, bool STEM>
+static int launch_conv(const ConvArgs& a, hipStream_t stream) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int lds = 2 * (BM + BN) * 32 * 4;
+    ConvArgs b = a;
+    b.mtiles = (a.M + BM - 1) / BM;
+    b.ntiles = (a.Cout + BN - 1) / BN;
+    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles), dim3(256), lds, stream, b);
+    FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32");
+    return FD_OK;
+}
+
+extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FD_REQUIRE(p && p->x && p->w && p->y, FD_E_INVAL, "fd_conv2d: null pointer");
+    FD_REQUIRE(fd_segs_ok(&p->in), FD_E_INVAL, "fd_conv2d: bad segment table");
+    const bool stem = p->mode == FD_CONV_STEM;
+    FD_REQUIRE(p->Cout >= 1 && p->KH >= 1 && p->KW >= 1 && p->stride >= 1 && p->dil >= 1 && p->pad >= 0, FD_E_INVAL,
+               "fd_conv2d: bad geometry");
+    if (stem) {
+        FD_REQUIRE(p->KH == 7 && p->KW == 7 && p->stride == 2 && p->pad == 3 && p->dil == 1 && p->in.nseg == 1 &&
+                       p->x_cs == 4 && p->x_co == 0,
+                   FD_E_INVAL, "fd_conv2d: stem mode needs 7x7 s2 p3 on an [N][H][W][4] input");
+    } else {
+        FD_REQUIRE(p->Cin >= 32 && p->Cin % 32 == 0, FD_E_UNSUPPORTED, "fd_conv2d: Cin=%d must be a multiple of 32", p->Cin);
+        FD_REQUIRE(p->x_cs % 4 == 0 && p->x_co % 4 == 0 && p->x_cs >= p->x_co + p->Cin, FD_E_INVAL,
+                   "fd_conv2d: input channel view (cs=%d co=%d Cin=%d) must be 4-aligned and in range", p->x_cs, p->x_co, p->Cin);
+    }
+    FD_REQUIRE((((uintptr_t)p->x | (uintptr_t)p->w) & 15) == 0, FD_E_INVAL, "fd_conv2d: x / w not 16-byte aligned");
+    FD_REQUIRE(p->y_cs >= p->y_co + p->Cout, FD_E_INVAL, "fd_conv2d: output channel view out of range");
+    FD_REQUIRE(!p->res || p->res_cs >= p->res_co + p->Cout, FD_E_INVAL, "fd_conv2d: residual channel view out of range");
+    if (p->in.nseg > 1)
+        FD_REQUIRE(p->stride == 1 && 2 * p->pad == p->dil * (p->KH - 1) && p->KH == p->KW, FD_E_INVAL,
+                   "fd_conv2d: multi-level input needs stride 1 and 'same' padding");
+
+    ConvArgs a;
+    a.x = p->x; a.w = p->w; a.scale = p->scale; a.shift = p->shift; a.res = p->res; a.y = p->y;
+    a.x_cs = p->x_cs; a.x_co = p->x_co; a.res_cs = p->res_cs; a.res_co = p->res_co; a.y_cs = p->y_cs; a.y_co = p->y_co;
+    a.Cin = p->Cin; a.Cout = p->Cout; a.KW = p->KW; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;
+    a.act = p->act; a.act_c0 = p->act_c0;
+    a.nseg = p->in.nseg;
+    long mo = 0;
+    for (int s = 0; s < FD_MAX_SEG; ++s) {
+        if (s < p->in.nseg) {
+            a.H[s] = p->in.H[s]; a.W[s] = p->in.W[s];
+            a.Ho[s] = (p->in.H[s] + 2 * p->pad - p->dil * (p->KH - 1) - 1) / p->stride + 1;
+            a.Wo[s] = (p->in.W[s] + 2 * p->pad - p->dil * (p->KW - 1) - 1) / p->stride + 1;
+            FD_REQUIRE(a.Ho[s] >= 1 && a.Wo[s] >= 1, FD_E_INVAL, "fd_conv2d: empty output");
+            a.m_in[s] = p->in.m_start[s];
+            a.m_out[s] = (int)mo;
+            mo += (long)p->in.batch * a.Ho[s] * a.Wo[s];
+        } else {
+            a.H[s] = a.W[s] = a.Ho[s] = a.Wo[s] = 1; a.m_in[s] = 0; a.m_out[s] = (int)mo;
+        }
+        a.seg_param[s] = p->seg_param[s];
+    }
+    a.m_out[FD_MAX_SEG] = (int)mo;
+    FD_REQUIRE(mo > 0 && mo < (1L << 31), FD_E_INVAL, "fd_conv2d: row count out of range");
+    a.M = (int)mo;
+    FD_REQUIRE((long)p->in.m_start[p->in.nseg] * p->x_cs < (1L << 31) && mo * p->y_cs < (1L << 31), FD_E_UNSUPPORTED,
+               "fd_conv2d: tensor exceeds 2^31 elements");
+    if (stem) { a.KT = 7; a.ctiles = 1; a.Kpacked = 7 * 32; }
+    else { a.ctiles = p->Cin / 32; a.KT = p->KH * p->KW * a.ctiles; a.Kpacked = p->KH * p->KW * p->Cin; }
+    a.mtiles = a.ntiles = 0;
+
+    if (stem) return launch_conv<2, 2, 2, 1, true>(a, stream);       // 128 x 64
+    if (a.Cout <= 32) return launch_conv<4, 1, 1, 1, false>(a, stream);   // 128 x 32
+    if (a.Cout <= 64) return launch_conv<2, 2, 2, 1, false>(a, stream);   // 128 x 64
+    if (a.M <= 2048) return launch_conv<2, 2, 1, 2, false>(a, stream);    // 64 x 128: more blocks for tiny maps
+    return launch_conv<2, 2, 2, 2, false>(a, stream);                     // 128 x 128
+}

@@ -1,0 +1,432 @@
+// fd_layers.hip — HBM-bound layer ops of the FCOS / HISFCOS stack on NHWC fp32 rows (gfx950).
+// All kernels move 16 bytes per lane (float4 over channels), rows x channel-quads flattened so that a wave
+// reads/writes contiguous 1 KiB spans.  See include/fcosdet.h for the reference call sites each replaces.
+#include "fd_common.h"
+
+#define FD_GRID_CAP 16384
+
+static inline unsigned grid_for(long work, int block) {
+    long g = (work + block - 1) / block;
+    if (g > FD_GRID_CAP) g = FD_GRID_CAP;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ------------------------------------------------------------------------------ layout converters
+__global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float4* __restrict__ y,
+                                                              int HW, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / HW;
+        const long p = i - n * HW;
+        const float* b = x + n * 3 * HW + p;
+        y[i] = make_float4(b[0], b[HW], b[2 * (long)HW], 0.f);
+    }
+}
+
+extern "C" int32_t fd_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, fd_stream_t stream) {
+    FD_REQUIRE(x && y && N >= 1 && H >= 1 && W >= 1, FD_E_INVAL, "fd_nchw3_to_nhwc4: bad argument");
+    FD_REQUIRE(((uintptr_t)y & 15) == 0, FD_E_INVAL, "fd_nchw3_to_nhwc4: y not 16-byte aligned");
+    const long total = (long)N * H * W;
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (float4*)y, H * W, total);
+    FD_CHECK_LAUNCH("fd_nchw3_to_nhwc4");
+    return FD_OK;
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, int x_cs, int x_co,
+                                                            float* __restrict__ y, int HW, int C) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (p < HW && c < C) ? x[((long)n * HW + p) * x_cs + x_co + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) y[((long)n * C + c) * HW + p] = tile[tx][r];
+    }
+}
+
+extern "C" int32_t fd_nhwc_to_nchw(const float* x, int32_t x_cs, int32_t x_co, float* y, int32_t N, int32_t HW,
+                                   int32_t C, fd_stream_t stream) {
+    FD_REQUIRE(x && y && N >= 1 && HW >= 1 && C >= 1 && N <= 65535, FD_E_INVAL, "fd_nhwc_to_nchw: bad argument");
+    dim3 grid((HW + 31) / 32, (C + 31) / 32, N);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, y, HW, C);
+    FD_CHECK_LAUNCH("fd_nhwc_to_nchw");
+    return FD_OK;
+}
+
+// ------------------------------------------------------------------------------ max-pool (+ add)
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, int x_cs, int x_co,
+                                                       float* __restrict__ y, int y_cs, int y_co,
+                                                       const float* __restrict__ add, int add_cs, int add_co, int H,
+                                                       int W, int Ho, int Wo, int C4, int k, int s, int pad, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const long m = i / C4;
+        const int wo = (int)(m % Wo);
+        const long t = m / Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int r = 0; r < k; ++r) {
+            const int hi = ho * s - pad + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int c = 0; c < k; ++c) {
+                const int wi = wo * s - pad + c;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 u = *reinterpret_cast<const float4*>(x + ((n * H + hi) * W + wi) * x_cs + x_co + 4 * q);
+                v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
+            }
+        }
+        if (add) {
+            const float4 u = *reinterpret_cast<const float4*>(add + m * add_cs + add_co + 4 * q);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) = v;
+    }
+}
+
+static inline bool view_ok(const void* p, int cs, int co, int C) {
+    return p && C % 4 == 0 && cs % 4 == 0 && co % 4 == 0 && cs >= co + C && ((uintptr_t)p & 15) == 0;
+}
+
+extern "C" int32_t fd_maxpool_nhwc(const float* x, int32_t x_cs, int32_t x_co, float* y, int32_t y_cs, int32_t y_co,
+                                   const float* add, int32_t add_cs, int32_t add_co, int32_t N, int32_t H, int32_t W,
+                                   int32_t C, int32_t k, int32_t s, int32_t pad, fd_stream_t stream) {
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C), FD_E_INVAL,
+               "fd_maxpool: channel views must be 4-aligned (C=%d)", C);
+    FD_REQUIRE(!add || view_ok(add, add_cs, add_co, C), FD_E_INVAL, "fd_maxpool: bad add view");
+    FD_REQUIRE(N >= 1 && k >= 1 && s >= 1 && pad >= 0 && 2 * pad <= k, FD_E_INVAL, "fd_maxpool: bad geometry");
+    const int Ho = (H + 2 * pad - k) / s + 1, Wo = (W + 2 * pad - k) / s + 1;
+    FD_REQUIRE(Ho >= 1 && Wo >= 1, FD_E_INVAL, "fd_maxpool: empty output");
+    const long total = (long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, y,
+                       y_cs, y_co, add, add_cs, add_co, H, W, Ho, Wo, C / 4, k, s, pad, total);
+    FD_CHECK_LAUNCH("fd_maxpool_nhwc");
+    return FD_OK;
+}
+
+// ------------------------------------------------------------------------------ nearest x2 upsample + add
+__global__ __launch_bounds__(256) void upsample2x_add_kernel(const float* __restrict__ x, int x_cs, int x_co,
+                                                              const float* __restrict__ lat, int lat_cs, int lat_co,
+                                                              float* __restrict__ y, int y_cs, int y_co, int H, int W,
+                                                              int C4, long total) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const long m = i / C4;
+        const int wo = (int)(m % Wo);
+        const long t = m / Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        const float4 u = *reinterpret_cast<const float4*>(x + ((n * H + (ho >> 1)) * W + (wo >> 1)) * x_cs + x_co + 4 * q);
+        const float4 l = *reinterpret_cast<const float4*>(lat + m * lat_cs + lat_co + 4 * q);
+        *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) = make_float4(u.x + l.x, u.y + l.y, u.z + l.z, u.w + l.w);
+    }
+}
+
+extern "C" int32_t fd_upsample2x_add_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* lat, int32_t lat_cs,
+                                          int32_t lat_co, float* y, int32_t y_cs, int32_t y_co, int32_t N, int32_t H,
+                                          int32_t W, int32_t C, fd_stream_t stream) {
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(lat, lat_cs, lat_co, C) && view_ok(y, y_cs, y_co, C), FD_E_INVAL,
+               "fd_upsample2x_add: channel views must be 4-aligned (C=%d)", C);
+    FD_REQUIRE(N >= 1 && H >= 1 && W >= 1, FD_E_INVAL, "fd_upsample2x_add: bad geometry");
+    const long total = (long)N * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs,
+                       x_co, lat, lat_cs, lat_co, y, y_cs, y_co, H, W, C / 4, total);
+    FD_CHECK_LAUNCH("fd_upsample2x_add_nhwc");
+    return FD_OK;
+}
+
+// ------------------------------------------------------------------------------ depthwise 3x3 (+scale/shift/act)
+struct SegTab { fd_segs s; };
+
+__device__ __forceinline__ void seg_decode(const fd_segs& sg, long m, int& H, int& W, long& img_row0, int& h, int& w) {
+    int s = 0;
+#pragma unroll
+    for (int t = 1; t < FD_MAX_SEG; ++t)
+        if (t < sg.nseg && m >= sg.m_start[t]) s = t;
+    H = sg.H[s]; W = sg.W[s];
+    const long local = m - sg.m_start[s];
+    const int hw = H * W;
+    const long n = local / hw;
+    const int rem = (int)(local - n * hw);
+    h = rem / W; w = rem - h * W;
+    img_row0 = sg.m_start[s] + n * hw;
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, int x_cs, int x_co,
+                                                         const float* __restrict__ wt, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ y, int y_cs,
+                                                         int y_co, int C, int act, SegTab tab, long total) {
+    const int C4 = C >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const long m = i / C4;
+        int H, W, h, w;
+        long r0;
+        seg_decode(tab.s, m, H, W, r0, h, w);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = h + r - 1;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int wi = w + c - 1;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 u = *reinterpret_cast<const float4*>(x + (r0 + hi * W + wi) * x_cs + x_co + 4 * q);
+                const float4 k = *reinterpret_cast<const float4*>(wt + (r * 3 + c) * C + 4 * q);
+                acc.x = fmaf(u.x, k.x, acc.x); acc.y = fmaf(u.y, k.y, acc.y);
+                acc.z = fmaf(u.z, k.z, acc.z); acc.w = fmaf(u.w, k.w, acc.w);
+            }
+        }
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) sc = *reinterpret_cast<const float4*>(scale + 4 * q);
+        if (shift) sf = *reinterpret_cast<const float4*>(shift + 4 * q);
+        float4 o;
+        o.x = fd_act(acc.x * sc.x + sf.x, act, 0.f); o.y = fd_act(acc.y * sc.y + sf.y, act, 0.f);
+        o.z = fd_act(acc.z * sc.z + sf.z, act, 0.f); o.w = fd_act(acc.w * sc.w + sf.w, act, 0.f);
+        *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) = o;
+    }
+}
+
+extern "C" int32_t fd_dwconv3x3_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w, const float* scale,
+                                     const float* shift, float* y, int32_t y_cs, int32_t y_co, int32_t C, int32_t act,
+                                     const fd_segs* segs, fd_stream_t stream) {
+    FD_REQUIRE(fd_segs_ok(segs), FD_E_INVAL, "fd_dwconv3x3: bad segment table");
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C) && w && ((uintptr_t)w & 15) == 0, FD_E_INVAL,
+               "fd_dwconv3x3: channel views must be 4-aligned (C=%d)", C);
+    SegTab tab; tab.s = *segs;
+    const long total = (long)segs->m_start[segs->nseg] * (C / 4);
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, w,
+                       scale, shift, y, y_cs, y_co, C, act, tab, total);
+    FD_CHECK_LAUNCH("fd_dwconv3x3_nhwc");
+    return FD_OK;
+}
+
+// ------------------------------------------------------------------------------ GroupNorm + activation
+// pass 1: per (level, image, row-chunk) partial (sum, sumsq) per group, fp64, fixed order
+// pass 2: per (level, image) finalise mean / rstd from the partials, normalise + affine + act
+#define GN_MAXCHUNK 64
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int x_cs, int x_co, int C, int G,
+                                                          SegTab tab, double* __restrict__ part) {
+    __shared__ double s_sum[256 * 4];
+    __shared__ double s_sq[256 * 4];
+    const int img = blockIdx.y;  // level-major: img = s * batch + n
+    const int s = img / tab.s.batch, n = img - s * tab.s.batch;
+    const int HW = tab.s.H[s] * tab.s.W[s];
+    const int nchunk = min(GN_MAXCHUNK, (HW + 63) / 64);
+    const int chunk = blockIdx.x;
+    if (chunk >= nchunk) return;
+    const int rows_per = (HW + nchunk - 1) / nchunk;
+    const int r_begin = chunk * rows_per, r_end = min(HW, r_begin + rows_per);
+    const int C4 = C >> 2, RT = 256 / C4;
+    const int tid = threadIdx.x, q = tid % C4, rt = tid / C4;
+    double su[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    if (rt < RT) {
+        const float* base = x + ((long)tab.s.m_start[s] + (long)n * HW) * x_cs + x_co + 4 * q;
+        for (int r = r_begin + rt; r < r_end; r += RT) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)r * x_cs);
+            su[0] += v.x; sq[0] += (double)v.x * v.x; su[1] += v.y; sq[1] += (double)v.y * v.y;
+            su[2] += v.z; sq[2] += (double)v.z * v.z; su[3] += v.w; sq[3] += (double)v.w * v.w;
+        }
+    }
+    // s_*[rt][c], c = 4q + e
+    if (rt < RT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s_sum[rt * C + 4 * q + e] = su[e]; s_sq[rt * C + 4 * q + e] = sq[e]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        double a = 0, b = 0;
+        for (int r = 0; r < RT; ++r) { a += s_sum[r * C + c]; b += s_sq[r * C + c]; }
+        s_sum[c] = a; s_sq[c] = b;   // row 0 of the table: only thread c touches column c
+    }
+    __syncthreads();
+    const int cg = C / G;
+    for (int g = tid; g < G; g += 256) {
+        double a = 0, b = 0;
+        for (int c = 0; c < cg; ++c) { a += s_sum[g * cg + c]; b += s_sq[g * cg + c]; }
+        double* o = part + (((long)img * GN_MAXCHUNK + chunk) * G + g) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int x_cs, int x_co,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ y, int y_cs, int y_co, int C, int G, float eps,
+                                                        int act, SegTab tab, const double* __restrict__ part) {
+    __shared__ float s_a[1024], s_b[1024];  // per-channel scale / bias
+    const int img = blockIdx.y;
+    const int s = img / tab.s.batch, n = img - s * tab.s.batch;
+    const int HW = tab.s.H[s] * tab.s.W[s];
+    const int nchunk = min(GN_MAXCHUNK, (HW + 63) / 64);
+    const int nblk = gridDim.x;
+    const int rows_per = (HW + nblk - 1) / nblk;
+    const int r_begin = blockIdx.x * rows_per, r_end = min(HW, r_begin + rows_per);
+    if (r_begin >= r_end) return;
+    const int cg = C / G, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cg;
+        double a = 0, b = 0;
+        for (int k = 0; k < nchunk; ++k) {
+            const double* p = part + (((long)img * GN_MAXCHUNK + k) * G + g) * 2;
+            a += p[0]; b += p[1];
+        }
+        const double cnt = (double)HW * cg;
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = rstd * gamma[c];
+        s_a[c] = sc;
+        s_b[c] = beta[c] - (float)mean * sc;
+    }
+    __syncthreads();
+    const int C4 = C >> 2;
+    const long row0 = (long)tab.s.m_start[s] + (long)n * HW;
+    const long total = (long)(r_end - r_begin) * C4;
+    for (long i = tid; i < total; i += 256) {
+        const int q = (int)(i % C4);
+        const long m = row0 + r_begin + i / C4;
+        const float4 v = *reinterpret_cast<const float4*>(x + m * x_cs + x_co + 4 * q);
+        float4 o;
+        o.x = fd_act(v.x * s_a[4 * q] + s_b[4 * q], act, 0.f);
+        o.y = fd_act(v.y * s_a[4 * q + 1] + s_b[4 * q + 1], act, 0.f);
+        o.z = fd_act(v.z * s_a[4 * q + 2] + s_b[4 * q + 2], act, 0.f);
+        o.w = fd_act(v.w * s_a[4 * q + 3] + s_b[4 * q + 3], act, 0.f);
+        *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) = o;
+    }
+}
+
+extern "C" int64_t fd_groupnorm_workspace_bytes(const fd_segs* segs, int32_t G) {
+    if (!fd_segs_ok(segs) || G < 1) return -1;
+    return (int64_t)segs->nseg * segs->batch * GN_MAXCHUNK * G * 2 * (int64_t)sizeof(double);
+}
+
+extern "C" int32_t fd_groupnorm_act_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* gamma,
+                                         const float* beta, float* y, int32_t y_cs, int32_t y_co, int32_t C, int32_t G,
+                                         float eps, int32_t act, const fd_segs* segs, void* workspace,
+                                         fd_stream_t stream) {
+    FD_REQUIRE(fd_segs_ok(segs), FD_E_INVAL, "fd_groupnorm: bad segment table");
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C) && gamma && beta && workspace, FD_E_INVAL,
+               "fd_groupnorm: bad pointer / channel view (C=%d)", C);
+    FD_REQUIRE(G >= 1 && C % G == 0 && C <= 1024 && 256 % (C / 4) == 0, FD_E_UNSUPPORTED,
+               "fd_groupnorm: C=%d G=%d unsupported (C/4 must divide 256, C <= 1024)", C, G);
+    FD_REQUIRE((long)segs->nseg * segs->batch <= 65535, FD_E_UNSUPPORTED, "fd_groupnorm: too many (level, image) pairs");
+    SegTab tab; tab.s = *segs;
+    const int imgs = segs->nseg * segs->batch;
+    int maxhw = 0;
+    for (int s = 0; s < segs->nseg; ++s) maxhw = max(maxhw, segs->H[s] * segs->W[s]);
+    const int nchunk = min(GN_MAXCHUNK, (maxhw + 63) / 64);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, imgs), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, C, G, tab,
+                       (double*)workspace);
+    FD_CHECK_LAUNCH("fd_groupnorm (partial)");
+    const int ablk = max(1, min(64, (maxhw * (C / 4) + 2047) / 2048));
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, imgs), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, gamma, beta, y,
+                       y_cs, y_co, C, G, eps, act, tab, (const double*)workspace);
+    FD_CHECK_LAUNCH("fd_groupnorm (apply)");
+    return FD_OK;
+}
+
+// ------------------------------------------------------------------------------ squeeze-excitation
+#define SE_MAXCHUNK 64
+
+__global__ __launch_bounds__(256) void se_gap_kernel(const float* __restrict__ x, int x_cs, int x_co, int HW, int C,
+                                                      int nchunk, double* __restrict__ part) {
+    __shared__ double s_sum[256 * 4];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int rows_per = (HW + nchunk - 1) / nchunk;
+    const int r_begin = chunk * rows_per, r_end = min(HW, r_begin + rows_per);
+    const int C4 = C >> 2, RT = 256 / C4;
+    const int tid = threadIdx.x, q = tid % C4, rt = tid / C4;
+    double su[4] = {0, 0, 0, 0};
+    if (rt < RT) {
+        const float* base = x + (long)n * HW * x_cs + x_co + 4 * q;
+        for (int r = r_begin + rt; r < r_end; r += RT) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)r * x_cs);
+            su[0] += v.x; su[1] += v.y; su[2] += v.z; su[3] += v.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_sum[rt * C + 4 * q + e] = su[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        double a = 0;
+        for (int r = 0; r < RT; ++r) a += s_sum[r * C + c];
+        part[((long)n * SE_MAXCHUNK + chunk) * C + c] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void se_fc_kernel(const double* __restrict__ part, int nchunk, int HW, int C, int Cr,
+                                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     float* __restrict__ gate) {
+    __shared__ float s_mean[1024];
+    __shared__ float s_h[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        double a = 0;
+        for (int k = 0; k < nchunk; ++k) a += part[((long)n * SE_MAXCHUNK + k) * C + c];
+        s_mean[c] = (float)(a / (double)HW);
+    }
+    __syncthreads();
+    for (int j = tid; j < Cr; j += 256) {
+        float a = b1 ? b1[j] : 0.f;
+        for (int c = 0; c < C; ++c) a = fmaf(w1[j * C + c], s_mean[c], a);
+        s_h[j] = fd_act(a, FD_ACT_SILU, 0.f);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = b2 ? b2[c] : 0.f;
+        for (int j = 0; j < Cr; ++j) a = fmaf(w2[c * Cr + j], s_h[j], a);
+        gate[(long)n * C + c] = fd_sigmoid(a);
+    }
+}
+
+__global__ __launch_bounds__(256) void se_scale_kernel(const float* __restrict__ x, int x_cs, int x_co,
+                                                        const float* __restrict__ gate, float* __restrict__ y, int y_cs,
+                                                        int y_co, int HW, int C4, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const long m = i / C4;
+        const long n = m / HW;
+        const float4 v = *reinterpret_cast<const float4*>(x + m * x_cs + x_co + 4 * q);
+        const float4 g = *reinterpret_cast<const float4*>(gate + n * C4 * 4 + 4 * q);
+        *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
+    }
+}
+
+extern "C" int64_t fd_se_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
+    if (N < 1 || HW < 1 || C < 1) return -1;
+    return (int64_t)N * SE_MAXCHUNK * C * (int64_t)sizeof(double) + (int64_t)N * C * (int64_t)sizeof(float);
+}
+
+extern "C" int32_t fd_se_scale_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w1, const float* b1,
+                                    const float* w2, const float* b2, float* y, int32_t y_cs, int32_t y_co, int32_t N,
+                                    int32_t HW, int32_t C, int32_t Cr, void* workspace, fd_stream_t stream) {
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C) && w1 && w2 && workspace, FD_E_INVAL,
+               "fd_se_scale: bad pointer / channel view (C=%d)", C);
+    FD_REQUIRE(N >= 1 && N <= 65535 && HW >= 1 && Cr >= 1 && Cr <= 256 && C <= 1024 && 256 % (C / 4) == 0,
+               FD_E_UNSUPPORTED, "fd_se_scale: C=%d Cr=%d unsupported", C, Cr);
+    FD_REQUIRE(((uintptr_t)workspace & 15) == 0, FD_E_INVAL, "fd_se_scale: workspace not 16-byte aligned");
+    double* part = (double*)workspace;
+    float* gate = (float*)((char*)workspace + (size_t)N * SE_MAXCHUNK * C * sizeof(double));
+    const int nchunk = min(SE_MAXCHUNK, (HW + 63) / 64);
+    hipLaunchKernelGGL(se_gap_kernel, dim3(nchunk, N), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, HW, C, nchunk, part);
+    FD_CHECK_LAUNCH("fd_se_scale (gap)");
+    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const double*)part, nchunk, HW, C, Cr, w1,
+                       b1, w2, b2, gate);
+    FD_CHECK_LAUNCH("fd_se_scale (fc)");
+    const long total = (long)N * HW * (C / 4);
+    hipLaunchKernelGGL(se_scale_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co,
+                       (const float*)gate, y, y_cs, y_co, HW, C / 4, total);
+    FD_CHECK_LAUNCH("fd_se_scale (scale)");
+    return FD_OK;
+}

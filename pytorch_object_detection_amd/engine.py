@@ -1,0 +1,396 @@
+"""Inference engine: compiles the reference-shaped module tree (parameter containers) into a flat list of HIP
+launches over pre-allocated NHWC buffers.
+
+ * frozen BatchNorm (HISFcos.py:57-68) is folded into the conv epilogue (scale, shift);
+ * torch.cat (HISFcos.py:107,111) disappears: producers write channel slices of the consumer's input buffer;
+ * the 5 pyramid levels live in ONE rows buffer, so the shared-weight head (HISFcos.py:215-229) is one grouped
+   launch per layer instead of five;
+ * cls_conv / reg_conv (same input) run as one 512-wide conv, their GroupNorm(32,256) pair as GroupNorm(64,512);
+   cnt_logits / reg_pred (same input) as one 5-wide conv with exp(scale_i * x) on channels 1..4.
+A plan is specific to (batch, H, W) and cached by the owning module.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from ._lib import ACT_EXP, ACT_NONE, ACT_RELU, ACT_SILU, FdError, Segs
+from .ops import Rows
+
+
+class PRows(Rows):
+    """Rows carved from a pooled flat buffer."""
+    __slots__ = ("_flat",)
+
+
+class Pool:
+    """Plan-time buffer pool: activations whose lifetime ended are reused by later layers (fewer live bytes in
+    HBM / Infinity Cache).  Safe because the plan runs in stream order: a buffer is only handed out again after
+    every step that reads it has been planned."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free: List[torch.Tensor] = []
+        self.total = 0
+
+    def get(self, rows: int, C: int) -> PRows:
+        need = rows * C
+        best = None
+        for i, t in enumerate(self.free):
+            if t.numel() >= need and (best is None or t.numel() < self.free[best].numel()):
+                best = i
+        if best is None:
+            flat = torch.empty(need, dtype=torch.float32, device=self.device)
+            self.total += need * 4
+        else:
+            flat = self.free.pop(best)
+        r = PRows(flat[:need].view(rows, C))
+        r._flat = flat
+        return r
+
+    def put(self, r: PRows) -> None:
+        self.free.append(r._flat)
+
+
+class Plan:
+    def __init__(self, device):
+        self.device = device
+        self.steps: List[Callable[[], None]] = []
+        self.names: List[str] = []
+        self.pool = Pool(device)
+        self.keep: List[object] = []       # tensors that must outlive the plan (packed weights, workspaces)
+        self.flops = 0                     # algorithmic conv FLOPs (2*MACs) of one run
+        self.marks: Dict[str, Tuple[int, int]] = {}
+
+    def add(self, name: str, fn: Callable[[], None]) -> None:
+        self.steps.append(fn)
+        self.names.append(name)
+
+    def run(self) -> None:
+        for s in self.steps:
+            s()
+
+    def run_range(self, lo: int, hi: int) -> None:
+        for s in self.steps[lo:hi]:
+            s()
+
+
+def _dev(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ conv helpers
+def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, y: Rows, *, bn=None, act=ACT_NONE,
+             res: Optional[Rows] = None, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+             Cout: Optional[int] = None, act_c0: int = 0, seg_param=None) -> Segs:
+    """conv (+folded BN / bias) (+res) (+act).  `weight`/`bias` override conv's own (fused multi-conv launches)."""
+    dev = plan.device
+    w = conv.weight if weight is None else weight
+    b = (conv.bias if bias is None else bias)
+    k, stride, pad, dil = conv.kernel_size[0], conv.stride[0], conv.padding, conv.dilation[0]
+    if isinstance(pad, str):  # 'same'
+        pad = dil * (k - 1) // 2
+    else:
+        pad = pad[0]
+    Cin, co = w.shape[1], (w.shape[0] if Cout is None else Cout)
+    wp = ops.pack_conv_weight(_dev(w, dev))
+    scale = shift = None
+    if bn is not None:
+        scale, shift = ops.fold_bn(_dev(bn.weight, dev), _dev(bn.bias, dev), _dev(bn.running_mean, dev),
+                                   _dev(bn.running_var, dev), bn.eps, _dev(b, dev) if b is not None else None)
+    elif b is not None:
+        shift = _dev(b, dev)
+    plan.keep += [wp, scale, shift]
+    plan.add(name, ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
+                                 shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param))
+    out = ops.conv_out_segs(segs, k, stride, pad, dil)
+    plan.flops += 2 * out.rows * co * Cin * k * k
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ ResNet-50 trunk
+def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: List[torch.Tensor]):
+    """torchvision-style ResNet-50 v1.5 trunk -> (C3, C4, C5) as (Rows, Segs).  `trunk` has conv1, bn1, layer1..4."""
+    dev, pool = plan.device, plan.pool
+    x4 = pool.get(batch * H * W, 4)
+    plan.add("input.nchw3_to_nhwc4", lambda: ops.nchw3_to_nhwc4(image_ref[0], x4.buf))
+    s_in = Segs.make(batch, [(H, W)])
+    # stem 7x7 s2 + BN + ReLU
+    wp = ops.pack_stem_weight(_dev(trunk.conv1.weight, dev))
+    sc, sf = ops.fold_bn(_dev(trunk.bn1.weight, dev), _dev(trunk.bn1.bias, dev), _dev(trunk.bn1.running_mean, dev),
+                         _dev(trunk.bn1.running_var, dev), trunk.bn1.eps)
+    plan.keep += [wp, sc, sf]
+    s1 = ops.conv_out_segs(s_in, 7, 2, 3, 1)
+    y1 = pool.get(s1.rows, 64)
+    plan.add("backbone.conv1", ops.conv_call(x4, s_in, wp, y1, Cin=4, Cout=64, k=7, stride=2, pad=3, scale=sc, shift=sf,
+                                             act=ACT_RELU, stem=True))
+    plan.flops += 2 * s1.rows * 64 * 147
+    pool.put(x4)
+    H1, W1 = s1.H[0], s1.W[0]
+    H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+    s2 = Segs.make(batch, [(H2, W2)])
+    y2 = pool.get(s2.rows, 64)
+    plan.add("backbone.maxpool", lambda: ops.maxpool(y1, y2, batch, H1, W1, 3, 2, 1))
+    pool.put(y1)
+    x, sx = y2, s2
+    feats = []
+    for li in (1, 2, 3, 4):
+        layer = getattr(trunk, f"layer{li}")
+        for bi, blk in enumerate(layer):
+            nm = f"backbone.layer{li}.{bi}"
+            planes = blk.conv1.weight.shape[0]
+            o1 = pool.get(sx.rows, planes)
+            add_conv(plan, nm + ".conv1", x, sx, blk.conv1, o1, bn=blk.bn1, act=ACT_RELU)
+            so = ops.conv_out_segs(sx, 3, blk.conv2.stride[0], 1, 1)
+            o2 = pool.get(so.rows, planes)
+            add_conv(plan, nm + ".conv2", o1, sx, blk.conv2, o2, bn=blk.bn2, act=ACT_RELU)
+            pool.put(o1)
+            if blk.downsample is not None:
+                idt = pool.get(so.rows, 4 * planes)
+                add_conv(plan, nm + ".downsample", x, sx, blk.downsample[0], idt, bn=blk.downsample[1])
+            else:
+                idt = x
+            out = pool.get(so.rows, 4 * planes)
+            add_conv(plan, nm + ".conv3", o2, so, blk.conv3, out, bn=blk.bn3, act=ACT_RELU, res=idt)
+            pool.put(o2)
+            if idt is not x:
+                pool.put(idt)
+            if not (feats and feats[-1][0] is x):  # keep C3/C4/C5 alive
+                pool.put(x)
+            x, sx = out, so
+        if li >= 2:
+            feats.append((x, sx))
+    return feats  # [(C3, segs), (C4, segs), (C5, segs)]
+
+
+# ------------------------------------------------------------------------------------------------ HISFCOS FPN
+def _his_block(plan: Plan, name: str, blk, x: Rows, segs: Segs, out: Rows) -> None:
+    """HisBlock (HISFcos.py:95-112); `out` is a [M, feature] view (a level slice of the pyramid buffer)."""
+    dev, pool = plan.device, plan.pool
+    M = segs.rows
+    half = blk.conv1.weight.shape[0]
+    N, HW = segs.batch, segs.H[0] * segs.W[0]
+    x1 = pool.get(M, half)
+    cat1 = pool.get(M, 2 * half)
+    cat2 = pool.get(M, 2 * half)
+    add_conv(plan, name + ".conv1", x, segs, blk.conv1, x1, bn=blk.bn1, act=ACT_SILU)
+    add_conv(plan, name + ".conv2", x, segs, blk.conv2, cat2.slice(half, half))
+    wd = ops.pack_dw_weight(_dev(blk.conv1_1.weight, dev))
+    sc, sf = ops.fold_bn(_dev(blk.bn2.weight, dev), _dev(blk.bn2.bias, dev), _dev(blk.bn2.running_mean, dev),
+                         _dev(blk.bn2.running_var, dev), blk.bn2.eps)
+    u = cat1.slice(0, half)
+    plan.add(name + ".conv1_1", lambda: ops.dwconv3x3(x1, wd, u, segs, sc, sf, ACT_RELU))
+    se = blk.conv1_2.excitation
+    w1 = _dev(se[0].weight, dev).reshape(se[0].weight.shape[0], -1).contiguous()
+    b1 = _dev(se[0].bias, dev)
+    w2 = _dev(se[2].weight, dev).reshape(se[2].weight.shape[0], -1).contiguous()
+    b2 = _dev(se[2].bias, dev)
+    ws = ops.se_workspace(N, HW, half, dev)
+    v = cat1.slice(half, half)
+    cr = w1.shape[0]
+    plan.add(name + ".conv1_2", lambda: ops.se_scale(x1, w1, b1, w2, b2, v, N, HW, cr, ws))
+    plan.keep += [wd, sc, sf, w1, b1, w2, b2, ws]
+    add_conv(plan, name + ".conv3", cat1, segs, blk.conv3, cat2.slice(0, half), bn=blk.bn3, act=ACT_RELU)
+    add_conv(plan, name + ".conv4", cat2, segs, blk.conv4, out, bn=blk.bn4, act=ACT_SILU)
+    pool.put(x1); pool.put(cat1); pool.put(cat2)
+
+
+def build_his_fpn(plan: Plan, fpn, feats):
+    """HalfInvertedStageFPN.forward (HISFcos.py:147-179) -> pyramid (Rows, Segs) with levels P3..P7."""
+    pool = plan.pool
+    (c3, s3), (c4, s4), (c5, s5) = feats
+    B = s3.batch
+    F = fpn.tf1.weight.shape[0]
+    h5, w5 = s5.H[0], s5.W[0]
+    hw = [(s3.H[0], s3.W[0]), (s4.H[0], s4.W[0]), (h5, w5), (h5 // 2, w5 // 2), (h5 // 4, w5 // 4)]
+    if hw[4][0] < 1 or hw[4][1] < 1:
+        raise FdError("HISFCOS FPN: input too small for the stride-128 level")
+    if (s4.H[0], s4.W[0]) != (2 * h5, 2 * w5) or (s3.H[0], s3.W[0]) != (4 * h5, 4 * w5):
+        raise FdError("HISFCOS FPN: H and W must be multiples of 32 (x2 upsample-adds must line up, HISFcos.py:155-165)")
+    pyr_segs = Segs.make(B, hw)
+    pyr = pool.get(pyr_segs.rows, F)
+
+    lv = [Rows(pyr.buf[pyr_segs.m_start[i]:pyr_segs.m_start[i + 1]]) for i in range(5)]
+
+    def level(i: int) -> Rows:
+        return lv[i]
+
+    seg = [Segs.make(B, [hw[i]]) for i in range(5)]
+    a = pool.get(s5.rows, F)
+    add_conv(plan, "fpn.tf1", c5, s5, fpn.tf1, a, bn=fpn.gn1, act=ACT_RELU)
+    x4 = pool.get(seg[3].rows, F)
+    x5 = pool.get(seg[4].rows, F)
+    plan.add("fpn.down_sample1", lambda: ops.maxpool(a, x4, B, hw[2][0], hw[2][1], 2, 2, 0))
+    plan.add("fpn.down_sample2", lambda: ops.maxpool(x4, x5, B, hw[3][0], hw[3][1], 2, 2, 0))
+    t3 = pool.get(s5.rows, F)
+    _his_block(plan, "fpn.HisBlock1", fpn.HisBlock1, a, s5, t3)
+    pool.put(a)
+    l4 = pool.get(s4.rows, F)
+    add_conv(plan, "fpn.tf2", c4, s4, fpn.tf2, l4, bn=fpn.gn2, act=ACT_RELU)
+    plan.add("fpn.up1_add", lambda: ops.upsample2x_add(t3, l4, l4, B, hw[2][0], hw[2][1]))
+    t4 = pool.get(s4.rows, F)
+    _his_block(plan, "fpn.HisBlock2", fpn.HisBlock2, l4, s4, t4)
+    pool.put(l4)
+    l3 = pool.get(s3.rows, F)
+    add_conv(plan, "fpn.tf3", c3, s3, fpn.tf3, l3, bn=fpn.gn2, act=ACT_RELU)  # gn2 again: HISFcos.py:163
+    plan.add("fpn.up2_add", lambda: ops.upsample2x_add(t4, l3, l3, B, hw[1][0], hw[1][1]))
+    _his_block(plan, "fpn.HisBlock3", fpn.HisBlock3, l3, s3, level(0))
+    pool.put(l3)
+    i4 = pool.get(s4.rows, F)
+    plan.add("fpn.down3_add", lambda: ops.maxpool(level(0), i4, B, hw[0][0], hw[0][1], 2, 2, 0, add=t4))
+    _his_block(plan, "fpn.HisBlock4", fpn.HisBlock4, i4, s4, level(1))
+    pool.put(i4); pool.put(t4)
+    i5 = pool.get(s5.rows, F)
+    plan.add("fpn.down4_add", lambda: ops.maxpool(level(1), i5, B, hw[1][0], hw[1][1], 2, 2, 0, add=t3))
+    _his_block(plan, "fpn.HisBlock5", fpn.HisBlock5, i5, s5, level(2))
+    pool.put(i5); pool.put(t3)
+    i6 = pool.get(seg[3].rows, F)
+    plan.add("fpn.down5_add", lambda: ops.maxpool(level(2), i6, B, hw[2][0], hw[2][1], 2, 2, 0, add=x4))
+    _his_block(plan, "fpn.HisBlock6", fpn.HisBlock6, i6, seg[3], level(3))
+    pool.put(i6); pool.put(x4)
+    i7 = pool.get(seg[4].rows, F)
+    plan.add("fpn.down6_add", lambda: ops.maxpool(level(3), i7, B, hw[3][0], hw[3][1], 2, 2, 0, add=x5))
+    _his_block(plan, "fpn.HisBlock7", fpn.HisBlock7, i7, seg[4], level(4))
+    pool.put(i7); pool.put(x5)
+    return pyr, pyr_segs
+
+
+# ------------------------------------------------------------------------------------------------ heads
+def _out_convs(plan: Plan, head, tower: Rows, segs: Segs, F: int, ncls: int):
+    """cls_logits on tower[:, :F]; cnt_logits + reg_pred (+ScaleExp) on tower[:, F:] as one 5-wide conv."""
+    dev, pool = plan.device, plan.pool
+    M = segs.rows
+    cls = pool.get(M, ncls if ncls % 4 == 0 else ncls + (4 - ncls % 4))
+    add_conv(plan, "head.cls_logits", tower.slice(0, F), segs, head.cls_logits, cls.slice(0, ncls))
+    cr = pool.get(M, 8)
+    w = torch.cat([head.cnt_logits.weight.detach(), head.reg_pred.weight.detach()], 0)
+    b = torch.cat([head.cnt_logits.bias.detach(), head.reg_pred.bias.detach()], 0)
+    scales = [float(s.scale.detach().reshape(-1)[0]) for s in head.scale_exp][:segs.nseg]
+    add_conv(plan, "head.cnt_reg", tower.slice(F, F), segs, head.reg_pred, cr.slice(0, 5), weight=w, bias=b, Cout=5,
+             act=ACT_EXP, act_c0=1, seg_param=scales)
+    return cls.slice(0, ncls), cr.slice(0, 1), cr.slice(1, 4)
+
+
+def _fused_gn(plan: Plan, name: str, x: Rows, segs: Segs, gns, act: int) -> None:
+    """k GroupNorm(32, F) over k adjacent F-channel slices == one GroupNorm(32k, kF) with concatenated affine."""
+    dev = plan.device
+    gamma = torch.cat([_dev(g.weight, dev) for g in gns]).contiguous()
+    beta = torch.cat([_dev(g.bias, dev) for g in gns]).contiguous()
+    G = sum(g.num_groups for g in gns)
+    ws = ops.groupnorm_workspace(segs, G, dev)
+    eps = gns[0].eps
+    plan.keep += [gamma, beta, ws]
+    plan.add(name, lambda: ops.groupnorm_act(x, gamma, beta, x, segs, G, act, ws, eps))
+
+
+def build_his_head(plan: Plan, head, pyr: Rows, segs: Segs):
+    """HISFCOSHead.forward (HISFcos.py:211-229), all levels in one launch per layer."""
+    dev, pool = plan.device, plan.pool
+    M = segs.rows
+    F = head.pw1.weight.shape[1]
+    ncls = head.cls_logits.weight.shape[0]
+    h1 = pool.get(M, 2 * F)
+    add_conv(plan, "head.pw1", pyr, segs, head.pw1, h1)
+    _fused_gn(plan, "head.gn1", h1, segs, [head.gn1], ACT_RELU)
+    h2 = pool.get(M, 2 * F)
+    wd = ops.pack_dw_weight(_dev(head.dw1.weight, dev))
+    plan.keep.append(wd)
+    plan.add("head.dw1", lambda: ops.dwconv3x3(h1, wd, h2, segs, None, None, ACT_NONE))
+    _fused_gn(plan, "head.gn2", h2, segs, [head.gn2], ACT_SILU)
+    pool.put(h1)
+    z = pool.get(M, F)
+    add_conv(plan, "head.pw2", h2, segs, head.pw2, z, res=pyr)
+    pool.put(h2)
+    tower = pool.get(M, 2 * F)
+    w = torch.cat([head.cls_conv[0].weight.detach(), head.reg_conv[0].weight.detach()], 0)
+    mark = len(plan.steps)
+    add_conv(plan, "head.tower3x3", z, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F)
+    plan.marks["head.tower3x3"] = (mark, len(plan.steps))
+    _fused_gn(plan, "head.tower_gn", tower, segs, [head.cls_conv[1], head.reg_conv[1]], ACT_RELU)
+    pool.put(z)
+    return _out_convs(plan, head, tower, segs, F, ncls)
+
+
+# ------------------------------------------------------------------------------------------------ FCOS baseline
+def build_fcos_fpn(plan: Plan, fpn, feats):
+    """FeaturePyramidNetwork.forward (Fcos.py:77-91); the returned P6 is the rectified map (in-place ReLU, Fcos.py:90)."""
+    pool = plan.pool
+    (c3, s3), (c4, s4), (c5, s5) = feats
+    B = s3.batch
+    F = fpn.P5.weight.shape[0]
+    h5, w5 = s5.H[0], s5.W[0]
+    h6, w6 = (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1
+    h7, w7 = (h6 - 1) // 2 + 1, (w6 - 1) // 2 + 1
+    hw = [(s3.H[0], s3.W[0]), (s4.H[0], s4.W[0]), (h5, w5), (h6, w6), (h7, w7)]
+    if (s4.H[0], s4.W[0]) != (2 * h5, 2 * w5) or (s3.H[0], s3.W[0]) != (4 * h5, 4 * w5):
+        raise FdError("FCOS FPN: H and W must be multiples of 32")
+    pyr_segs = Segs.make(B, hw)
+    pyr = pool.get(pyr_segs.rows, F)
+
+    lv = [Rows(pyr.buf[pyr_segs.m_start[i]:pyr_segs.m_start[i + 1]]) for i in range(5)]
+
+    def level(i: int) -> Rows:
+        return lv[i]
+
+    seg = [Segs.make(B, [hw[i]]) for i in range(5)]
+    p5 = pool.get(s5.rows, F)
+    add_conv(plan, "FPN.P5", c5, s5, fpn.P5, p5)
+    p4 = pool.get(s4.rows, F)
+    add_conv(plan, "FPN.P4", c4, s4, fpn.P4, p4)
+    plan.add("FPN.P5_Up_add", lambda: ops.upsample2x_add(p5, p4, p4, B, h5, w5))
+    add_conv(plan, "FPN.P4_c1", p4, s4, fpn.P4_c1, level(1))
+    pool.put(p4)
+    p3 = pool.get(s3.rows, F)
+    add_conv(plan, "FPN.P3", c3, s3, fpn.P3, p3)
+    plan.add("FPN.P4_Up_add", lambda: ops.upsample2x_add(level(1), p3, p3, B, hw[1][0], hw[1][1]))
+    add_conv(plan, "FPN.P3_c1", p3, s3, fpn.P3_c1, level(0))
+    pool.put(p3)
+    add_conv(plan, "FPN.P5_c1", p5, s5, fpn.P5_c1, level(2))
+    pool.put(p5)
+    add_conv(plan, "FPN.P6_c1", level(2), seg[2], fpn.P6_c1, level(3), act=ACT_RELU)
+    add_conv(plan, "FPN.P7_c1", level(3), seg[3], fpn.P7_c1, level(4))
+    return pyr, pyr_segs
+
+
+def build_fcos_head(plan: Plan, head, pyr: Rows, segs: Segs):
+    """HeadFCOS.forward (Fcos.py:120-133): 4 x (3x3, GN, ReLU) per branch; layer 0 of both branches is one launch."""
+    pool = plan.pool
+    M = segs.rows
+    F = head.cls_logits.weight.shape[1]
+    ncls = head.cls_logits.weight.shape[0]
+    cur = pool.get(M, 2 * F)
+    w = torch.cat([head.cls_branch[0].weight.detach(), head.reg_branch[0].weight.detach()], 0)
+    mark = len(plan.steps)
+    add_conv(plan, "head.tower0", pyr, segs, head.cls_branch[0], cur, weight=w, Cout=2 * F)
+    plan.marks["head.tower3x3"] = (mark, len(plan.steps))
+    _fused_gn(plan, "head.tower0_gn", cur, segs, [head.cls_branch[1], head.reg_branch[1]], ACT_RELU)
+    for k in (1, 2, 3):
+        nxt = pool.get(M, 2 * F)
+        add_conv(plan, f"head.cls_branch.{3 * k}", cur.slice(0, F), segs, head.cls_branch[3 * k], nxt.slice(0, F))
+        add_conv(plan, f"head.reg_branch.{3 * k}", cur.slice(F, F), segs, head.reg_branch[3 * k], nxt.slice(F, F))
+        _fused_gn(plan, f"head.tower{k}_gn", nxt, segs, [head.cls_branch[3 * k + 1], head.reg_branch[3 * k + 1]], ACT_RELU)
+        pool.put(cur)
+        cur = nxt
+    return _out_convs(plan, head, cur, segs, F, ncls)
+
+
+# ------------------------------------------------------------------------------------------------ views
+def level_views(rows: Rows, segs: Segs) -> List[torch.Tensor]:
+    """Per-level NCHW-shaped tensors (channels-last memory: zero-copy views of the pyramid rows buffer)."""
+    outs = []
+    t = rows.tensor()
+    for i in range(segs.nseg):
+        h, w = segs.H[i], segs.W[i]
+        outs.append(t[segs.m_start[i]:segs.m_start[i + 1]].view(segs.batch, h, w, rows.C).permute(0, 3, 1, 2))
+    return outs
+
+
+def rows_from_nchw(x: torch.Tensor) -> Tuple[Rows, Segs]:
+    """NCHW tensor -> NHWC rows (zero-copy when x already is a channels-last view of a rows buffer)."""
+    B, Cc, H, W = x.shape
+    xp = x.permute(0, 2, 3, 1)
+    if not xp.is_contiguous():
+        xp = xp.contiguous()
+    return Rows(xp.reshape(B * H * W, Cc)), Segs.make(B, [(H, W)])

@@ -1,0 +1,127 @@
+"""FCOS-R50 baseline on MI355X — mirrors the reference's model/od/Fcos.py (FCOS :12-58,
+FeaturePyramidNetwork :61-91, HeadFCOS :94-133): same constructors and state_dict keys, HIP plan forward."""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import engine
+from ..._lib import FdError, Segs
+from ..backbone.resnet50 import ResNet50
+from ..modules.modules import ScaleExp, init_conv_kaiming, init_conv_random_normal
+from ._planned import PlannedModule, copy_in_nchw, pyramid_out
+
+
+class FeaturePyramidNetwork(PlannedModule):
+    def __init__(self, in_channel: List[int], feature: int = 256):
+        super().__init__()
+        self.P5 = nn.Conv2d(in_channel[0], feature, 1, 1, 'same')
+        self.P4 = nn.Conv2d(in_channel[1], feature, 1, 1, 'same')
+        self.P3 = nn.Conv2d(in_channel[2], feature, 1, 1, 'same')
+        self.P5_c1 = nn.Conv2d(feature, feature, 3, 1, 'same')
+        self.P4_c1 = nn.Conv2d(feature, feature, 3, 1, 'same')
+        self.P3_c1 = nn.Conv2d(feature, feature, 3, 1, 'same')
+        self.P6_c1 = nn.Conv2d(feature, feature, 3, 2, 1)
+        self.P7_c1 = nn.Conv2d(feature, feature, 3, 2, 1)
+        self.apply(init_conv_kaiming)
+
+    def forward(self, x):
+        self._check_eval()
+        c3, c4, c5 = x
+        key = ("FPN",) + tuple(tuple(t.shape) for t in x) + (str(c3.device),)
+
+        def build():
+            plan = engine.Plan(c3.device)
+            ins = []
+            for t in (c3, c4, c5):
+                B, C, H, W = t.shape
+                ins.append((plan.pool.get(B * H * W, C), Segs.make(B, [(H, W)])))
+            pyr, segs = engine.build_fcos_fpn(plan, self, ins)
+            return plan, ins, pyr, segs
+
+        plan, ins, pyr, segs = self._get_plan(key, build)
+        for (r, s), t in zip(ins, (c3, c4, c5)):
+            copy_in_nchw(r, s, 0, t)
+        plan.run()
+        return pyramid_out(pyr, segs)
+
+
+class HeadFCOS(PlannedModule):
+    def __init__(self, feature: int, num_class: int, prior: float = 0.01):
+        super().__init__()
+        self.class_num, self.prior = num_class, prior
+        cls_branch, reg_branch = [], []
+        for _ in range(4):
+            cls_branch += [nn.Conv2d(feature, feature, 3, padding=1, bias=False), nn.GroupNorm(32, feature), nn.ReLU(True)]
+            reg_branch += [nn.Conv2d(feature, feature, 3, padding=1, bias=False), nn.GroupNorm(32, feature), nn.ReLU(True)]
+        self.cls_branch = nn.Sequential(*cls_branch)
+        self.reg_branch = nn.Sequential(*reg_branch)
+        self.cls_logits = nn.Conv2d(feature, num_class, 3, padding=1)
+        self.cnt_logits = nn.Conv2d(feature, 1, 3, padding=1)
+        self.reg_pred = nn.Conv2d(feature, 4, 3, padding=1)
+        self.apply(init_conv_random_normal)
+        nn.init.constant_(self.cls_logits.bias, -np.log((1 - prior) / prior))
+        self.scale_exp = nn.ModuleList([ScaleExp(1.0) for _ in range(5)])
+
+    def forward(self, inputs):
+        self._check_eval()
+        shapes = tuple(tuple(t.shape) for t in inputs)
+        key = ("head",) + shapes + (str(inputs[0].device),)
+
+        def build():
+            plan = engine.Plan(inputs[0].device)
+            B, C = shapes[0][0], shapes[0][1]
+            segs = Segs.make(B, [(s[2], s[3]) for s in shapes])
+            pyr = plan.pool.get(segs.rows, C)
+            outs = engine.build_fcos_head(plan, self, pyr, segs)
+            return plan, pyr, segs, outs
+
+        plan, pyr, segs, outs = self._get_plan(key, build)
+        for i, t in enumerate(inputs):
+            copy_in_nchw(pyr, segs, i, t)
+        plan.run()
+        return tuple(pyramid_out(o, segs) for o in outs)
+
+
+class FCOS(PlannedModule):
+    def __init__(self, in_channel: List[int], num_class: int, feature: int, freeze_bn: bool = True,
+                 efficientnet: bool = False):
+        super().__init__()
+        if efficientnet:
+            raise FdError("EfficientNet backbones (efficientnet_pytorch, third-party) are not built; use ResNet-50")
+        self.backbone = ResNet50(3)
+        self.FPN = FeaturePyramidNetwork(in_channel, feature)
+        self.head = HeadFCOS(feature, num_class, 0.01)
+        self.backbone_freeze = freeze_bn
+        if self.backbone_freeze:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+                    for p in m.parameters():
+                        p.requires_grad = False
+
+    def build_plan(self, B: int, H: int, W: int, device):
+        plan = engine.Plan(device)
+        plan.image_ref = [None]
+        feats = engine.build_resnet50(plan, self.backbone.trunk, B, H, W, plan.image_ref)
+        pyr, segs = engine.build_fcos_fpn(plan, self.FPN, feats)
+        for r, _ in feats:
+            plan.pool.put(r)
+        outs = engine.build_fcos_head(plan, self.head, pyr, segs)
+        plan.outs, plan.segs = outs, segs
+        return plan
+
+    def plan_for(self, x: torch.Tensor):
+        self._check_image(x)
+        self._check_eval()
+        B, _, H, W = x.shape
+        return self._get_plan(("model", B, H, W, str(x.device)), lambda: self.build_plan(B, H, W, x.device))
+
+    def forward(self, x: torch.Tensor):
+        plan = self.plan_for(x)
+        plan.image_ref[0] = x.contiguous()
+        plan.run()
+        return tuple(pyramid_out(o, plan.segs) for o in plan.outs)

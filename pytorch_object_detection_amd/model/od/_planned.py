@@ -1,0 +1,76 @@
+"""Shared plumbing of the detector modules: plan cache, input checks, pyramid-aware output lists."""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from ... import engine
+from ..._lib import FdError, Segs
+from ...ops import Rows
+
+
+class PyramidOut(list):
+    """List of per-level NCHW-shaped tensors (what the reference model returns) that also remembers the single
+    NHWC rows buffer they are views of, so FCOSHead can consume it without any re-layout."""
+
+    def __init__(self, views, rows: Rows, segs: Segs):
+        super().__init__(views)
+        self.rows, self.segs = rows, segs
+
+
+def pyramid_out(rows: Rows, segs: Segs) -> PyramidOut:
+    return PyramidOut(engine.level_views(rows, segs), rows, segs)
+
+
+class PlannedModule(nn.Module):
+    """nn.Module whose forward is a cached engine.Plan keyed by input shapes and the parameters' version counters."""
+
+    def __init__(self):
+        super().__init__()
+        self._plans: Dict[Tuple, Tuple[int, object]] = {}
+
+    def _param_version(self) -> int:
+        v = 0
+        for t in list(self.parameters()) + list(self.buffers()):
+            v += t._version + (t.data_ptr() & 0xFFFF)
+        return v
+
+    def _get_plan(self, key: Tuple, build: Callable[[], object]):
+        ver = self._param_version()
+        hit = self._plans.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        if len(self._plans) > 8:
+            self._plans.clear()
+        built = build()
+        self._plans[key] = (ver, built)
+        return built
+
+    def invalidate_plans(self) -> None:
+        self._plans.clear()
+
+    @staticmethod
+    def _check_image(x: torch.Tensor) -> None:
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3:
+            raise FdError("expected an image batch [B, 3, H, W]")
+        if not x.is_cuda:
+            raise FdError("pytorch_object_detection_amd runs on the GPU only; there is no CPU fallback "
+                          "(got a CPU tensor)")
+        if x.dtype != torch.float32:
+            raise FdError("expected float32 images (the HIP path computes in fp32)")
+        if x.shape[2] % 32 or x.shape[3] % 32:
+            raise FdError("H and W must be multiples of 32 (reference datasets pad to 32, dataset/voc.py:128-132)")
+
+    def _check_eval(self) -> None:
+        if self.training:
+            raise FdError("the HIP plan implements the frozen-BN inference forward; call model.eval() first "
+                          "(training forward/backward is not built yet)")
+
+
+def copy_in_nchw(dst: Rows, segs: Segs, level: int, x: torch.Tensor) -> None:
+    """Stage a caller-owned NCHW tensor into level `level` of a plan-owned rows buffer (standalone sub-module calls)."""
+    B, C, H, W = x.shape
+    m0, m1 = segs.m_start[level], segs.m_start[level + 1]
+    dst.tensor()[m0:m1].view(B, H, W, C).copy_(x.permute(0, 2, 3, 1))

@@ -1,0 +1,270 @@
+"""Tensor-level wrappers over the C-ABI (include/fcosdet.h).  Every function enqueues HIP kernels on torch's
+current stream and returns immediately; tensors must be CUDA (ROCm) fp32 and are never copied to the host.
+
+`Rows` describes an NHWC activation as rows x channels with a channel stride / offset, so concatenations are
+written in place (torch.cat in HISFcos.py:107,111 disappears) and slices are read without copies.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_EXP, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ConvParams, FdError, Segs, check  # noqa: F401
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise FdError("pytorch_object_detection_amd runs on the GPU only (got a CPU tensor); there is no CPU "
+                          "fallback — use the reference or oracle/ for CPU runs")
+
+
+class Rows:
+    """Channel view [rows, C] of a [rows, cs] fp32 buffer starting at channel `co`."""
+    __slots__ = ("buf", "cs", "co", "C")
+
+    def __init__(self, buf: torch.Tensor, co: int = 0, C_: Optional[int] = None):
+        assert buf.dim() == 2 and buf.dtype == torch.float32 and buf.is_contiguous()
+        _need_gpu(buf)
+        self.buf, self.cs, self.co = buf, buf.shape[1], co
+        self.C = buf.shape[1] - co if C_ is None else C_
+        assert 0 <= co and co + self.C <= self.cs
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr()
+
+    @property
+    def rows(self) -> int:
+        return self.buf.shape[0]
+
+    def slice(self, co: int, C_: int) -> "Rows":
+        return Rows(self.buf, self.co + co, C_)
+
+    def tensor(self) -> torch.Tensor:
+        return self.buf[:, self.co:self.co + self.C]
+
+
+def new_rows(rows: int, C_: int, device) -> Rows:
+    return Rows(torch.empty(rows, C_, dtype=torch.float32, device=device))
+
+
+# ---------------------------------------------------------------------------------------------------- weights
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW -> [Cout][KH][KW][Cin] contiguous (K contiguous)."""
+    return w.detach().permute(0, 2, 3, 1).contiguous().float()
+
+
+def pack_stem_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,3,7,7] -> [Cout][7][8][4], zero at kw=7 and c=3 (FD_CONV_STEM)."""
+    co = w.shape[0]
+    p = torch.zeros(co, 7, 8, 4, dtype=torch.float32, device=w.device)
+    p[:, :, :7, :3] = w.detach().permute(0, 2, 3, 1).float()
+    return p.contiguous()
+
+
+def pack_dw_weight(w: torch.Tensor) -> torch.Tensor:
+    """[C,1,3,3] -> [9][C]."""
+    return w.detach().reshape(w.shape[0], 9).t().contiguous().float()
+
+
+def fold_bn(weight, bias, mean, var, eps: float = 1e-5, conv_bias: Optional[torch.Tensor] = None):
+    """Frozen BatchNorm2d -> per-channel (scale, shift); a preceding conv bias is absorbed into the shift."""
+    scale = (weight.detach().double() / torch.sqrt(var.detach().double() + eps))
+    shift = bias.detach().double() - mean.detach().double() * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.detach().double() * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------- conv
+def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int, Cout: int, k: int, stride: int = 1,
+              pad: int = 0, dil: int = 1, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+              res: Optional[Rows] = None, act: int = ACT_NONE, act_c0: int = 0,
+              seg_param: Optional[Sequence[float]] = None, stem: bool = False) -> Callable[[], None]:
+    """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream."""
+    _need_gpu(w_packed, scale, shift)
+    p = ConvParams()
+    p.x, p.w, p.y = x.ptr, w_packed.data_ptr(), y.ptr
+    p.scale = scale.data_ptr() if scale is not None else None
+    p.shift = shift.data_ptr() if shift is not None else None
+    p.res = res.ptr if res is not None else None
+    p.x_cs, p.x_co, p.y_cs, p.y_co = x.cs, x.co, y.cs, y.co
+    if res is not None:
+        p.res_cs, p.res_co = res.cs, res.co
+    p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, k, stride, pad, dil
+    p.act, p.act_c0, p.mode = act, act_c0, (_lib.CONV_STEM if stem else _lib.CONV_GENERIC)
+    if seg_param is not None:
+        for i, v in enumerate(seg_param):
+            p.seg_param[i] = float(v)
+    p.segs = segs
+    fn = _lib.lib().fd_conv2d_nhwc_f32
+    ref = C.byref(p)
+    keep = (x, w_packed, y, scale, shift, res, p)
+
+    def run(_keep=keep):
+        check(fn(ref, _stream()), "fd_conv2d_nhwc_f32")
+
+    return run
+
+
+def conv_out_segs(segs: Segs, k: int, stride: int, pad: int, dil: int) -> Segs:
+    hw = [((h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1)
+          for h, w in segs.level_hw()]
+    return Segs.make(segs.batch, hw)
+
+
+# ---------------------------------------------------------------------------------------------------- layer ops
+def nchw3_to_nhwc4(x: torch.Tensor, y: torch.Tensor) -> None:
+    _need_gpu(x, y)
+    N, c, H, W = x.shape
+    assert c == 3 and x.is_contiguous() and x.dtype == torch.float32
+    check(_lib.lib().fd_nchw3_to_nhwc4(x.data_ptr(), y.data_ptr(), N, H, W, _stream()), "fd_nchw3_to_nhwc4")
+
+
+def nhwc_to_nchw(x: Rows, N: int, HW: int, out: torch.Tensor) -> None:
+    check(_lib.lib().fd_nhwc_to_nchw(x.ptr, x.cs, x.co, out.data_ptr(), N, HW, x.C, _stream()), "fd_nhwc_to_nchw")
+
+
+def maxpool(x: Rows, y: Rows, N: int, H: int, W: int, k: int, s: int, pad: int, add: Optional[Rows] = None) -> None:
+    a = (add.ptr, add.cs, add.co) if add is not None else (None, 0, 0)
+    check(_lib.lib().fd_maxpool_nhwc(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, a[0], a[1], a[2], N, H, W, x.C, k, s, pad,
+                                     _stream()), "fd_maxpool_nhwc")
+
+
+def upsample2x_add(x: Rows, lat: Rows, y: Rows, N: int, H: int, W: int) -> None:
+    check(_lib.lib().fd_upsample2x_add_nhwc(x.ptr, x.cs, x.co, lat.ptr, lat.cs, lat.co, y.ptr, y.cs, y.co, N, H, W, x.C,
+                                            _stream()), "fd_upsample2x_add_nhwc")
+
+
+def dwconv3x3(x: Rows, w9c: torch.Tensor, y: Rows, segs: Segs, scale=None, shift=None, act: int = ACT_NONE) -> None:
+    check(_lib.lib().fd_dwconv3x3_nhwc(x.ptr, x.cs, x.co, w9c.data_ptr(),
+                                       scale.data_ptr() if scale is not None else None,
+                                       shift.data_ptr() if shift is not None else None, y.ptr, y.cs, y.co, x.C, act,
+                                       C.byref(segs), _stream()), "fd_dwconv3x3_nhwc")
+
+
+def groupnorm_workspace(segs: Segs, G: int, device) -> torch.Tensor:
+    n = _lib.lib().fd_groupnorm_workspace_bytes(C.byref(segs), G)
+    if n < 0:
+        raise FdError("fd_groupnorm_workspace_bytes: bad arguments")
+    return torch.empty(n // 8, dtype=torch.float64, device=device)
+
+
+def groupnorm_act(x: Rows, gamma: torch.Tensor, beta: torch.Tensor, y: Rows, segs: Segs, G: int, act: int,
+                  ws: torch.Tensor, eps: float = 1e-5) -> None:
+    check(_lib.lib().fd_groupnorm_act_nhwc(x.ptr, x.cs, x.co, gamma.data_ptr(), beta.data_ptr(), y.ptr, y.cs, y.co, x.C,
+                                           G, eps, act, C.byref(segs), ws.data_ptr(), _stream()), "fd_groupnorm_act_nhwc")
+
+
+def se_workspace(N: int, HW: int, C_: int, device) -> torch.Tensor:
+    n = _lib.lib().fd_se_workspace_bytes(N, HW, C_)
+    return torch.empty((n + 7) // 8, dtype=torch.float64, device=device)
+
+
+def se_scale(x: Rows, w1, b1, w2, b2, y: Rows, N: int, HW: int, Cr: int, ws: torch.Tensor) -> None:
+    check(_lib.lib().fd_se_scale_nhwc(x.ptr, x.cs, x.co, w1.data_ptr(), b1.data_ptr() if b1 is not None else None,
+                                      w2.data_ptr(), b2.data_ptr() if b2 is not None else None, y.ptr, y.cs, y.co, N, HW,
+                                      x.C, Cr, ws.data_ptr(), _stream()), "fd_se_scale_nhwc")
+
+
+# ---------------------------------------------------------------------------------------------------- post-process
+def fcos_decode(cls: Rows, cnt: Rows, reg: Rows, segs: Segs, strides: Sequence[int]):
+    """-> scores [N,L] f32, classes [N,L] i32, boxes [N,L,4] f32 (levels concatenated per image)."""
+    N = segs.batch
+    L = sum(h * w for h, w in segs.level_hw())
+    dev = cls.buf.device
+    scores = torch.empty(N, L, dtype=torch.float32, device=dev)
+    classes = torch.empty(N, L, dtype=torch.int32, device=dev)
+    boxes = torch.empty(N, L, 4, dtype=torch.float32, device=dev)
+    st = (C.c_int32 * len(strides))(*strides)
+    check(_lib.lib().fd_fcos_decode(cls.ptr, cls.cs, cls.co, cnt.ptr, cnt.cs, cnt.co, reg.ptr, reg.cs, reg.co, cls.C,
+                                    C.byref(segs), st, scores.data_ptr(), classes.data_ptr(), boxes.data_ptr(), _stream()),
+          "fd_fcos_decode")
+    return scores, classes, boxes
+
+
+def fcos_topk(scores: torch.Tensor, classes: torch.Tensor, boxes: torch.Tensor, K: int, want_idx: bool = False):
+    _need_gpu(scores, classes, boxes)
+    N, L = scores.shape
+    dev = scores.device
+    ts = torch.empty(N, K, dtype=torch.float32, device=dev)
+    tc = torch.empty(N, K, dtype=torch.int64, device=dev)
+    tb = torch.empty(N, K, 4, dtype=torch.float32, device=dev)
+    ti = torch.empty(N, K, dtype=torch.int32, device=dev) if want_idx else None
+    check(_lib.lib().fd_fcos_topk(scores.data_ptr(), classes.data_ptr(), boxes.data_ptr(), N, L, K, ts.data_ptr(),
+                                  tc.data_ptr(), tb.data_ptr(), ti.data_ptr() if want_idx else None, None, _stream()),
+          "fd_fcos_topk")
+    return (ts, tc, tb, ti) if want_idx else (ts, tc, tb)
+
+
+def batched_nms(scores: torch.Tensor, classes: torch.Tensor, boxes: torch.Tensor, score_thr: float, iou_thr: float):
+    """Padded outputs [N,K] + keep_idx [N,K] (int32, -1 padded) + counts [N] (int32)."""
+    _need_gpu(scores, classes, boxes)
+    N, K = scores.shape
+    assert classes.dtype == torch.int64 and scores.is_contiguous() and classes.is_contiguous() and boxes.is_contiguous()
+    dev = scores.device
+    os_ = torch.empty(N, K, dtype=torch.float32, device=dev)
+    oc = torch.empty(N, K, dtype=torch.int64, device=dev)
+    ob = torch.empty(N, K, 4, dtype=torch.float32, device=dev)
+    keep = torch.empty(N, K, dtype=torch.int32, device=dev)
+    counts = torch.empty(N, dtype=torch.int32, device=dev)
+    check(_lib.lib().fd_batched_nms(scores.data_ptr(), classes.data_ptr(), boxes.data_ptr(), N, K, score_thr, iou_thr,
+                                    os_.data_ptr(), oc.data_ptr(), ob.data_ptr(), keep.data_ptr(), counts.data_ptr(),
+                                    _stream()), "fd_batched_nms")
+    return os_, oc, ob, keep, counts
+
+
+def box_nms_plus1(boxes: torch.Tensor, scores: torch.Tensor, thr: float = 0.5, mode: str = "union",
+                  n_valid: Optional[torch.Tensor] = None):
+    _need_gpu(boxes, scores)
+    N, K = scores.shape
+    keep = torch.empty(N, K, dtype=torch.int32, device=scores.device)
+    counts = torch.empty(N, dtype=torch.int32, device=scores.device)
+    check(_lib.lib().fd_box_nms_plus1(boxes.data_ptr(), scores.data_ptr(), n_valid.data_ptr() if n_valid is not None else None,
+                                      N, K, thr, {"union": 0, "min": 1}[mode], keep.data_ptr(), counts.data_ptr(), _stream()),
+          "fd_box_nms_plus1")
+    return keep, counts
+
+
+def pairwise_iou(a: torch.Tensor, b: torch.Tensor, plus_one: bool) -> torch.Tensor:
+    _need_gpu(a, b)
+    out = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=a.device)
+    check(_lib.lib().fd_pairwise_iou(a.data_ptr(), b.data_ptr(), a.shape[0], b.shape[0], int(plus_one), out.data_ptr(),
+                                     _stream()), "fd_pairwise_iou")
+    return out
+
+
+def clip_boxes_(boxes: torch.Tensor, img_h: int, img_w: int) -> torch.Tensor:
+    _need_gpu(boxes)
+    assert boxes.is_contiguous() and boxes.shape[-1] == 4 and boxes.dtype == torch.float32
+    check(_lib.lib().fd_clip_boxes(boxes.data_ptr(), boxes.numel() // 4, img_h, img_w, _stream()), "fd_clip_boxes")
+    return boxes
+
+
+# ---------------------------------------------------------------------------------------------------- loss
+def ltrb_loss_fwd(pred: torch.Tensor, target: torch.Tensor, mask: torch.Tensor, mode: int):
+    _need_gpu(pred, target, mask)
+    B, L, _ = pred.shape
+    loss = torch.empty(B, dtype=torch.float32, device=pred.device)
+    npos = torch.empty(B, dtype=torch.int32, device=pred.device)
+    check(_lib.lib().fd_ltrb_iou_loss_fwd(pred.data_ptr(), target.data_ptr(), mask.data_ptr(), B, L, mode, loss.data_ptr(),
+                                          npos.data_ptr(), _stream()), "fd_ltrb_iou_loss_fwd")
+    return loss, npos
+
+
+def ltrb_loss_bwd(pred: torch.Tensor, target: torch.Tensor, mask: torch.Tensor, gscale: torch.Tensor, mode: int):
+    B, L, _ = pred.shape
+    grad = torch.empty_like(pred)
+    check(_lib.lib().fd_ltrb_iou_loss_bwd(pred.data_ptr(), target.data_ptr(), mask.data_ptr(), gscale.data_ptr(), B, L, mode,
+                                          grad.data_ptr(), _stream()), "fd_ltrb_iou_loss_bwd")
+    return grad

@@ -1,0 +1,203 @@
+"""GPU parity of the layer kernels (C-ABI) against torch fp32 CPU references of the same op.
+Tolerance for conv / norm outputs: 1e-4 absolute + 1e-5 relative (north_star: 'conv ... within 1e-4 fp32')."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pytorch_object_detection_amd import ops
+from pytorch_object_detection_amd._lib import ACT_EXP, ACT_NONE, ACT_RELU, ACT_SILU, Segs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ATOL, RTOL = 1e-4, 1e-5
+
+
+def to_rows(x):  # NCHW cpu -> Rows on device
+    B, C, H, W = x.shape
+    return ops.Rows(x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().to(DEV))
+
+
+def from_rows(r, B, H, W):
+    return r.tensor().reshape(B, H, W, -1).permute(0, 3, 1, 2).cpu()
+
+
+def act_ref(v, act):
+    return {ACT_NONE: lambda t: t, ACT_RELU: F.relu, ACT_SILU: F.silu}[act](v)
+
+
+CONV_CASES = [
+    # Cin, Cout, k, stride, pad, dil, H, W, act, res, bn
+    (64, 64, 1, 1, 0, 1, 20, 20, ACT_RELU, False, True),
+    (64, 256, 1, 1, 0, 1, 13, 21, ACT_NONE, True, True),
+    (256, 128, 1, 2, 0, 1, 20, 20, ACT_NONE, False, True),        # downsample 1x1 s2
+    (128, 128, 3, 2, 1, 1, 21, 13, ACT_RELU, False, True),        # 3x3 s2 on odd sizes
+    (256, 256, 3, 1, 2, 2, 20, 20, ACT_SILU, False, True),        # HisBlock conv4: dilation 2
+    (256, 128, 3, 1, 1, 1, 5, 5, ACT_RELU, False, True),          # tiny level
+    (256, 80, 3, 1, 1, 1, 10, 10, ACT_NONE, False, False),        # cls_logits (bias only)
+    (256, 5, 3, 1, 1, 1, 10, 10, ACT_NONE, False, False),         # cnt+reg
+    (2048, 256, 1, 1, 0, 1, 20, 20, ACT_RELU, False, True),       # FPN lateral, K=2048
+    (32, 32, 3, 1, 1, 1, 16, 16, ACT_NONE, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_single_level(case):
+    Cin, Cout, k, stride, pad, dil, H, W, act, use_res, use_bn = case
+    gen = torch.Generator().manual_seed(hash(case) % 1000)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * k * k)
+    scale = torch.rand(Cout, generator=gen) + 0.5 if use_bn else None
+    shift = torch.randn(Cout, generator=gen)
+    ref = F.conv2d(x, w, None, stride, pad, dil)
+    ref = ref * (scale.view(1, -1, 1, 1) if use_bn else 1.0) + shift.view(1, -1, 1, 1)
+    Ho, Wo = ref.shape[2:]
+    res = torch.randn(B, Cout, Ho, Wo, generator=gen) if use_res else None
+    if use_res:
+        ref = ref + res
+    ref = act_ref(ref, act)
+    segs = Segs.make(B, [(H, W)])
+    xr = to_rows(x)
+    y = ops.new_rows(B * Ho * Wo, Cout, DEV)
+    rr = to_rows(res) if use_res else None
+    ops.conv_call(xr, segs, ops.pack_conv_weight(w.to(DEV)), y, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil,
+                  scale=scale.to(DEV) if use_bn else None, shift=shift.to(DEV), res=rr, act=act)()
+    np.testing.assert_allclose(from_rows(y, B, Ho, Wo).numpy(), ref.numpy(), atol=ATOL, rtol=RTOL)
+
+
+def test_conv_stem_7x7():
+    gen = torch.Generator().manual_seed(7)
+    B, H, W = 2, 64, 96
+    x = torch.randn(B, 3, H, W, generator=gen)
+    w = torch.randn(64, 3, 7, 7, generator=gen) / np.sqrt(147)
+    scale, shift = torch.rand(64, generator=gen) + 0.5, torch.randn(64, generator=gen)
+    ref = F.relu(F.conv2d(x, w, None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    x4 = torch.empty(B * H * W, 4, device=DEV)
+    ops.nchw3_to_nhwc4(x.to(DEV), x4)
+    assert torch.equal(x4.view(B, H, W, 4)[..., :3].permute(0, 3, 1, 2).cpu(), x) and x4[:, 3].abs().sum() == 0
+    y = ops.new_rows(B * 32 * 48, 64, DEV)
+    ops.conv_call(ops.Rows(x4), Segs.make(B, [(H, W)]), ops.pack_stem_weight(w.to(DEV)), y, Cin=4, Cout=64, k=7, stride=2,
+                  pad=3, scale=scale.to(DEV), shift=shift.to(DEV), act=ACT_RELU, stem=True)()
+    np.testing.assert_allclose(from_rows(y, B, 32, 48).numpy(), ref.numpy(), atol=ATOL, rtol=RTOL)
+
+
+def test_conv_pyramid_channel_views_and_exp():
+    """5 levels in one launch, input read from a channel slice, output written into a channel slice,
+    exp(scale_level * x) on channels >= 1 (the fused cnt_logits + reg_pred conv)."""
+    gen = torch.Generator().manual_seed(3)
+    B, F_ = 2, 64
+    hw = [(12, 20), (6, 10), (3, 5), (2, 3), (1, 1)]
+    segs = Segs.make(B, hw)
+    feats = [torch.randn(B, 2 * F_, h, w, generator=gen) for h, w in hw]
+    w = torch.randn(5, F_, 3, 3, generator=gen) / np.sqrt(9 * F_)
+    bias = torch.randn(5, generator=gen) * 0.1
+    scales = [0.8, 0.9, 1.0, 1.1, 1.2]
+    buf = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, 2 * F_) for f in feats]).contiguous().to(DEV)
+    out = torch.full((segs.rows, 8), -7.0, device=DEV)
+    ops.conv_call(ops.Rows(buf, F_, F_), segs, ops.pack_conv_weight(w.to(DEV)), ops.Rows(out, 2, 5), Cin=F_, Cout=5, k=3,
+                  pad=1, shift=bias.to(DEV), act=ACT_EXP, act_c0=1, seg_param=scales)()
+    o = out.cpu()
+    assert (o[:, :2] == -7).all() and (o[:, 7] == -7).all()
+    for i, (f, s) in enumerate(zip(feats, scales)):
+        ref = F.conv2d(f[:, F_:], w, bias, 1, 1)
+        ref = torch.cat([ref[:, :1], torch.exp(ref[:, 1:] * s)], 1)
+        got = o[segs.m_start[i]:segs.m_start[i + 1], 2:7].reshape(B, hw[i][0], hw[i][1], 5).permute(0, 3, 1, 2)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=ATOL, rtol=1e-4)
+
+
+def test_conv_full_width_head_tower_sample():
+    """The K6 shape at full width (256 -> 512, 3x3, K=2304) on a 40x40 + 20x20 pyramid."""
+    gen = torch.Generator().manual_seed(9)
+    B = 1
+    hw = [(40, 40), (20, 20)]
+    segs = Segs.make(B, hw)
+    feats = [torch.randn(B, 256, h, w, generator=gen) for h, w in hw]
+    w = torch.randn(512, 256, 3, 3, generator=gen) / np.sqrt(2304)
+    buf = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, 256) for f in feats]).contiguous().to(DEV)
+    y = ops.new_rows(segs.rows, 512, DEV)
+    ops.conv_call(ops.Rows(buf), segs, ops.pack_conv_weight(w.to(DEV)), y, Cin=256, Cout=512, k=3, pad=1)()
+    o = y.buf.cpu()
+    for i, f in enumerate(feats):
+        ref = F.conv2d(f, w, None, 1, 1)
+        got = o[segs.m_start[i]:segs.m_start[i + 1]].reshape(B, hw[i][0], hw[i][1], 512).permute(0, 3, 1, 2)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("k,s,pad,H,W", [(3, 2, 1, 32, 48), (2, 2, 0, 20, 20), (2, 2, 0, 13, 21)])
+def test_maxpool_and_add(k, s, pad, H, W):
+    gen = torch.Generator().manual_seed(1)
+    B, C = 2, 64
+    x = torch.randn(B, C, H, W, generator=gen)
+    ref = F.max_pool2d(x, k, s, pad)
+    Ho, Wo = ref.shape[2:]
+    add = torch.randn(B, C, Ho, Wo, generator=gen)
+    y = ops.new_rows(B * Ho * Wo, C, DEV)
+    ops.maxpool(to_rows(x), y, B, H, W, k, s, pad)
+    assert torch.equal(from_rows(y, B, Ho, Wo), ref)
+    ops.maxpool(to_rows(x), y, B, H, W, k, s, pad, add=to_rows(add))
+    assert torch.equal(from_rows(y, B, Ho, Wo), ref + add)
+
+
+def test_upsample2x_add():
+    gen = torch.Generator().manual_seed(2)
+    B, C, H, W = 2, 32, 5, 7
+    x, lat = torch.randn(B, C, H, W, generator=gen), torch.randn(B, C, 2 * H, 2 * W, generator=gen)
+    y = ops.new_rows(B * 4 * H * W, C, DEV)
+    ops.upsample2x_add(to_rows(x), to_rows(lat), y, B, H, W)
+    assert torch.equal(from_rows(y, B, 2 * H, 2 * W), F.interpolate(x, scale_factor=2.0, mode="nearest") + lat)
+
+
+def test_dwconv3x3_pyramid():
+    gen = torch.Generator().manual_seed(4)
+    B, C = 2, 128
+    hw = [(9, 11), (4, 5), (1, 1)]
+    segs = Segs.make(B, hw)
+    feats = [torch.randn(B, C, h, w, generator=gen) for h, w in hw]
+    w = torch.randn(C, 1, 3, 3, generator=gen) / 3
+    scale, shift = torch.rand(C, generator=gen) + .5, torch.randn(C, generator=gen)
+    buf = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, C) for f in feats]).contiguous().to(DEV)
+    y = ops.new_rows(segs.rows, C, DEV)
+    ops.dwconv3x3(ops.Rows(buf), ops.pack_dw_weight(w.to(DEV)), y, segs, scale.to(DEV), shift.to(DEV), ACT_RELU)
+    o = y.buf.cpu()
+    for i, f in enumerate(feats):
+        ref = F.relu(F.conv2d(f, w, None, 1, 1, 1, C) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+        got = o[segs.m_start[i]:segs.m_start[i + 1]].reshape(B, hw[i][0], hw[i][1], C).permute(0, 3, 1, 2)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("C,G,act", [(512, 32, ACT_RELU), (512, 64, ACT_SILU), (256, 32, ACT_RELU), (32, 32, ACT_NONE)])
+def test_groupnorm_pyramid(C, G, act):
+    gen = torch.Generator().manual_seed(C + G)
+    B = 3
+    hw = [(80, 80), (10, 10), (5, 5), (1, 1)]
+    segs = Segs.make(B, hw)
+    feats = [torch.randn(B, C, h, w, generator=gen) * 2 + 0.5 for h, w in hw]
+    gamma, beta = torch.rand(C, generator=gen) + .5, torch.randn(C, generator=gen)
+    buf = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, C) for f in feats]).contiguous().to(DEV)
+    x = ops.Rows(buf)
+    ws = ops.groupnorm_workspace(segs, G, DEV)
+    ops.groupnorm_act(x, gamma.to(DEV), beta.to(DEV), x, segs, G, act, ws)
+    o = buf.cpu()
+    for i, f in enumerate(feats):
+        if hw[i] == (1, 1) and C // G == 1:
+            continue  # a single-element group has zero variance: output is beta either way, checked below
+        ref = act_ref(F.group_norm(f, G, gamma, beta, 1e-5), act)
+        got = o[segs.m_start[i]:segs.m_start[i + 1]].reshape(B, hw[i][0], hw[i][1], C).permute(0, 3, 1, 2)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_se_block():
+    gen = torch.Generator().manual_seed(6)
+    B, C, Cr, H, W = 3, 128, 32, 20, 20
+    x = torch.randn(B, C, H, W, generator=gen)
+    w1, b1 = torch.randn(Cr, C, generator=gen) / 8, torch.randn(Cr, generator=gen) * .1
+    w2, b2 = torch.randn(C, Cr, generator=gen) / 4, torch.randn(C, generator=gen) * .1
+    g = torch.sigmoid(F.silu(x.mean((2, 3)) @ w1.t() + b1) @ w2.t() + b2)
+    ref = x * g[:, :, None, None]
+    out = torch.zeros(B * H * W, 2 * C, device=DEV)
+    ws = ops.se_workspace(B, H * W, C, DEV)
+    ops.se_scale(to_rows(x), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), ops.Rows(out, C, C), B, H * W, Cr, ws)
+    got = out[:, C:].reshape(B, H, W, C).permute(0, 3, 1, 2).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-5, rtol=1e-5)
+    assert out[:, :C].abs().sum() == 0

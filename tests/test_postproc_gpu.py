@@ -1,0 +1,182 @@
+"""GPU parity: HIP post-processing (through the C-ABI) vs the oracle and the golden fixtures.
+Kept-box indices, classes and box coordinates are bit-exact; scores (sigmoid/sqrt on device) within 2e-6 rel."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+from pytorch_object_detection_amd import ops
+from pytorch_object_detection_amd.model.modules.head import ClipBoxes, FCOSHead
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dtype) if dtype else t).to(DEV)
+
+
+def _rand_boxes(rng, n, crowded=False, size=640.0):
+    if crowded:
+        nc = max(1, n // 5)
+        cxy = rng.uniform(20, size - 20, (nc, 2)); wh = rng.uniform(16, 160, (nc, 2))
+        idx = rng.integers(0, nc, n)
+        c = cxy[idx] + rng.normal(0, 4, (n, 2)); s = wh[idx] * rng.uniform(0.85, 1.15, (n, 2))
+    else:
+        c = rng.uniform(0, size, (n, 2)); s = np.exp(rng.uniform(np.log(8), np.log(512), (n, 2)))
+    return np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("ncls", [20, 80])
+@pytest.mark.parametrize("tag", ["s5", "s4"])
+def test_decode_topk_golden(golden, ncls, tag):
+    g = golden("g2_decode_topk")
+    strides = [int(s) for s in g[f"c{ncls}_{tag}_strides"]]
+    outs = [[_t(g[f"c{ncls}_{n}{i}"]) for i in range(5)] for n in ("cls", "cnt", "reg")]
+    s, c, b = FCOSHead(0.05, 0.6, 100, strides).decode_topk(outs)
+    np.testing.assert_allclose(s.cpu().numpy(), g[f"c{ncls}_{tag}_scores"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_array_equal(c.cpu().numpy(), g[f"c{ncls}_{tag}_classes"])
+    np.testing.assert_array_equal(b.cpu().numpy(), g[f"c{ncls}_{tag}_boxes"])
+
+
+def test_decode_full_size_vs_oracle():
+    """640x640 pyramid, 80 classes, B=2: every location's score/class/box against the C restatement."""
+    gen = torch.Generator().manual_seed(11)
+    sizes = [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
+    strides = [8, 16, 32, 64, 128]
+    B, C = 2, 80
+    cls = [torch.randn(B, C, h, w, generator=gen) * 2 - 3 for h, w in sizes]
+    cnt = [torch.randn(B, 1, h, w, generator=gen) for h, w in sizes]
+    reg = [torch.exp(torch.randn(B, 4, h, w, generator=gen)) * 16 for h, w in sizes]
+    coords = np.concatenate([R.coords_fcos(h, w, s) for (h, w), s in zip(sizes, strides)], 0)
+    es, ec, eb = R.decode(R.flatten_levels(cls, 5), R.flatten_levels(cnt, 5), R.flatten_levels(reg, 5), coords)
+    from pytorch_object_detection_amd.model.modules.head import _as_pyramid
+    rc, segs = _as_pyramid([t.to(DEV) for t in cls], 5)
+    rn, _ = _as_pyramid([t.to(DEV) for t in cnt], 5)
+    rr, _ = _as_pyramid([t.to(DEV) for t in reg], 5)
+    s, c, b = ops.fcos_decode(rc, rn, rr, segs, strides)
+    np.testing.assert_allclose(s.cpu().numpy(), es, rtol=2e-6, atol=1e-7)
+    np.testing.assert_array_equal(b.cpu().numpy(), eb)
+    # class may legitimately differ only where two sigmoids tie within device/host exp rounding
+    diff = c.cpu().numpy() != ec
+    assert diff.mean() < 1e-4
+
+
+@pytest.mark.parametrize("L,K", [(8525, 1000), (23265, 1000), (341, 100), (50, 50), (1000, 1)])
+def test_topk_matches_stable_sort(L, K):
+    rng = np.random.default_rng(L + K)
+    B = 3
+    scores = rng.uniform(0, 1, (B, L)).astype(np.float32)
+    scores[:, rng.integers(0, L, L // 3)] = np.float32(0.25)     # heavy ties, also straddling the K-th value
+    scores[1] = np.round(scores[1] * 8) / 8                      # very few distinct values
+    classes = rng.integers(1, 81, (B, L)).astype(np.int32)
+    boxes = rng.uniform(0, 640, (B, L, 4)).astype(np.float32)
+    ts, tc, tb, ti = ops.fcos_topk(_t(scores), _t(classes), _t(boxes), K, want_idx=True)
+    idx = R.topk(scores, K)
+    np.testing.assert_array_equal(ti.cpu().numpy(), idx)
+    for b in range(B):
+        np.testing.assert_array_equal(ts[b].cpu().numpy(), scores[b][idx[b]])
+        np.testing.assert_array_equal(tc[b].cpu().numpy(), classes[b][idx[b]])
+        np.testing.assert_array_equal(tb[b].cpu().numpy(), boxes[b][idx[b]])
+
+
+def _run_batched_nms(boxes, scores, classes, thr, score_thr=0.0):
+    order = np.argsort(-scores, kind="stable")
+    s, c, b = scores[order][None], classes[order][None].astype(np.int64), boxes[order][None]
+    os_, oc, ob, keep, counts = ops.batched_nms(_t(s), _t(c), _t(b), score_thr, thr)
+    n = int(counts[0])
+    return order[keep[0, :n].cpu().numpy()], os_[0].cpu().numpy(), n
+
+
+def test_batched_nms_golden_kept_indices(golden):
+    g = golden("g3_nms")
+    for case in range(int(g["n_batched"])):
+        keep, _, _ = _run_batched_nms(g[f"b{case}_boxes"], g[f"b{case}_scores"], g[f"b{case}_classes"], float(g[f"b{case}_thr"]))
+        np.testing.assert_array_equal(keep, g[f"b{case}_keep"], err_msg=f"case {case}")
+    keep, _, _ = _run_batched_nms(g["edge_boxes"], g["edge_scores"], g["edge_classes"], 0.5)
+    np.testing.assert_array_equal(keep, g["edge_keep_0.5"])
+
+
+def test_box_nms_plus1_golden(golden):
+    g = golden("g3_nms")
+    for case in range(int(g["n_plus1"])):
+        boxes, scores = g[f"p{case}_boxes"], g[f"p{case}_scores"]
+        keep, counts = ops.box_nms_plus1(_t(boxes[None]), _t(scores[None]), float(g[f"p{case}_thr"]),
+                                         "union" if int(g[f"p{case}_mode"]) == 0 else "min")
+        np.testing.assert_array_equal(keep[0, :int(counts[0])].cpu().numpy(), g[f"p{case}_keep"], err_msg=f"case {case}")
+
+
+@pytest.mark.parametrize("crowded", [False, True])
+def test_batched_nms_full_size_batch_vs_oracle(crowded):
+    """BASELINE config: B=16 images x 1000 candidates, 80 classes, thresholds 0.05 / 0.6, fractional boxes."""
+    rng = np.random.default_rng(5 + crowded)
+    B, K = 16, 1000
+    scores = np.sort(np.sqrt(rng.uniform(0, 1, (B, K)) * rng.uniform(0, 1, (B, K))).astype(np.float32), axis=1)[:, ::-1].copy()
+    scores[3, 500:] = 0.01          # image with a short valid prefix
+    scores[4, :] = 0.01             # image with no candidate above the threshold
+    classes = rng.integers(1, 81, (B, K)).astype(np.int64)
+    boxes = np.stack([_rand_boxes(rng, K, crowded) for _ in range(B)])
+    boxes[5, :, :] -= 300.0         # negative coordinates: the offset trick lets classes overlap; must match anyway
+    os_, oc, ob, keep, counts = ops.batched_nms(_t(scores), _t(classes), _t(boxes), 0.05, 0.6)
+    exp = R.post_process(scores, classes, boxes, 0.05, 0.6)
+    for b in range(B):
+        n = int(counts[b])
+        np.testing.assert_array_equal(keep[b, :n].cpu().numpy(), exp[b], err_msg=f"image {b}")
+        assert (keep[b, n:] == -1).all() and (os_[b, n:] == 0).all()
+        np.testing.assert_array_equal(os_[b, :n].cpu().numpy(), scores[b][exp[b]])
+        np.testing.assert_array_equal(oc[b, :n].cpu().numpy(), classes[b][exp[b]])
+        np.testing.assert_array_equal(ob[b, :n].cpu().numpy(), boxes[b][exp[b]])
+    assert int(counts[4]) == 0
+    # size-independent properties: idempotence and sortedness
+    os2, oc2, ob2, keep2, counts2 = ops.batched_nms(os_, oc, ob, 0.05, 0.6)
+    assert torch.equal(counts2, counts) and torch.equal(os2, os_) and torch.equal(ob2, ob)
+    assert (os_[:, :-1] >= os_[:, 1:]).all()
+
+
+def test_nms_exact_threshold_double_compare():
+    """IoU 3/5 rounds to float32(0.6) > 0.6 (double): torchvision's CPU kernel suppresses it; so must we."""
+    boxes = np.array([[0, 0, 5, 4], [0, 0, 5, 4], [0, 0, 3, 4], [100, 100, 105, 104]], np.float32)
+    boxes[1] = [0, 0, 3, 4]; boxes[2] = [50, 50, 60, 60]      # box1 inside box0: inter 12, union 20 -> 0.6f
+    scores = np.array([0.9, 0.8, 0.7, 0.6], np.float32); classes = np.ones(4, np.int64)
+    assert np.float32(12) / np.float32(20) == np.float32(0.6)
+    keep, _, n = _run_batched_nms(boxes, scores, classes, 0.6)
+    np.testing.assert_array_equal(keep, R.batched_nms(boxes, scores, classes, 0.6))
+    assert 1 not in keep
+
+
+def test_pairwise_iou_bit_exact(golden):
+    g = golden("g4_pairwise_iou")
+    out = ops.pairwise_iou(_t(g["a"]), _t(g["b"]), True)
+    np.testing.assert_array_equal(out.cpu().numpy(), g["iou_plus1"])
+    rng = np.random.default_rng(0)
+    a, b = _rand_boxes(rng, 1000), _rand_boxes(rng, 700, True)
+    for p1 in (False, True):
+        np.testing.assert_array_equal(ops.pairwise_iou(_t(a), _t(b), p1).cpu().numpy(), R.pairwise_iou(a, b, p1))
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_head_end_to_end_golden(golden, ci):
+    g = golden("g3b_head_end2end")
+    sthr, thr, maxbox = g[f"e{ci}_cfg"]
+    outs = [[_t(g[f"e{ci}_{n}{i}"]) for i in range(5)] for n in ("cls", "cnt", "reg")]
+    s, c, b = FCOSHead(float(sthr), float(thr), int(maxbox), [8, 16, 32, 64, 128])(outs)
+    assert s.shape == g[f"e{ci}_scores"].shape and c.dtype == torch.int64
+    np.testing.assert_allclose(s.cpu().numpy(), g[f"e{ci}_scores"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_array_equal(c.cpu().numpy(), g[f"e{ci}_classes"])
+    np.testing.assert_array_equal(b.cpu().numpy(), g[f"e{ci}_boxes"])
+    clipped = ClipBoxes()(torch.zeros(1, 3, 128, 128, device=DEV), b.contiguous().clone())
+    np.testing.assert_array_equal(clipped.cpu().numpy(), g[f"e{ci}_clipped"])
+
+
+def test_head_ragged_batch_raises_like_reference_and_padded_works(golden):
+    g = golden("g3b_head_end2end")
+    outs = [[torch.cat([_t(g[f"e0_{n}{i}"]), _t(g[f"e2_{n}{i}"])[:, :_t(g[f"e0_{n}{i}"]).shape[1]]]) for i in range(5)]
+            for n in ("cls", "cnt", "reg")]
+    head = FCOSHead(0.05, 0.5, 200, [8, 16, 32, 64, 128])
+    s, c, b, counts = head.detect_padded(outs)
+    assert s.shape[0] == 2 and counts.shape == (2,)
+    np.testing.assert_allclose(s[0, :int(counts[0])].cpu().numpy(), g["e0_scores"][0], rtol=2e-6, atol=1e-7)
+    if int(counts[0]) != int(counts[1]):
+        with pytest.raises(RuntimeError, match="equal size"):
+            head(outs)
