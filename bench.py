@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of HISFCOS-R50 640x640 inference on MI355X (BASELINE.json metric, configs[1]/[2]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of synthetic images already resident in HBM:
+  model(x) [ResNet-50 trunk -> HIS FPN -> HIS head, all HIP kernels] -> FCOSHead (decode, top-1000, score >= 0.05,
+  per-class NMS 0.6) -> ClipBoxes, plus (N > 1) one RCCL all-gather of the padded detections.
+Per GPU: 16 images of 3x640x640 fp32 (weak scaling: the global batch is 16*N), 80 classes, random-init weights
+with randomised BN statistics, seeded.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(num_classes: int, seed: int):
+    from pytorch_object_detection_amd.model.od import HalfInvertedStageFCOS
+    torch.manual_seed(seed)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], num_classes, 256).eval()
+    gen = torch.Generator().manual_seed(seed + 1)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=gen) * 0.5 + 0.75)
+    return model
+
+
+def cpu_baseline(sd, num_classes: int, size: int, budget_s: float = 12.0):
+    """The oracle (CPU restatement of the reference's torch path) timed on this host's cores on a bounded sample."""
+    from oracle import torch_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(123)
+    strides = [8, 16, 32, 64, 128]
+
+    def one():
+        x = torch.randn(1, 3, size, size, generator=gen)
+        with torch.no_grad():
+            outs = R.hisfcos_forward(sd, x)
+        R.fcos_detect(outs, strides, 0.05, 0.6, 1000, (size, size))
+
+    one()  # warm-up (oneDNN primitive creation)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 16:
+            break
+    return {"value": round(n / el, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} single-image 640x640 forward+post-process passes of oracle/torch_ref.py "
+                      f"(torch {torch.__version__} CPU, {cores} threads) in {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--classes", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pytorch_object_detection_amd import _lib
+    from pytorch_object_detection_amd.dist import gather_detections
+    from pytorch_object_detection_amd.model.modules.head import ClipBoxes, FCOSHead
+    _lib.lib()
+
+    model = build_model(args.classes, seed=0)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    model.to(dev)
+    head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
+    clip = ClipBoxes()
+    gen = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(args.batch, 3, args.size, args.size, generator=gen).to(dev)
+
+    plan = model.plan_for(x)
+    tower_flops = 2 * plan.segs.rows * 512 * 256 * 9   # fused cls_conv + reg_conv 3x3, all 5 levels, this rank's batch
+    ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    nms_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        out = model(x, events=None if i is None else {"head.tower3x3": ev_pairs[i]})
+        s, c, b = head.decode_topk(out)
+        if i is not None:
+            nms_pairs[i][0].record()
+        from pytorch_object_detection_amd import ops
+        os_, oc, ob, _, counts = ops.batched_nms(s, c, b, 0.05, 0.6)
+        if i is not None:
+            nms_pairs[i][1].record()
+        ob = clip(x, ob)
+        return gather_detections(os_, oc, ob, counts)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        tower_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / args.steps
+        nms_ms = sum(a.elapsed_time(b) for a, b in nms_pairs) / args.steps
+        achieved = tower_flops / (tower_ms * 1e-3) / 1e12
+        ms_step = el / args.steps * 1e3
+        line = {
+            "metric": "images/sec HISFCOS-R50 640x640 inference",
+            "value": round(images / el, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"HISFCOS-R50 {args.size}x{args.size} batch={args.batch}/GPU inference on MI355X, "
+                                   f"fused conv head + HIP NMS ({args.classes} classes, score>=0.05, IoU 0.6, top-1000)"
+                                   + (", RCCL detection all-gather" if world > 1 else ""),
+                       "global_batch": args.batch * world, "parallelism": f"dp{world} (image-sharded)"},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<2,2,2,2> head tower 3x3 (cls_conv+reg_conv, 5 levels)",
+                         "instruction": "v_mfma_f32_32x32x2_f32", "achieved": round(achieved, 2),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": None, "flops_per_launch": tower_flops, "avg_launch_ms": round(tower_ms, 4)},
+            "model_conv_tflops": round(plan.flops / (ms_step * 1e-3) / 1e12, 2),
+            "nms_boxes_per_ms": round(args.batch * 1000 / nms_ms, 1), "nms_ms": round(nms_ms, 4),
+            "detections_kept_rank0": [int(v) for v in res[3][:args.batch].tolist()][:4],
+        }
+        if sd_cpu is not None:
+            line["cpu_baseline"] = cpu_baseline(sd_cpu, args.classes, args.size)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,9 +68,21 @@ class Plan:
         self.steps.append(fn)
         self.names.append(name)
 
-    def run(self) -> None:
-        for s in self.steps:
-            s()
+    def run(self, events=None) -> None:
+        """Launch every step on the current stream.  `events` maps a mark name to an (start, end) pair of
+        torch.cuda.Event recorded around that mark's launches (used by bench.py for per-kernel timing)."""
+        if not events:
+            for s in self.steps:
+                s()
+            return
+        i = 0
+        for lo, hi, (e0, e1) in sorted((self.marks[k][0], self.marks[k][1], ev) for k, ev in events.items()):
+            self.run_range(i, lo)
+            e0.record()
+            self.run_range(lo, hi)
+            e1.record()
+            i = hi
+        self.run_range(i, len(self.steps))
 
     def run_range(self, lo: int, hi: int) -> None:
         for s in self.steps[lo:hi]:

@@ -120,8 +120,8 @@ class FCOS(PlannedModule):
         B, _, H, W = x.shape
         return self._get_plan(("model", B, H, W, str(x.device)), lambda: self.build_plan(B, H, W, x.device))
 
-    def forward(self, x: torch.Tensor):
+    def forward(self, x: torch.Tensor, events=None):
         plan = self.plan_for(x)
         plan.image_ref[0] = x.contiguous()
-        plan.run()
+        plan.run(events)
         return tuple(pyramid_out(o, plan.segs) for o in plan.outs)

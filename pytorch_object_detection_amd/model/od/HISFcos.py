@@ -137,11 +137,11 @@ class HalfInvertedStageFCOS(PlannedModule):
         B, _, H, W = x.shape
         return self._get_plan(("model", B, H, W, str(x.device)), lambda: self.build_plan(B, H, W, x.device))
 
-    def forward(self, x: torch.Tensor):
+    def forward(self, x: torch.Tensor, events=None):
         """[B,3,H,W] fp32 CUDA -> (cls_logits, cnt_logits, reg_preds), each a list of 5 NCHW-shaped tensors
         (strides 8..128; reference HISFcos.py:70-74).  The tensors are views of plan-owned buffers and are
         overwritten by the next forward of the same shape."""
         plan = self.plan_for(x)
         plan.image_ref[0] = x.contiguous()
-        plan.run()
+        plan.run(events)
         return tuple(pyramid_out(o, plan.segs) for o in plan.outs)

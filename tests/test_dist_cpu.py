@@ -1,0 +1,55 @@
+"""world_size-2 gloo test of the detection all-gather (the only collective of the sharded inference path)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pytorch_object_detection_amd.dist import gather_detections, pack_detections, shard_batch, unpack_detections
+
+
+def test_shard_batch_partition():
+    for g, w in ((128, 8), (16, 1), (10, 4), (3, 8)):
+        spans = [shard_batch(g, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == g
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_pack_roundtrip():
+    s, c, b = torch.rand(3, 7), torch.randint(1, 81, (3, 7)), torch.rand(3, 7, 4) * 640
+    s2, c2, b2 = unpack_detections(pack_detections(s, c, b))
+    assert torch.equal(s, s2) and torch.equal(c, c2) and torch.equal(b, b2)
+
+
+def _worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gen = torch.Generator().manual_seed(100 + rank)
+        B, K = 2, 5
+        s = torch.rand(B, K, generator=gen)
+        c = torch.randint(1, 81, (B, K), generator=gen)
+        b = torch.rand(B, K, 4, generator=gen) * 640
+        n = torch.tensor([rank + 1, K - rank], dtype=torch.int32)
+        gs, gc, gb, gn = gather_detections(s, c, b, n)
+        assert gs.shape == (world * B, K) and gb.shape == (world * B, K, 4) and gn.shape == (world * B,)
+        for r in range(world):
+            gen_r = torch.Generator().manual_seed(100 + r)
+            es = torch.rand(B, K, generator=gen_r)
+            ec = torch.randint(1, 81, (B, K), generator=gen_r)
+            eb = torch.rand(B, K, 4, generator=gen_r) * 640
+            assert torch.equal(gs[r * B:(r + 1) * B], es) and torch.equal(gc[r * B:(r + 1) * B], ec)
+            assert torch.equal(gb[r * B:(r + 1) * B], eb)
+            assert gn[r * B:(r + 1) * B].tolist() == [r + 1, K - r]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_detections_gloo_world2():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker, args=(2, port), nprocs=2, join=True)
