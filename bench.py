@@ -40,10 +40,29 @@ def build_model(num_classes: int, seed: int):
     return model
 
 
+def usable_cores() -> int:
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box exposes
+    all host cores in os.cpu_count() but grants a 16-core share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get("FD_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(sd, num_classes: int, size: int, budget_s: float = 12.0):
     """The oracle (CPU restatement of the reference's torch path) timed on this host's cores on a bounded sample."""
     from oracle import torch_ref as R
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(123)
     strides = [8, 16, 32, 64, 128]
@@ -67,6 +86,33 @@ def cpu_baseline(sd, num_classes: int, size: int, budget_s: float = 12.0):
                       f"(torch {torch.__version__} CPU, {cores} threads) in {el:.1f} s"}
 
 
+def layer_times(plan, x, path, reps=5):
+    """Diagnostic: HIP-event time of every plan step (median of `reps`), with conv TFLOP/s where applicable."""
+    plan.image_ref[0] = x
+    for _ in range(2):
+        plan.run()
+    n = len(plan.steps)
+    acc = [[] for _ in range(n)]
+    for _ in range(reps):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        evs[0].record()
+        for i, st in enumerate(plan.steps):
+            st()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        for i in range(n):
+            acc[i].append(evs[i].elapsed_time(evs[i + 1]))
+    tot = 0.0
+    with open(path, "w") as f:
+        f.write("step\tname\tms\tgflop\ttflops\n")
+        for i, name in enumerate(plan.names):
+            ms = sorted(acc[i])[len(acc[i]) // 2]
+            tot += ms
+            fl = plan.step_flops.get(i, 0)
+            f.write(f"{i}\t{name}\t{ms:.4f}\t{fl / 1e9:.2f}\t{(fl / (ms * 1e-3) / 1e12) if fl else 0:.1f}\n")
+        f.write(f"#total_ms\t{tot:.3f}\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +122,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layer-times", default="", help="diagnostic: write per-plan-step timings (TSV) to this file and exit")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,6 +154,9 @@ def main():
     x = torch.randn(args.batch, 3, args.size, args.size, generator=gen).to(dev)
 
     plan = model.plan_for(x)
+    if args.layer_times:
+        layer_times(plan, x, args.layer_times)
+        return
     tower_flops = 2 * plan.segs.rows * 512 * 256 * 9   # fused cls_conv + reg_conv 3x3, all 5 levels, this rank's batch
     ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     nms_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]

@@ -87,6 +87,9 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise FdError(f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # torch bundles its own libamdhip64: import it first so this library binds to the SAME HIP runtime
+        # (two runtimes in one process => "no ROCm-capable device" / foreign stream handles)
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)

@@ -62,6 +62,7 @@ class Plan:
         self.pool = Pool(device)
         self.keep: List[object] = []       # tensors that must outlive the plan (packed weights, workspaces)
         self.flops = 0                     # algorithmic conv FLOPs (2*MACs) of one run
+        self.step_flops: Dict[int, int] = {}
         self.marks: Dict[str, Tuple[int, int]] = {}
 
     def add(self, name: str, fn: Callable[[], None]) -> None:
@@ -119,6 +120,7 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
                                  shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param))
     out = ops.conv_out_segs(segs, k, stride, pad, dil)
     plan.flops += 2 * out.rows * co * Cin * k * k
+    plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k
     return out
 
 
@@ -139,6 +141,7 @@ def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: Lis
     plan.add("backbone.conv1", ops.conv_call(x4, s_in, wp, y1, Cin=4, Cout=64, k=7, stride=2, pad=3, scale=sc, shift=sf,
                                              act=ACT_RELU, stem=True))
     plan.flops += 2 * s1.rows * 64 * 147
+    plan.step_flops[len(plan.steps) - 1] = 2 * s1.rows * 64 * 147
     pool.put(x4)
     H1, W1 = s1.H[0], s1.W[0]
     H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
