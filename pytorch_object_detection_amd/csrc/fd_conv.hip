@@ -26,6 +26,8 @@ struct ConvArgs {
     int m_out[FD_MAX_SEG + 1];   // first output row of the segment
     float seg_param[FD_MAX_SEG];
     int mtiles, ntiles;
+    int vec_epi;   // output / residual views are 16-byte addressable: transposed float4 epilogue
+    int is_gemm;   // 1x1 stride-1 unpadded conv: pure GEMM addressing
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -57,6 +59,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + lrow + 32 * i;
+        if (a.is_gemm) {  // 1x1, stride 1, no padding: the input row IS the output row (no divisions)
+            a_base[i] = m; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = (m < a.M) ? 1 : 0; a_W[i] = 1;
+            continue;
+        }
         int s = 0;
 #pragma unroll
         for (int t = 1; t < FD_MAX_SEG; ++t)
@@ -122,6 +128,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
+    // residual tile prefetch (vector epilogue): issued before the K loop so its HBM latency hides under the MFMAs
+    float4 rres[TM][TN][4];
+    if (a.res && a.vec_epi) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int m = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * p;
+                    const int nn = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
+                    rres[i][j][p] = (m < a.M && nn < a.Cout)
+                                        ? *reinterpret_cast<const float4*>(a.res + (size_t)m * a.res_cs + a.res_co + nn)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+    }
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -152,31 +174,71 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: acc reg e of lane l is C[row = (e&3) + 8*(e>>2) + 4*(l>>5)][col = l&31] ----
+    // Vector path: each 32x32 sub-tile is transposed through a per-wave LDS stage so that a lane owns 4 consecutive
+    // channels of one pixel: residual loads / output stores are 16 B per lane, 8 full 128-B lines per instruction
+    // (4x fewer memory instructions than storing straight from the accumulator layout).
+    float* stage = reinterpret_cast<float*>(smem) + wave * 1024;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + l31;
+        const int nb = n0 + (wn * TN + j) * 32;
+        const int n = nb + l31;
         const bool n_ok = n < a.Cout;
         const float sc = (a.scale && n_ok) ? a.scale[n] : 1.0f;
         const float sf = (a.shift && n_ok) ? a.shift[n] : 0.0f;
-        const int act = (n >= a.act_c0) ? a.act : FD_ACT_NONE;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm * TM + i) * 32 + 4 * lh;
+            const int mb = m0 + (wm * TM + i) * 32;
+            if (a.vec_epi) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (n_ok && m < a.M) {
-                    float v = acc[i][j][e] * sc + sf;
-                    if (a.res) v += a.res[(size_t)m * a.res_cs + a.res_co + n];
-                    float p = 0.f;
-                    if (act == FD_ACT_EXP) {
-                        int s = 0;
+                for (int e = 0; e < 16; ++e)
+                    stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + l31] = acc[i][j][e] * sc + sf;
+                __syncthreads();
 #pragma unroll
-                        for (int t = 1; t < FD_MAX_SEG; ++t)
-                            if (t < a.nseg && m >= a.m_out[t]) s = t;
-                        p = a.seg_param[s];
+                for (int p = 0; p < 4; ++p) {
+                    const int row = (lane >> 3) + 8 * p, c4 = (lane & 7) * 4;
+                    const int m = mb + row, nn = nb + c4;
+                    float4 v = *reinterpret_cast<const float4*>(stage + row * 32 + c4);
+                    if (m < a.M && nn < a.Cout) {
+                        if (a.res) {
+                            const float4 r = rres[i][j][p];
+                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        }
+                        if (a.act != FD_ACT_NONE) {
+                            float prm = 0.f;
+                            if (a.act == FD_ACT_EXP) {
+                                int s = 0;
+#pragma unroll
+                                for (int t = 1; t < FD_MAX_SEG; ++t)
+                                    if (t < a.nseg && m >= a.m_out[t]) s = t;
+                                prm = a.seg_param[s];
+                            }
+                            if (nn + 0 >= a.act_c0) v.x = fd_act(v.x, a.act, prm);
+                            if (nn + 1 >= a.act_c0) v.y = fd_act(v.y, a.act, prm);
+                            if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, prm);
+                            if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, prm);
+                        }
+                        *reinterpret_cast<float4*>(a.y + (size_t)m * a.y_cs + a.y_co + nn) = v;
                     }
-                    a.y[(size_t)m * a.y_cs + a.y_co + n] = fd_act(v, act, p);
+                }
+                __syncthreads();
+            } else {
+                const int act = (n >= a.act_c0) ? a.act : FD_ACT_NONE;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + 4 * lh + (e & 3) + 8 * (e >> 2);
+                    if (n_ok && m < a.M) {
+                        float v = acc[i][j][e] * sc + sf;
+                        if (a.res) v += a.res[(size_t)m * a.res_cs + a.res_co + n];
+                        float prm = 0.f;
+                        if (act == FD_ACT_EXP) {
+                            int s = 0;
+#pragma unroll
+                            for (int t = 1; t < FD_MAX_SEG; ++t)
+                                if (t < a.nseg && m >= a.m_out[t]) s = t;
+                            prm = a.seg_param[s];
+                        }
+                        a.y[(size_t)m * a.y_cs + a.y_co + n] = fd_act(v, act, prm);
+                    }
                 }
             }
         }
@@ -254,9 +316,22 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     else { a.ctiles = p->Cin / 32; a.KT = p->KH * p->KW * a.ctiles; a.Kpacked = p->KH * p->KW * p->Cin; }
     a.mtiles = a.ntiles = 0;
 
+    a.vec_epi = (p->Cout % 4 == 0 && p->y_cs % 4 == 0 && p->y_co % 4 == 0 && ((uintptr_t)p->y & 15) == 0 &&
+                 (!p->res || (p->res_cs % 4 == 0 && p->res_co % 4 == 0 && ((uintptr_t)p->res & 15) == 0)))
+                    ? 1 : 0;
+
+    a.is_gemm = (!stem && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0) ? 1 : 0;
+
     if (stem) return launch_conv<2, 2, 2, 1, true>(a, stream);       // 128 x 64
     if (a.Cout <= 32) return launch_conv<4, 1, 1, 1, false>(a, stream);   // 128 x 32
-    if (a.Cout <= 64) return launch_conv<2, 2, 2, 1, false>(a, stream);   // 128 x 64
-    if (a.M <= 2048) return launch_conv<2, 2, 1, 2, false>(a, stream);    // 64 x 128: more blocks for tiny maps
-    return launch_conv<2, 2, 2, 2, false>(a, stream);                     // 128 x 128
+    // Largest tile that still yields >= 2 workgroups per CU (256 CUs); tiny maps fall through to 64 x 64.
+    auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
+    const long want = 384;
+    if (a.Cout > 64 && a.Cout <= 96 && blocks(128, 96) >= want) return launch_conv<4, 1, 1, 3, false>(a, stream);  // 128 x 96
+    if (a.Cout > 64 && blocks(128, 128) >= want) return launch_conv<2, 2, 2, 2, false>(a, stream);
+    if (blocks(128, 64) >= want || a.Cout <= 64) {
+        if (a.Cout <= 64 && blocks(128, 64) < want) return launch_conv<2, 2, 1, 1, false>(a, stream);
+        return launch_conv<2, 2, 2, 1, false>(a, stream);             // 128 x 64
+    }
+    return launch_conv<2, 2, 1, 1, false>(a, stream);                 // 64 x 64
 }
