@@ -186,6 +186,31 @@ int32_t fd_ltrb_iou_loss_fwd(const float* pred, const float* target, const uint8
 int32_t fd_ltrb_iou_loss_bwd(const float* pred, const float* target, const uint8_t* mask, const float* gscale,
                              int32_t B, int32_t L, int32_t mode, float* grad_pred, fd_stream_t stream);
 
+/* Focal classification loss from logits (model/loss.py:6-28,180-193), alpha 0.25 / gamma 2 in the reference.
+ * logits [B][L][C], labels [B][L] int64 (1..C, 0 = background).  loss_per_image [B] = sum over [L][C]
+ * (not yet divided by num_pos).  backward: grad [B][L][C] = dloss_b/dlogits * gscale[b].  Only gamma == 2 is built.
+ * workspace: fd_focal_workspace_bytes(B). */
+int64_t fd_focal_workspace_bytes(int32_t B);
+int32_t fd_focal_loss_fwd(const float* logits, const int64_t* labels, int32_t B, int32_t L, int32_t C, float alpha,
+                          float gamma, float* loss_per_image, void* workspace, fd_stream_t stream);
+int32_t fd_focal_loss_bwd(const float* logits, const int64_t* labels, const float* gscale, int32_t B, int32_t L, int32_t C,
+                          float alpha, float gamma, float* grad_logits, fd_stream_t stream);
+
+/* Centerness loss: binary_cross_entropy_with_logits(reduction='sum') over positives (model/loss.py:31-57).
+ * x / target / mask [B][L]; loss_per_image [B] (sum), num_pos [B]; backward grad [B][L] = (sigmoid(x)-t)*gscale[b]. */
+int32_t fd_bce_logits_loss_fwd(const float* x, const float* target, const uint8_t* mask, int32_t B, int32_t L,
+                               float* loss_per_image, int32_t* num_pos, fd_stream_t stream);
+int32_t fd_bce_logits_loss_bwd(const float* x, const float* target, const uint8_t* mask, const float* gscale, int32_t B,
+                               int32_t L, float* grad, fd_stream_t stream);
+
+/* FCOS target assignment (FCOSGenTargets, model/modules/head.py:211-316): gt_boxes [B][M][4] xyxy (pad -1),
+ * labels [B][M] int64 (pad -1); per level: stride, (range_lo, range_hi]; centre-sampling radius = stride*radius_ratio
+ * (1.5 in the reference).  Outputs per image, levels concatenated: cls_target [B][L] int64 (0 = negative),
+ * cnt_target [B][L] (-1 = negative), reg_target [B][L][4] LTRB (-1 = negative).  segs->batch = B. */
+int32_t fd_fcos_gen_targets(const float* gt_boxes, const int64_t* labels, int32_t M, const fd_segs* segs,
+                            const int32_t* strides, const int32_t* range_lo, const int32_t* range_hi, float radius_ratio,
+                            int64_t* cls_target, float* cnt_target, float* reg_target, fd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

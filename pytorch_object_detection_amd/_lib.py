@@ -76,6 +76,12 @@ _SIGS = {
     "fd_clip_boxes": (_I, [_P, _L, _I, _I, _P]),
     "fd_ltrb_iou_loss_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "fd_ltrb_iou_loss_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "fd_focal_workspace_bytes": (_L, [_I]),
+    "fd_focal_loss_fwd": (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "fd_focal_loss_bwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _P, _P]),
+    "fd_bce_logits_loss_fwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "fd_bce_logits_loss_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
+    "fd_fcos_gen_targets": (_I, [_P, _P, _I, C.POINTER(Segs), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _F, _P, _P, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

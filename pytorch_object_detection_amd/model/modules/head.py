@@ -104,7 +104,9 @@ class ClipBoxes(nn.Module):
 
 
 class FCOSGenTargets(nn.Module):
-    """Target assignment (head.py:211-316) is a SURVEY §8(f) 'next' row and is not built yet."""
+    """FCOSGenTargets(strides, limit_range)([out, gt_boxes, classes]) -> (cls_target [B,L,1] int64,
+    cnt_target [B,L,1], reg_target [B,L,4]) (head.py:211-316) as one HIP kernel (fd_fcos_gen_targets): one thread
+    per (image, location) loops over the GT boxes in registers instead of materialising [B,HW,M,4] temporaries."""
 
     def __init__(self, strides: List[int], limit_range: List[List[int]]):
         super().__init__()
@@ -112,4 +114,8 @@ class FCOSGenTargets(nn.Module):
         self.stride, self.lim_range = strides, limit_range
 
     def forward(self, x):
-        raise FdError("FCOSGenTargets: the HIP target-assignment kernel is not built yet (SURVEY.md §8f n2)")
+        cls_logit = x[0][0]
+        gt_box, labels = x[1], x[2]
+        assert len(self.stride) == len(cls_logit)
+        level_hw = [(int(t.shape[2]), int(t.shape[3])) for t in cls_logit]
+        return ops.fcos_gen_targets(gt_box, labels, level_hw, self.stride, self.lim_range, 1.5)

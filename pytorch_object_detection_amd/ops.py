@@ -268,3 +268,61 @@ def ltrb_loss_bwd(pred: torch.Tensor, target: torch.Tensor, mask: torch.Tensor, 
     check(_lib.lib().fd_ltrb_iou_loss_bwd(pred.data_ptr(), target.data_ptr(), mask.data_ptr(), gscale.data_ptr(), B, L, mode,
                                           grad.data_ptr(), _stream()), "fd_ltrb_iou_loss_bwd")
     return grad
+
+
+def focal_loss_fwd(logits: torch.Tensor, labels: torch.Tensor, alpha: float = 0.25, gamma: float = 2.0) -> torch.Tensor:
+    """logits [B,L,C] f32, labels [B,L] int64 -> per-image summed focal loss [B]."""
+    _need_gpu(logits, labels)
+    B, L, Cn = logits.shape
+    loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+    ws = torch.empty(_lib.lib().fd_focal_workspace_bytes(B) // 8, dtype=torch.float64, device=logits.device)
+    check(_lib.lib().fd_focal_loss_fwd(logits.data_ptr(), labels.data_ptr(), B, L, Cn, alpha, gamma, loss.data_ptr(),
+                                       ws.data_ptr(), _stream()), "fd_focal_loss_fwd")
+    return loss
+
+
+def focal_loss_bwd(logits, labels, gscale, alpha: float = 0.25, gamma: float = 2.0) -> torch.Tensor:
+    B, L, Cn = logits.shape
+    grad = torch.empty_like(logits)
+    check(_lib.lib().fd_focal_loss_bwd(logits.data_ptr(), labels.data_ptr(), gscale.data_ptr(), B, L, Cn, alpha, gamma,
+                                       grad.data_ptr(), _stream()), "fd_focal_loss_bwd")
+    return grad
+
+
+def bce_loss_fwd(x: torch.Tensor, target: torch.Tensor, mask: torch.Tensor):
+    _need_gpu(x, target, mask)
+    B, L = x.shape
+    loss = torch.empty(B, dtype=torch.float32, device=x.device)
+    npos = torch.empty(B, dtype=torch.int32, device=x.device)
+    check(_lib.lib().fd_bce_logits_loss_fwd(x.data_ptr(), target.data_ptr(), mask.data_ptr(), B, L, loss.data_ptr(),
+                                            npos.data_ptr(), _stream()), "fd_bce_logits_loss_fwd")
+    return loss, npos
+
+
+def bce_loss_bwd(x, target, mask, gscale) -> torch.Tensor:
+    B, L = x.shape
+    grad = torch.empty_like(x)
+    check(_lib.lib().fd_bce_logits_loss_bwd(x.data_ptr(), target.data_ptr(), mask.data_ptr(), gscale.data_ptr(), B, L,
+                                            grad.data_ptr(), _stream()), "fd_bce_logits_loss_bwd")
+    return grad
+
+
+def fcos_gen_targets(gt_boxes: torch.Tensor, labels: torch.Tensor, level_hw, strides, ranges, radius: float = 1.5):
+    """gt_boxes [B,M,4] f32, labels [B,M] int64 -> (cls [B,L,1] int64, cnt [B,L,1] f32, reg [B,L,4] f32)."""
+    _need_gpu(gt_boxes, labels)
+    B, M = labels.shape
+    segs = Segs.make(B, list(level_hw))
+    L = sum(h * w for h, w in level_hw)
+    dev = gt_boxes.device
+    cls = torch.empty(B, L, 1, dtype=torch.int64, device=dev)
+    cnt = torch.empty(B, L, 1, dtype=torch.float32, device=dev)
+    reg = torch.empty(B, L, 4, dtype=torch.float32, device=dev)
+    n = len(level_hw)
+    st = (C.c_int32 * n)(*[int(s) for s in strides])
+    lo = (C.c_int32 * n)(*[int(r[0]) for r in ranges])
+    hi = (C.c_int32 * n)(*[int(r[1]) for r in ranges])
+    gb = gt_boxes.contiguous().float()
+    lb = labels.contiguous().to(torch.int64)
+    check(_lib.lib().fd_fcos_gen_targets(gb.data_ptr(), lb.data_ptr(), M, C.byref(segs), st, lo, hi, radius, cls.data_ptr(),
+                                         cnt.data_ptr(), reg.data_ptr(), _stream()), "fd_fcos_gen_targets")
+    return cls, cnt, reg

@@ -35,3 +35,23 @@ def load_config(cfg: str = os.path.join(_PKG, 'config', 'main.yaml')) -> dict:
                        'persistent': main['persistent_workers'], 'prefetch': main['prefetch_factor']}
     config['savename'] = main['savename']
     return config
+
+
+class DataEncoder:
+    """The two hot functions of the reference's DataEncoder (utill/utills.py:201-255) on the GPU.
+    Anchor encode/decode (RetinaNet path) is outside the FCOS hot path and not provided."""
+
+    def _box_iou(self, box1: torch.Tensor, box2: torch.Tensor, order: str = 'xyxy') -> torch.Tensor:
+        """[N,4] x [M,4] -> [N,M] IoU with the '+1' pixel convention."""
+        from .. import ops
+        if order != 'xyxy':
+            raise NotImplementedError("only order='xyxy' is built")
+        return ops.pairwise_iou(box1.contiguous().float(), box2.contiguous().float(), True)
+
+    def _box_nms(self, bboxes: torch.Tensor, scores: torch.Tensor, threshold: float = 0.5, mode: str = 'union') -> torch.Tensor:
+        """Greedy class-agnostic NMS, '+1' areas, keep while ovr <= threshold; returns kept indices (int64, score-descending)."""
+        from .. import ops
+        if mode not in ('union', 'min'):
+            raise TypeError('Unknown nms mode: %s.' % mode)
+        keep, counts = ops.box_nms_plus1(bboxes.contiguous().float()[None], scores.contiguous().float()[None], threshold, mode)
+        return keep[0, :int(counts[0])].to(torch.int64)

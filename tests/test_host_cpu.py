@@ -106,8 +106,8 @@ def test_no_cpu_fallback():
         head(outs)
     with pytest.raises(_lib.FdError):
         ops.clip_boxes_(torch.zeros(1, 4, 4), 10, 10)
-    with pytest.raises(_lib.FdError):
-        FCOSGenTargets([8], [[-1, 64]])(None)
+    with pytest.raises(_lib.FdError, match="GPU only"):
+        FCOSGenTargets([8], [[-1, 64]])([[[torch.zeros(1, 20, 4, 4)]], torch.zeros(1, 2, 4), torch.zeros(1, 2, dtype=torch.long)])
 
 
 def test_abi_argument_errors_without_gpu():
