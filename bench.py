@@ -109,7 +109,7 @@ def layer_times(plan, x, path, reps=5):
             ms = sorted(acc[i])[len(acc[i]) // 2]
             tot += ms
             fl = plan.step_flops.get(i, 0)
-            f.write(f"{i}\t{name}\t{ms:.4f}\t{fl / 1e9:.2f}\t{(fl / (ms * 1e-3) / 1e12) if fl else 0:.1f}\n")
+            f.write(f"{i}\t{name}\t{ms:.4f}\t{fl / 1e9:.2f}\t{(fl / (ms * 1e-3) / 1e12) if fl else 0:.1f}\t{plan.tiles.get(name, '')}\n")
         f.write(f"#total_ms\t{tot:.3f}\n")
 
 
@@ -137,7 +137,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FD_BENCH_FORCE_DIST") == "1"   # the env knob exercises the RCCL path with 1 rank
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from pytorch_object_detection_amd import _lib
@@ -171,21 +174,21 @@ def main():
         if i is not None:
             nms_pairs[i][1].record()
         ob = clip(x, ob)
-        return gather_detections(os_, oc, ob, counts)
+        return gather_detections(os_, oc, ob, counts, force=use_dist)
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         res = step(i)
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -216,7 +219,7 @@ def main():
         if sd_cpu is not None:
             line["cpu_baseline"] = cpu_baseline(sd_cpu, args.classes, args.size)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -70,6 +70,19 @@ const char* fd_last_error(void);
 #define FD_CONV_GENERIC 0
 #define FD_CONV_STEM 1
 
+/* block tiles (output pixels x output channels) of the conv kernel */
+#define FD_TILE_AUTO 0
+#define FD_TILE_128x128 1
+#define FD_TILE_128x64 2
+#define FD_TILE_64x128 3
+#define FD_TILE_64x64 4
+#define FD_TILE_128x32 5
+#define FD_TILE_128x96 6
+#define FD_TILE_128x128_SB 7 /* _SB: single LDS buffer (half the LDS, two barriers per K-tile) */
+#define FD_TILE_128x64_SB 8
+#define FD_TILE_64x128_SB 9
+#define FD_TILE_COUNT 9
+
 typedef struct fd_conv_params {
     const float* x;
     const float* w;
@@ -84,6 +97,7 @@ typedef struct fd_conv_params {
     int32_t act;    /* FD_ACT_* applied to output channels >= act_c0; channels below get identity */
     int32_t act_c0;
     int32_t mode;   /* FD_CONV_GENERIC | FD_CONV_STEM */
+    int32_t tile;   /* 0 = built-in heuristic; FD_TILE_* forces a block tile (plan-time autotuning) */
     float seg_param[FD_MAX_SEG]; /* per-level scalar for FD_ACT_EXP */
     fd_segs in;     /* input geometry */
 } fd_conv_params;

@@ -32,13 +32,14 @@ struct ConvArgs {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
-template <int WGM, int WGN, int TM, int TN, bool STEM>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB>
+__global__ __launch_bounds__(256, (SB && TM * TN == 4) ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int AP = BM / 32, BP = BN / 32;  // loader passes (32 rows x 8 chunks per pass)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* As = reinterpret_cast<float*>(smem);  // [2][BM*32]
-    float* Bs = As + 2 * BM * 32;                // [2][BN*32]
+    constexpr int NBUF = SB ? 1 : 2;             // SB: one LDS buffer (2 barriers per K-tile, half the LDS -> more blocks/CU)
+    float* As = reinterpret_cast<float*>(smem);  // [NBUF][BM*32]
+    float* Bs = As + NBUF * BM * 32;             // [NBUF][BN*32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -128,27 +129,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
-    // residual tile prefetch (vector epilogue): issued before the K loop so its HBM latency hides under the MFMAs
-    float4 rres[TM][TN][4];
-    if (a.res && a.vec_epi) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int m = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * p;
-                    const int nn = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
-                    rres[i][j][p] = (m < a.M && nn < a.Cout)
-                                        ? *reinterpret_cast<const float4*>(a.res + (size_t)m * a.res_cs + a.res_co + nn)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-    }
     load_tile(0);
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < a.KT; ++kt) {
-        const int buf = kt & 1;
+        const int buf = SB ? 0 : (kt & 1);
         if (kt + 1 < a.KT) load_tile(kt + 1);
         const float* Ab = As + buf * BM * 32 + (wm * TM * 32) * 32;
         const float* Bb = Bs + buf * BN * 32 + (wn * TN * 32) * 32;
@@ -169,10 +154,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < a.KT) store_tile(buf ^ 1);
+        if (SB) {
+            __syncthreads();                       // every wave is done reading the tile
+            if (kt + 1 < a.KT) store_tile(0);
+        } else if (kt + 1 < a.KT) {
+            store_tile(buf ^ 1);
+        }
         __syncthreads();
     }
 
+    // residual tile prefetch (vector epilogue): all 16-byte loads of the wave's tile issued back to back right after the K loop (they fly while the first sub-tile is staged)
+    float4 rres[TM][TN][4];
+    if (a.res && a.vec_epi) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int m = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * p;
+                    const int nn = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
+                    rres[i][j][p] = (m < a.M && nn < a.Cout)
+                                        ? *reinterpret_cast<const float4*>(a.res + (size_t)m * a.res_cs + a.res_co + nn)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+    }
     // ---- epilogue: acc reg e of lane l is C[row = (e&3) + 8*(e>>2) + 4*(l>>5)][col = l&31] ----
     // Vector path: each 32x32 sub-tile is transposed through a per-wave LDS stage so that a lane owns 4 consecutive
     // channels of one pixel: residual loads / output stores are 16 B per lane, 8 full 128-B lines per instruction
@@ -245,14 +251,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, bool STEM>
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    constexpr int lds = 2 * (BM + BN) * 32 * 4;
+    constexpr int lds_ab = (SB ? 1 : 2) * (BM + BN) * 32 * 4;
+    constexpr int lds = lds_ab > 16384 ? lds_ab : 16384;   // the epilogue stages 4 x 4 KiB
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM>;
+    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -323,6 +330,19 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     a.is_gemm = (!stem && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0) ? 1 : 0;
 
     if (stem) return launch_conv<2, 2, 2, 1, true>(a, stream);       // 128 x 64
+    switch (p->tile) {
+        case FD_TILE_AUTO: break;
+        case FD_TILE_128x128: return launch_conv<2, 2, 2, 2, false>(a, stream);
+        case FD_TILE_128x64: return launch_conv<2, 2, 2, 1, false>(a, stream);
+        case FD_TILE_64x128: return launch_conv<2, 2, 1, 2, false>(a, stream);
+        case FD_TILE_64x64: return launch_conv<2, 2, 1, 1, false>(a, stream);
+        case FD_TILE_128x32: return launch_conv<4, 1, 1, 1, false>(a, stream);
+        case FD_TILE_128x96: return launch_conv<4, 1, 1, 3, false>(a, stream);
+        case FD_TILE_128x128_SB: return launch_conv<2, 2, 2, 2, false, true>(a, stream);
+        case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true>(a, stream);
+        case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true>(a, stream);
+        default: fd_set_error("fd_conv2d: unknown tile id %d", p->tile); return FD_E_INVAL;
+    }
     if (a.Cout <= 32) return launch_conv<4, 1, 1, 1, false>(a, stream);   // 128 x 32
     // Largest tile that still yields >= 2 workgroups per CU (256 CUs); tiny maps fall through to 64 x 64.
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };

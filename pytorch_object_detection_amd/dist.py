@@ -25,11 +25,11 @@ def unpack_detections(packed: torch.Tensor):
     return packed[..., 4].contiguous(), packed[..., 5].to(torch.int64), packed[..., :4].contiguous()
 
 
-def gather_detections(scores, classes, boxes, counts, group=None):
+def gather_detections(scores, classes, boxes, counts, group=None, force: bool = False):
     """All-gather padded detections from every rank: returns (scores [W*B,K], classes, boxes [W*B,K,4], counts [W*B]).
     Every rank must hold the same local batch B and K (pad the last shard).  Two fixed-size messages per rank:
     B*K*6 floats (384 KB at B=16, K=1000) and B int32 counts."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return scores, classes, boxes, counts
     world = dist.get_world_size(group)
     packed = pack_detections(scores, classes, boxes)

@@ -20,6 +20,11 @@ from ._lib import ACT_EXP, ACT_NONE, ACT_RELU, ACT_SILU, FdError, Segs
 from .ops import Rows
 
 
+import os as _os
+
+AUTOTUNE = _os.environ.get("FD_AUTOTUNE", "1") != "0"
+
+
 class PRows(Rows):
     """Rows carved from a pooled flat buffer."""
     __slots__ = ("_flat",)
@@ -64,6 +69,8 @@ class Plan:
         self.flops = 0                     # algorithmic conv FLOPs (2*MACs) of one run
         self.step_flops: Dict[int, int] = {}
         self.marks: Dict[str, Tuple[int, int]] = {}
+        self.autotune = AUTOTUNE        # time block-tile candidates per conv at plan-build time
+        self.tiles: Dict[str, int] = {}
 
     def add(self, name: str, fn: Callable[[], None]) -> None:
         self.steps.append(fn)
@@ -116,9 +123,13 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     elif b is not None:
         shift = _dev(b, dev)
     plan.keep += [wp, scale, shift]
-    plan.add(name, ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
-                                 shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param))
+    call = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
+                         shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param)
+    plan.add(name, call)
     out = ops.conv_out_segs(segs, k, stride, pad, dil)
+    if plan.autotune:
+        key = (tuple(segs.level_hw()), segs.batch, Cin, co, k, stride, pad, dil, res is not None, x.cs, y.cs)
+        plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co)
     plan.flops += 2 * out.rows * co * Cin * k * k
     plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k
     return out

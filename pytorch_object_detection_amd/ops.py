@@ -90,7 +90,7 @@ def fold_bn(weight, bias, mean, var, eps: float = 1e-5, conv_bias: Optional[torc
 def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int, Cout: int, k: int, stride: int = 1,
               pad: int = 0, dil: int = 1, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
               res: Optional[Rows] = None, act: int = ACT_NONE, act_c0: int = 0,
-              seg_param: Optional[Sequence[float]] = None, stem: bool = False) -> Callable[[], None]:
+              seg_param: Optional[Sequence[float]] = None, stem: bool = False, tile: int = 0) -> Callable[[], None]:
     """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream."""
     _need_gpu(w_packed, scale, shift)
     p = ConvParams()
@@ -103,6 +103,7 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
         p.res_cs, p.res_co = res.cs, res.co
     p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, k, stride, pad, dil
     p.act, p.act_c0, p.mode = act, act_c0, (_lib.CONV_STEM if stem else _lib.CONV_GENERIC)
+    p.tile = tile
     if seg_param is not None:
         for i, v in enumerate(seg_param):
             p.seg_param[i] = float(v)
@@ -114,7 +115,43 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     def run(_keep=keep):
         check(fn(ref, _stream()), "fd_conv2d_nhwc_f32")
 
+    run.params = p  # type: ignore[attr-defined]   (autotuning rewrites p.tile in place)
     return run
+
+
+_TUNE_CACHE: dict = {}
+
+
+def autotune_conv(run: Callable[[], None], key: tuple, M: int, Cout: int, reps: int = 3) -> int:
+    """Time the conv launch under every sensible block tile and keep the fastest (plan-time, once per distinct
+    conv shape per process).  The built-in heuristic (tile 0) is always a candidate.  Returns the chosen tile id."""
+    hit = _TUNE_CACHE.get(key)
+    p = run.params  # type: ignore[attr-defined]
+    if hit is not None:
+        p.tile = hit
+        return hit
+    cands = [0]
+    for tid, (bm, bn) in _lib.TILES.items():
+        padded = -(-Cout // bn) * bn
+        if padded <= max(32, int(Cout * 1.34)) and not (bn == 32 and Cout > 32):
+            cands.append(tid)
+    best, best_t = 0, float("inf")
+    for tid in cands:
+        p.tile = tid
+        run()  # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1) / reps
+        if t < best_t * 0.98 or best_t == float("inf"):  # prefer the earlier candidate on near-ties
+            if t < best_t:
+                best, best_t = tid, t
+    p.tile = best
+    _TUNE_CACHE[key] = best
+    return best
 
 
 def conv_out_segs(segs: Segs, k: int, stride: int, pad: int, dil: int) -> Segs:
