@@ -40,6 +40,18 @@ def build_model(num_classes: int, seed: int):
     return model
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the roofline kernel from the separate rocprofv3 --pmc passes of this same command
+    (tools_pmc.sh -> tools_pmc_summary.py -> profiles/pmc_traffic.json): 2 x FETCH_SIZE (gfx950 reports half of a
+    16-B/lane stream; calibrated on kernels of known byte count) + WRITE_SIZE.  None when no PMC run is recorded
+    for batch 16 / 640x640."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return d["head_tower_conv"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def usable_cores() -> int:
     """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box exposes
     all host cores in os.cpu_count() but grants a 16-core share)."""
@@ -79,11 +91,58 @@ def cpu_baseline(sd, num_classes: int, size: int, budget_s: float = 12.0):
         one()
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 16:
+        if el >= budget_s or n >= 256:
             break
     return {"value": round(n / el, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{n} single-image 640x640 forward+post-process passes of oracle/torch_ref.py "
                       f"(torch {torch.__version__} CPU, {cores} threads) in {el:.1f} s"}
+
+
+def nms_micro(dev, batch: int, with_cpu: bool):
+    """NMS micro-benchmark of SURVEY.md §8(d): per image 8 525 candidates (scores sqrt(U*U), 80 classes, box centres
+    uniform in 640x640, log-uniform sizes 8-512 px, plus 200 clusters x 5 jittered copies) -> top-1000 -> score >= 0.05
+    -> per-class NMS 0.6.  boxes/ms = batch * candidates entering NMS / device time of the NMS call."""
+    import numpy as np
+    from pytorch_object_detection_amd import ops
+    rng = np.random.default_rng(0)
+    L, K = 8525, 1000
+    c = rng.uniform(0, 640, (batch, L, 2)); sz = np.exp(rng.uniform(np.log(8), np.log(512), (batch, L, 2)))
+    cc = rng.uniform(40, 600, (batch, 200, 2)); cs = rng.uniform(24, 200, (batch, 200, 2))
+    for b in range(batch):                                    # crowded subset: the first 1000 locations
+        idx = np.repeat(np.arange(200), 5)
+        c[b, :1000] = cc[b, idx] + rng.normal(0, 4, (1000, 2)); sz[b, :1000] = cs[b, idx] * rng.uniform(0.9, 1.1, (1000, 2))
+    boxes = np.concatenate([c - sz / 2, c + sz / 2], -1).astype(np.float32)
+    scores = np.sqrt(rng.uniform(0, 1, (batch, L)) * rng.uniform(0, 1, (batch, L))).astype(np.float32)
+    scores[:, :1000] = np.maximum(scores[:, :1000], 0.6).astype(np.float32) + rng.uniform(0, 0.3, (batch, 1000)).astype(np.float32)
+    classes = rng.integers(1, 81, (batch, L)).astype(np.int32)
+    classes[:, :1000] = np.repeat(rng.integers(1, 81, (batch, 200)), 5, axis=1)
+    ds, dc, db = (torch.from_numpy(a).to(dev) for a in (scores, classes, boxes))
+    reps = 20
+    for _ in range(3):
+        ts, tc, tb = ops.fcos_topk(ds, dc, db, K)
+        out = ops.batched_nms(ts, tc, tb, 0.05, 0.6)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_topk = t_nms = 0.0
+    for _ in range(reps):
+        e[0].record(); ts, tc, tb = ops.fcos_topk(ds, dc, db, K)
+        e[1].record(); out = ops.batched_nms(ts, tc, tb, 0.05, 0.6)
+        e[2].record(); e[2].synchronize()
+        t_topk += e[0].elapsed_time(e[1]); t_nms += e[1].elapsed_time(e[2])
+    t_topk /= reps; t_nms /= reps
+    res = {"boxes_per_ms": round(batch * K / t_nms, 1), "nms_ms": round(t_nms, 4), "topk_ms": round(t_topk, 4),
+           "kept_mean": round(float(out[4].float().mean()), 1), "candidates_per_image": K, "batch": batch}
+    if with_cpu:
+        from oracle import torch_ref as R
+        hs, hc, hb = ts.cpu().numpy(), tc.cpu().numpy(), tb.cpu().numpy()
+        t0 = time.perf_counter()
+        n_img = min(batch, 8)
+        keeps = R.post_process(hs[:n_img], hc[:n_img], hb[:n_img], 0.05, 0.6)
+        el = time.perf_counter() - t0
+        res["cpu_boxes_per_ms"] = round(n_img * K / (el * 1e3), 2)
+        res["cpu_sample"] = f"oracle/postproc_ref.c ref_post_process, 1 thread, {n_img} images"
+        kd = out[3].cpu().numpy()
+        res["matches_oracle"] = bool(all((kd[i, :len(k)] == k).all() and (kd[i, len(k):] == -1).all() for i, k in enumerate(keeps)))
+    return res
 
 
 def layer_times(plan, x, path, reps=5):
@@ -211,11 +270,12 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<2,2,2,2> head tower 3x3 (cls_conv+reg_conv, 5 levels)",
                          "instruction": "v_mfma_f32_32x32x2_f32", "achieved": round(achieved, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": None, "flops_per_launch": tower_flops, "avg_launch_ms": round(tower_ms, 4)},
+                         "traffic": pmc_traffic(), "flops_per_launch": tower_flops, "avg_launch_ms": round(tower_ms, 4)},
             "model_conv_tflops": round(plan.flops / (ms_step * 1e-3) / 1e12, 2),
             "nms_boxes_per_ms": round(args.batch * 1000 / nms_ms, 1), "nms_ms": round(nms_ms, 4),
             "detections_kept_rank0": [int(v) for v in res[3][:args.batch].tolist()][:4],
         }
+        line["nms_micro"] = nms_micro(dev, args.batch, with_cpu=sd_cpu is not None)
         if sd_cpu is not None:
             line["cpu_baseline"] = cpu_baseline(sd_cpu, args.classes, args.size)
         print(json.dumps(line), flush=True)

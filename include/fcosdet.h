@@ -170,10 +170,13 @@ int32_t fd_fcos_topk(const float* scores, const int32_t* classes, const float* b
  * (FCOSHead.post_process, head.py:84-102).  Input rows must be score-descending (fd_fcos_topk
  * output).  Greedy rule: suppress j when (double)iou(i,j) > iou_thr, iou on class-offset boxes
  * without the "+1" pixel convention.  Outputs padded to [N][K] (rows >= counts[n] zero-filled),
- * keep_idx[n][r] = index into the K input rows.  K <= 1024. */
+ * keep_idx[n][r] = index into the K input rows.  K <= 1024.  Two launches: the suppression bitmask is built by
+ * K/64 workgroups per image into `workspace` (fd_nms_workspace_bytes), one workgroup per image then scans it.
+ * Outputs must not alias inputs. */
+int64_t fd_nms_workspace_bytes(int32_t N, int32_t K);
 int32_t fd_batched_nms(const float* scores, const int64_t* classes, const float* boxes, int32_t N, int32_t K,
                        float score_thr, double iou_thr, float* out_scores, int64_t* out_classes,
-                       float* out_boxes, int32_t* keep_idx, int32_t* counts, fd_stream_t stream);
+                       float* out_boxes, int32_t* keep_idx, int32_t* counts, void* workspace, fd_stream_t stream);
 
 /* Class-agnostic greedy NMS with the "+1" pixel convention, keep while ovr <= (float)thr
  * (DataEncoder._box_nms, utill/utills.py:221-255; mode 0 = 'union', 1 = 'min').

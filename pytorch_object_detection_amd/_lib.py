@@ -72,7 +72,8 @@ _SIGS = {
     "fd_fcos_decode": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, C.POINTER(Segs), C.POINTER(_I), _P, _P, _P, _P]),
     "fd_topk_workspace_bytes": (_L, [_I, _I, _I]),
     "fd_fcos_topk": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "fd_batched_nms": (_I, [_P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P, _P]),
+    "fd_nms_workspace_bytes": (_L, [_I, _I]),
+    "fd_batched_nms": (_I, [_P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P, _P, _P]),
     "fd_box_nms_plus1": (_I, [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P]),
     "fd_pairwise_iou": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "fd_clip_boxes": (_I, [_P, _L, _I, _I, _P]),

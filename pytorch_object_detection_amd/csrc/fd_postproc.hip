@@ -246,39 +246,10 @@ struct NmsShared {
 
 // PLUS1 = false: torchvision nms rule, suppress when (double)ovr > thr_d
 // PLUS1 = true : DataEncoder._box_nms rule (utills.py:221-255), suppress when ovr > thr_f ; mode 1 = 'min'
-template <bool PLUS1>
-__device__ __forceinline__ void nms_core(NmsShared& sh, int n, double thr_d, float thr_f, int mode, int tid) {
+// greedy pass over the LDS bitmask: wave 0 resolves each 64-box block's dependency chain on SGPR state, then the
+// other waves OR the kept rows into the later words.  Needs sh.mask filled and sh.remv / sh.kept zeroed.
+__device__ __forceinline__ void nms_scan(NmsShared& sh, int n, int tid) {
     const int nw = (n + 63) >> 6;
-    // ---- suppression mask, upper triangle ----
-    for (int idx = tid; idx < n * nw; idx += 1024) {
-        const int i = idx / nw, w = idx - i * nw;
-        if (w < (i >> 6)) continue;
-        const float4 bi = sh.box[i];
-        const float ai = sh.area[i];
-        unsigned long long bits = 0ull;
-        const int j0 = w << 6;
-        const int jend = min(64, n - j0);
-        for (int b = 0; b < jend; ++b) {
-            const int j = j0 + b;
-            if (j <= i) continue;
-            const float4 bj = sh.box[j];
-            const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-            const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-            float ww, hh;
-            if (PLUS1) { ww = fmaxf((xx2 - xx1) + 1.0f, 0.0f); hh = fmaxf((yy2 - yy1) + 1.0f, 0.0f); }
-            else       { ww = fmaxf(0.0f, xx2 - xx1);          hh = fmaxf(0.0f, yy2 - yy1); }
-            const float inter = ww * hh;
-            float ovr;
-            if (PLUS1 && mode == 1) ovr = inter / fminf(sh.area[j], ai);
-            else                    ovr = inter / ((ai + sh.area[j]) - inter);
-            const bool sup = PLUS1 ? (ovr > thr_f) : ((double)ovr > thr_d);
-            if (sup) bits |= 1ull << b;
-        }
-        sh.mask[i * NMS_NW + w] = bits;
-    }
-    if (tid < NMS_NW) { sh.remv[tid] = 0ull; sh.kept[tid] = 0ull; }
-    __syncthreads();
-
     // ---- serial scan, one 64-box block at a time ----
     const int lane = tid & 63, wv = tid >> 6;
     for (int blk = 0; blk < nw; ++blk) {
@@ -326,6 +297,42 @@ __device__ __forceinline__ void nms_core(NmsShared& sh, int n, double thr_d, flo
     }
 }
 
+template <bool PLUS1>
+__device__ __forceinline__ void nms_core(NmsShared& sh, int n, double thr_d, float thr_f, int mode, int tid) {
+    const int nw = (n + 63) >> 6;
+    // ---- suppression mask, upper triangle ----
+    for (int idx = tid; idx < n * nw; idx += 1024) {
+        const int i = idx / nw, w = idx - i * nw;
+        if (w < (i >> 6)) continue;
+        const float4 bi = sh.box[i];
+        const float ai = sh.area[i];
+        unsigned long long bits = 0ull;
+        const int j0 = w << 6;
+        const int jend = min(64, n - j0);
+        for (int b = 0; b < jend; ++b) {
+            const int j = j0 + b;
+            if (j <= i) continue;
+            const float4 bj = sh.box[j];
+            const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+            const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+            float ww, hh;
+            if (PLUS1) { ww = fmaxf((xx2 - xx1) + 1.0f, 0.0f); hh = fmaxf((yy2 - yy1) + 1.0f, 0.0f); }
+            else       { ww = fmaxf(0.0f, xx2 - xx1);          hh = fmaxf(0.0f, yy2 - yy1); }
+            const float inter = ww * hh;
+            float ovr;
+            if (PLUS1 && mode == 1) ovr = inter / fminf(sh.area[j], ai);
+            else                    ovr = inter / ((ai + sh.area[j]) - inter);
+            const bool sup = PLUS1 ? (ovr > thr_f) : ((double)ovr > thr_d);
+            if (sup) bits |= 1ull << b;
+        }
+        sh.mask[i * NMS_NW + w] = bits;
+    }
+    if (tid < NMS_NW) { sh.remv[tid] = 0ull; sh.kept[tid] = 0ull; }
+    __syncthreads();
+
+    nms_scan(sh, n, tid);
+}
+
 __device__ __forceinline__ int nms_rank(const NmsShared& sh, int r) {
     int rank = 0;
     const int w = r >> 6;
@@ -334,64 +341,125 @@ __device__ __forceinline__ int nms_rank(const NmsShared& sh, int r) {
     return rank;
 }
 
-__global__ __launch_bounds__(1024) void batched_nms_kernel(const float* __restrict__ scores,
-                                                            const long long* __restrict__ classes,
-                                                            const float* __restrict__ boxes, int K, float score_thr,
-                                                            double iou_thr, float* out_scores, long long* out_classes,
-                                                            float* out_boxes, int* keep_idx, int* counts) {
-    __shared__ NmsShared sh;
-    const int img = blockIdx.x, tid = threadIdx.x;
-    const long base = (long)img * K;
-    const int lane = tid & 63, wv = tid >> 6;
+// ---- batched NMS, multi-block: (1) every (image, 64-row block) builds its slice of the suppression bitmask on its
+// own CU and writes it to a global workspace, (2) one workgroup per image pulls the mask into LDS and runs the scan.
+struct NmsPrepShared {
+    float4 box[NMS_MAXK];
+    float area[NMS_MAXK];
+    float red[16];
+    int n_valid;
+};
 
-    // valid prefix: rows are score-descending, so {score >= thr} is [0, n)
-    float sc = 0.f;
-    bool ok = false;
-    if (tid < K) { sc = scores[base + tid]; ok = sc >= score_thr; }
+// valid prefix {score >= thr} = [0, n) (rows are score-descending), boxes.max() over it, class-offset boxes + areas
+// (torchvision _batched_nms_coordinate_trick).  blockDim.x threads cooperate; returns n.
+template <typename SH>
+__device__ __forceinline__ int nms_prep(SH& sh, const float* __restrict__ scores, const long long* __restrict__ classes,
+                                        const float* __restrict__ boxes, long base, int K, float score_thr, int tid, int nthr) {
     if (tid == 0) sh.n_valid = 0;
+    if (tid < 16) sh.red[tid] = -INFINITY;
     __syncthreads();
-    const unsigned long long bal = __ballot(ok);
-    if (lane == 0 && bal) atomicAdd(&sh.n_valid, __popcll(bal));
+    int cnt = 0;
+    for (int i = tid; i < K; i += nthr) cnt += (scores[base + i] >= score_thr) ? 1 : 0;
+    if (cnt) atomicAdd(&sh.n_valid, cnt);
     __syncthreads();
     const int n = sh.n_valid;
-
-    // boxes.max() over the masked boxes (torchvision _batched_nms_coordinate_trick)
-    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
     float mx = -INFINITY;
-    if (tid < n) {
-        bx = reinterpret_cast<const float4*>(boxes)[base + tid];
-        mx = fmaxf(fmaxf(bx.x, bx.y), fmaxf(bx.z, bx.w));
+    for (int i = tid; i < n; i += nthr) {
+        const float4 bx = reinterpret_cast<const float4*>(boxes)[base + i];
+        mx = fmaxf(mx, fmaxf(fmaxf(bx.x, bx.y), fmaxf(bx.z, bx.w)));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if (lane == 0) sh.red[wv] = mx;
+    if ((tid & 63) == 0) sh.red[tid >> 6] = mx;
     __syncthreads();
     float maxc = sh.red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) maxc = fmaxf(maxc, sh.red[w]);
-    long long cl = 0;
-    if (tid < n) {
-        cl = classes[base + tid];
-        const float off = (float)cl * (maxc + 1.0f);
+    for (int i = tid; i < n; i += nthr) {
+        const float4 bx = reinterpret_cast<const float4*>(boxes)[base + i];
+        const float off = (float)classes[base + i] * (maxc + 1.0f);
         const float4 ob = make_float4(bx.x + off, bx.y + off, bx.z + off, bx.w + off);
-        sh.box[tid] = ob;
-        sh.area[tid] = (ob.z - ob.x) * (ob.w - ob.y);
+        sh.box[i] = ob;
+        sh.area[i] = (ob.z - ob.x) * (ob.w - ob.y);
     }
     __syncthreads();
+    return n;
+}
 
-    if (n > 0) nms_core<false>(sh, n, iou_thr, 0.f, 0, tid);
-
-    // ---- ordered compaction + gathers; rows >= count are zero-filled ----
-    int total = 0;
-    if (n > 0) {
-        const int nw = (n + 63) >> 6;
-        for (int q = 0; q < nw; ++q) total += __popcll(sh.kept[q]);
+__device__ __forceinline__ unsigned long long nms_mask_word(const float4* box, const float* area, int i, int w, int n,
+                                                             double thr_d) {
+    const float4 bi = box[i];
+    const float ai = area[i];
+    unsigned long long bits = 0ull;
+    const int j0 = w << 6;
+    const int jend = min(64, n - j0);
+    for (int b = 0; b < jend; ++b) {
+        const int j = j0 + b;
+        if (j <= i) continue;
+        const float4 bj = box[j];
+        const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+        const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+        const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
+        const float inter = ww * hh;
+        const float ovr = inter / ((ai + area[j]) - inter);
+        if ((double)ovr > thr_d) bits |= 1ull << b;
     }
+    return bits;
+}
+
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ scores, const long long* __restrict__ classes,
+                                                        const float* __restrict__ boxes, int K, float score_thr, double iou_thr,
+                                                        unsigned long long* __restrict__ mask_ws) {
+    __shared__ NmsPrepShared sh;
+    const int img = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x;
+    const long base = (long)img * K;
+    const int n = nms_prep(sh, scores, classes, boxes, base, K, score_thr, tid, 256);
+    const int r0 = rb << 6;
+    if (r0 >= n) return;
+    const int nw = (n + 63) >> 6;
+    const int nwork = 64 * (nw - rb);  // (row, word >= rb) pairs of this row block
+    unsigned long long* out = mask_ws + (long)img * NMS_MAXK * NMS_NW;
+    for (int idx = tid; idx < nwork; idx += 256) {
+        const int w = rb + idx / 64, i = r0 + (idx & 63);   // a wave shares the word, lanes take consecutive rows
+        if (i < n) out[i * NMS_NW + w] = nms_mask_word(sh.box, sh.area, i, w, n, iou_thr);
+    }
+}
+
+__global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict__ scores, const long long* __restrict__ classes,
+                                                         const float* __restrict__ boxes, int K, float score_thr,
+                                                         const unsigned long long* __restrict__ mask_ws, float* out_scores,
+                                                         long long* out_classes, float* out_boxes, int* keep_idx, int* counts) {
+    __shared__ NmsShared sh;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const long base = (long)img * K;
+    const int lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) sh.n_valid = 0;
+    __syncthreads();
+    float sc = 0.f;
+    bool ok = false;
+    if (tid < K) { sc = scores[base + tid]; ok = sc >= score_thr; }
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0 && bal) atomicAdd(&sh.n_valid, __popcll(bal));
+    __syncthreads();
+    const int n = sh.n_valid;
+    const int nw = (n + 63) >> 6;
+    // pull the upper-triangular mask into LDS (coalesced 8-byte loads)
+    const unsigned long long* src = mask_ws + (long)img * NMS_MAXK * NMS_NW;
+    for (int idx = tid; idx < n * NMS_NW; idx += 1024) {
+        const int i = idx >> 4, w = idx & 15;
+        sh.mask[idx] = (w >= (i >> 6) && w < nw) ? src[idx] : 0ull;
+    }
+    if (tid < NMS_NW) { sh.remv[tid] = 0ull; sh.kept[tid] = 0ull; }
+    __syncthreads();
+    if (n > 0) nms_scan(sh, n, tid);
+
+    int total = 0;
+    for (int q = 0; q < nw; ++q) total += __popcll(sh.kept[q]);
     if (tid < n && ((sh.kept[tid >> 6] >> (tid & 63)) & 1ull)) {
         const int r = nms_rank(sh, tid);
         out_scores[base + r] = sc;
-        out_classes[base + r] = cl;
-        reinterpret_cast<float4*>(out_boxes)[base + r] = bx;
+        out_classes[base + r] = classes[base + tid];
+        reinterpret_cast<float4*>(out_boxes)[base + r] = reinterpret_cast<const float4*>(boxes)[base + tid];
         keep_idx[base + r] = tid;
     }
     if (tid < K && tid >= total) {
@@ -403,19 +471,30 @@ __global__ __launch_bounds__(1024) void batched_nms_kernel(const float* __restri
     if (tid == 0) counts[img] = total;
 }
 
+extern "C" int64_t fd_nms_workspace_bytes(int32_t N, int32_t K) {
+    if (N < 1 || K < 1 || K > NMS_MAXK) return -1;
+    return (int64_t)N * NMS_MAXK * NMS_NW * (int64_t)sizeof(unsigned long long);
+}
+
 extern "C" int32_t fd_batched_nms(const float* scores, const int64_t* classes, const float* boxes, int32_t N,
                                   int32_t K, float score_thr, double iou_thr, float* out_scores,
                                   int64_t* out_classes, float* out_boxes, int32_t* keep_idx, int32_t* counts,
-                                  fd_stream_t stream) {
-    FD_REQUIRE(scores && classes && boxes && out_scores && out_classes && out_boxes && keep_idx && counts,
+                                  void* workspace, fd_stream_t stream) {
+    FD_REQUIRE(scores && classes && boxes && out_scores && out_classes && out_boxes && keep_idx && counts && workspace,
                FD_E_INVAL, "fd_batched_nms: null pointer");
-    FD_REQUIRE(N >= 1 && K >= 1, FD_E_INVAL, "fd_batched_nms: N=%d K=%d", N, K);
+    FD_REQUIRE(N >= 1 && N <= 65535 && K >= 1, FD_E_INVAL, "fd_batched_nms: N=%d K=%d", N, K);
     FD_REQUIRE(K <= NMS_MAXK, FD_E_UNSUPPORTED, "fd_batched_nms: K=%d > %d not supported", K, NMS_MAXK);
-    FD_REQUIRE((((uintptr_t)boxes | (uintptr_t)out_boxes) & 15) == 0, FD_E_INVAL, "fd_batched_nms: boxes not 16-byte aligned");
-    hipLaunchKernelGGL(batched_nms_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, scores,
-                       (const long long*)classes, boxes, K, score_thr, iou_thr, out_scores, (long long*)out_classes,
-                       out_boxes, keep_idx, counts);
-    FD_CHECK_LAUNCH("fd_batched_nms");
+    FD_REQUIRE((((uintptr_t)boxes | (uintptr_t)out_boxes | (uintptr_t)workspace) & 15) == 0, FD_E_INVAL,
+               "fd_batched_nms: boxes / workspace not 16-byte aligned");
+    FD_REQUIRE(out_scores != scores && out_boxes != boxes && (const void*)out_classes != (const void*)classes, FD_E_INVAL,
+               "fd_batched_nms: outputs must not alias inputs");
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((K + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, scores,
+                       (const long long*)classes, boxes, K, score_thr, iou_thr, (unsigned long long*)workspace);
+    FD_CHECK_LAUNCH("fd_batched_nms (mask)");
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, scores, (const long long*)classes, boxes, K,
+                       score_thr, (const unsigned long long*)workspace, out_scores, (long long*)out_classes, out_boxes,
+                       keep_idx, counts);
+    FD_CHECK_LAUNCH("fd_batched_nms (scan)");
     return FD_OK;
 }
 

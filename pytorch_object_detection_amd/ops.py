@@ -244,6 +244,22 @@ def fcos_topk(scores: torch.Tensor, classes: torch.Tensor, boxes: torch.Tensor, 
     return (ts, tc, tb, ti) if want_idx else (ts, tc, tb)
 
 
+_NMS_WS: dict = {}
+
+
+def _nms_workspace(N: int, K: int, dev) -> torch.Tensor:
+    """Per-(device, stream) cached scratch for the suppression bitmask (stream order makes reuse safe)."""
+    key = (str(dev), _stream())
+    need = _lib.lib().fd_nms_workspace_bytes(N, K)
+    if need < 0:
+        raise FdError(f"fd_nms_workspace_bytes: unsupported N={N} K={K} (K <= 1024)")
+    ws = _NMS_WS.get(key)
+    if ws is None or ws.numel() * 8 < need:
+        ws = torch.empty(need // 8, dtype=torch.int64, device=dev)
+        _NMS_WS[key] = ws
+    return ws
+
+
 def batched_nms(scores: torch.Tensor, classes: torch.Tensor, boxes: torch.Tensor, score_thr: float, iou_thr: float):
     """Padded outputs [N,K] + keep_idx [N,K] (int32, -1 padded) + counts [N] (int32)."""
     _need_gpu(scores, classes, boxes)
@@ -255,9 +271,10 @@ def batched_nms(scores: torch.Tensor, classes: torch.Tensor, boxes: torch.Tensor
     ob = torch.empty(N, K, 4, dtype=torch.float32, device=dev)
     keep = torch.empty(N, K, dtype=torch.int32, device=dev)
     counts = torch.empty(N, dtype=torch.int32, device=dev)
+    ws = _nms_workspace(N, K, dev)
     check(_lib.lib().fd_batched_nms(scores.data_ptr(), classes.data_ptr(), boxes.data_ptr(), N, K, score_thr, iou_thr,
                                     os_.data_ptr(), oc.data_ptr(), ob.data_ptr(), keep.data_ptr(), counts.data_ptr(),
-                                    _stream()), "fd_batched_nms")
+                                    ws.data_ptr(), _stream()), "fd_batched_nms")
     return os_, oc, ob, keep, counts
 
 

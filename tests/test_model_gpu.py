@@ -132,3 +132,62 @@ def test_plan_cache_follows_weight_updates():
         model.head.cls_logits.bias.add_(1.0)
     c = model(x)[0][0]
     np.testing.assert_allclose((c - a).cpu().numpy(), 1.0, atol=1e-5)
+
+
+def test_baseline_config_640_batch2_vs_oracle():
+    """BASELINE configs[1] geometry (640x640, 80 classes; batch 2 keeps the CPU oracle to a few seconds):
+    every head output within 1e-4 (abs + rel) of the oracle and detections identical to the oracle post-process
+    applied to the device's own head outputs."""
+    torch.manual_seed(5)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 80, 256).eval()
+    randomize_norms(model, 6)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(2, 3, 640, 640)
+    with torch.no_grad():
+        ref = R.hisfcos_forward(sd, x)
+    model.to(DEV)
+    xd = x.to(DEV)
+    out = model(xd)
+    assert [tuple(t.shape[2:]) for t in out[0]] == [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
+    for name, o, r in zip(("cls", "cnt", "reg"), out, ref):
+        for i in range(5):
+            np.testing.assert_allclose(o[i].cpu().numpy(), r[i].numpy(), err_msg=f"{name}{i}", **TOL)
+    head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
+    s, c, b, counts = head.detect_padded(out)
+    b = ClipBoxes()(xd, b)
+    exp = R.fcos_detect([[t.cpu() for t in grp] for grp in out], [8, 16, 32, 64, 128], 0.05, 0.6, 1000, (640, 640))
+    for bi in range(2):
+        n = int(counts[bi])
+        assert n == len(exp[bi][0])
+        np.testing.assert_array_equal(c[bi, :n].cpu().numpy(), exp[bi][1])
+        np.testing.assert_array_equal(b[bi, :n].cpu().numpy(), exp[bi][2])
+
+
+def test_mixed_aspect_832x1344_pyramid():
+    """Cfg5 geometry: 832x1344 -> levels 104x168, 52x84, 26x42, 13x21, 6x10 (odd sizes, floor max-pool),
+    narrow FPN/head so the CPU oracle stays fast; FCOSHead top-k over sum HW = 23 265 locations."""
+    torch.manual_seed(7)
+    fpn = HalfInvertedStageFPN([32, 64, 128], 32).eval()
+    head = HISFCOSHead(32, 80, 0.01).eval()
+    randomize_norms(fpn, 8); randomize_norms(head, 9)
+    feats = [torch.randn(1, 32, 104, 168), torch.randn(1, 64, 52, 84), torch.randn(1, 128, 26, 42)]
+    sd = {"fpn." + k: v.clone() for k, v in fpn.state_dict().items()}
+    sd.update({"head." + k: v.clone() for k, v in head.state_dict().items()})
+    with torch.no_grad():
+        ps = R.his_fpn(sd, feats)
+        ref = R.his_head(sd, ps)
+    assert [tuple(p.shape[2:]) for p in ps] == [(104, 168), (52, 84), (26, 42), (13, 21), (6, 10)]
+    fpn.to(DEV); head.to(DEV)
+    pyr = fpn([f.to(DEV) for f in feats])
+    out = head(pyr)
+    for i in range(5):
+        np.testing.assert_allclose(pyr[i].cpu().numpy(), ps[i].numpy(), **TOL)
+        for o, r in zip(out, ref):
+            np.testing.assert_allclose(o[i].cpu().numpy(), r[i].numpy(), **TOL)
+    fh = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
+    s, c, b, counts = fh.detect_padded(out)
+    exp = R.fcos_detect([[t.cpu() for t in grp] for grp in out], [8, 16, 32, 64, 128], 0.05, 0.6, 1000)
+    n = int(counts[0])
+    assert n == len(exp[0][0])
+    np.testing.assert_array_equal(c[0, :n].cpu().numpy(), exp[0][1])
+    np.testing.assert_array_equal(b[0, :n].cpu().numpy(), exp[0][2])

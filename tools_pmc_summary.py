@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/pmc_<tag>/ (tools_pmc.sh) into profiles/<tag>_pmc_summary.json + profiles/pmc_traffic.json.
+HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE (KiB) is doubled on gfx950 (verified here on gn_apply /
+se_scale / nchw3_to_nhwc4, whose read bytes are known: ratio 0.50), WRITE_SIZE is exact."""
+import collections
+import csv
+import json
+import sys
+
+tag = sys.argv[1]
+root = f"gpurun_out/pmc_{tag}"
+
+
+def load(d):
+    disp = collections.OrderedDict()
+    for r in csv.DictReader(open(f"{root}/{d}/pmc_counter_collection.csv")):
+        e = disp.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"], "grid": int(r["Grid_Size"]), "c": {},
+                                               "dur_ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+        e["c"][r["Counter_Name"]] = float(r["Counter_Value"])
+    return list(disp.values())
+
+
+def longest_conv(rows):
+    conv = [v for v in rows if "conv_igemm_kernel" in v["name"]]
+    top = max(conv, key=lambda v: v["dur_ns"])
+    same = [v for v in conv if v["name"] == top["name"] and v["grid"] == top["grid"] and v["dur_ns"] > 0.7 * top["dur_ns"]]
+    return same
+
+
+fe, wr, sq = load("fetch"), load("write"), load("sq")
+f, w, q = longest_conv(fe), longest_conv(wr), longest_conv(sq)
+fetch_kib = sum(v["c"]["FETCH_SIZE"] for v in f) / len(f)
+write_kib = sum(v["c"]["WRITE_SIZE"] for v in w) / len(w)
+cyc = [v["c"]["GRBM_GUI_ACTIVE"] / 8 for v in q]
+util = [v["c"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (c * 1024) for v, c in zip(q, cyc)]
+clk = [c / v["dur_ns"] for v, c in zip(q, cyc)]
+# calibration of the FETCH_SIZE factor on gn_apply (reads exactly what it writes)
+cal = None
+gf = [v for v in fe if "gn_apply" in v["name"]]
+gw = [v for v in wr if "gn_apply" in v["name"]]
+if gf and gw:
+    cal = gf[0]["c"]["FETCH_SIZE"] / gw[0]["c"]["WRITE_SIZE"]
+out = {"head_tower_conv": {"kernel": f[0]["name"], "launches": len(f), "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
+                           "hbm_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024),
+                           "mfma_busy_frac": sum(util) / len(util), "clock_ghz": sum(clk) / len(clk),
+                           "avg_dur_ms_under_pmc": sum(v["dur_ns"] for v in q) / len(q) / 1e6},
+       "fetch_size_calibration_gn_apply(read/written)": cal,
+       "source": f"rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline ({tag})"}
+json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
