@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-tuning", action="store_true", help="write the conv tile table measured in this run back to tuned/gfx950_tiles.json")
     ap.add_argument("--layer-times", default="", help="diagnostic: write per-plan-step timings (TSV) to this file and exit")
     args = ap.parse_args()
 
@@ -216,6 +217,9 @@ def main():
     x = torch.randn(args.batch, 3, args.size, args.size, generator=gen).to(dev)
 
     plan = model.plan_for(x)
+    if args.save_tuning and rank == 0:
+        from pytorch_object_detection_amd import ops as _ops
+        _ops.save_tune_table()
     if args.layer_times:
         layer_times(plan, x, args.layer_times)
         return
@@ -267,7 +271,7 @@ def main():
                                    f"fused conv head + HIP NMS ({args.classes} classes, score>=0.05, IoU 0.6, top-1000)"
                                    + (", RCCL detection all-gather" if world > 1 else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (image-sharded)"},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<2,2,2,2> head tower 3x3 (cls_conv+reg_conv, 5 levels)",
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<...,TAG=1> head tower 3x3 (cls_conv+reg_conv fused, 5 levels, tile id %d)" % plan.tiles.get("head.tower3x3", 0),
                          "instruction": "v_mfma_f32_32x32x2_f32", "achieved": round(achieved, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic": pmc_traffic(), "flops_per_launch": tower_flops, "avg_launch_ms": round(tower_ms, 4)},

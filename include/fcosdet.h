@@ -98,6 +98,7 @@ typedef struct fd_conv_params {
     int32_t act_c0;
     int32_t mode;   /* FD_CONV_GENERIC | FD_CONV_STEM */
     int32_t tile;   /* 0 = built-in heuristic; FD_TILE_* forces a block tile (plan-time autotuning) */
+    int32_t tag;    /* 1 = launch under a separate kernel symbol (<..., TAG=1>) so a profiler can isolate this layer */
     float seg_param[FD_MAX_SEG]; /* per-level scalar for FD_ACT_EXP */
     fd_segs in;     /* input geometry */
 } fd_conv_params;

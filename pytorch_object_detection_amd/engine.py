@@ -20,9 +20,7 @@ from ._lib import ACT_EXP, ACT_NONE, ACT_RELU, ACT_SILU, FdError, Segs
 from .ops import Rows
 
 
-import os as _os
-
-AUTOTUNE = _os.environ.get("FD_AUTOTUNE", "1") != "0"
+AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see ops.autotune_conv, FD_AUTOTUNE)
 
 
 class PRows(Rows):
@@ -104,7 +102,7 @@ def _dev(t: torch.Tensor, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------ conv helpers
 def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, y: Rows, *, bn=None, act=ACT_NONE,
              res: Optional[Rows] = None, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
-             Cout: Optional[int] = None, act_c0: int = 0, seg_param=None) -> Segs:
+             Cout: Optional[int] = None, act_c0: int = 0, seg_param=None, tag: int = 0) -> Segs:
     """conv (+folded BN / bias) (+res) (+act).  `weight`/`bias` override conv's own (fused multi-conv launches)."""
     dev = plan.device
     w = conv.weight if weight is None else weight
@@ -124,11 +122,12 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         shift = _dev(b, dev)
     plan.keep += [wp, scale, shift]
     call = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
-                         shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param)
+                         shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param, tag=tag)
     plan.add(name, call)
     out = ops.conv_out_segs(segs, k, stride, pad, dil)
     if plan.autotune:
-        key = (tuple(segs.level_hw()), segs.batch, Cin, co, k, stride, pad, dil, res is not None, x.cs, y.cs)
+        hw = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
+        key = f"B{segs.batch}|{hw}|{Cin}>{co}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{x.cs}|ycs{y.cs}"
         plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co)
     plan.flops += 2 * out.rows * co * Cin * k * k
     plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k
@@ -332,7 +331,7 @@ def build_his_head(plan: Plan, head, pyr: Rows, segs: Segs):
     tower = pool.get(M, 2 * F)
     w = torch.cat([head.cls_conv[0].weight.detach(), head.reg_conv[0].weight.detach()], 0)
     mark = len(plan.steps)
-    add_conv(plan, "head.tower3x3", z, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F)
+    add_conv(plan, "head.tower3x3", z, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F, tag=1)
     plan.marks["head.tower3x3"] = (mark, len(plan.steps))
     _fused_gn(plan, "head.tower_gn", tower, segs, [head.cls_conv[1], head.reg_conv[1]], ACT_RELU)
     pool.put(z)

@@ -7,6 +7,8 @@ written in place (torch.cat in HISFcos.py:107,111 disappears) and slices are rea
 from __future__ import annotations
 
 import ctypes as C
+import json
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -90,7 +92,8 @@ def fold_bn(weight, bias, mean, var, eps: float = 1e-5, conv_bias: Optional[torc
 def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int, Cout: int, k: int, stride: int = 1,
               pad: int = 0, dil: int = 1, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
               res: Optional[Rows] = None, act: int = ACT_NONE, act_c0: int = 0,
-              seg_param: Optional[Sequence[float]] = None, stem: bool = False, tile: int = 0) -> Callable[[], None]:
+              seg_param: Optional[Sequence[float]] = None, stem: bool = False, tile: int = 0,
+              tag: int = 0) -> Callable[[], None]:
     """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream."""
     _need_gpu(w_packed, scale, shift)
     p = ConvParams()
@@ -103,7 +106,7 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
         p.res_cs, p.res_co = res.cs, res.co
     p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, k, stride, pad, dil
     p.act, p.act_c0, p.mode = act, act_c0, (_lib.CONV_STEM if stem else _lib.CONV_GENERIC)
-    p.tile = tile
+    p.tile, p.tag = tile, tag
     if seg_param is not None:
         for i, v in enumerate(seg_param):
             p.seg_param[i] = float(v)
@@ -120,16 +123,40 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
 
 
 _TUNE_CACHE: dict = {}
+_TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_tiles.json")
+_TUNE_MODE = os.environ.get("FD_AUTOTUNE", "1")   # "1": table, then tune misses; "0": table / heuristic only; "force": re-tune
+_TUNE_LOADED = False
 
 
-def autotune_conv(run: Callable[[], None], key: tuple, M: int, Cout: int, reps: int = 3) -> int:
-    """Time the conv launch under every sensible block tile and keep the fastest (plan-time, once per distinct
-    conv shape per process).  The built-in heuristic (tile 0) is always a candidate.  Returns the chosen tile id."""
-    hit = _TUNE_CACHE.get(key)
+def _tune_table() -> dict:
+    global _TUNE_LOADED
+    if not _TUNE_LOADED:
+        _TUNE_LOADED = True
+        try:
+            with open(_TUNE_FILE) as f:
+                _TUNE_CACHE.update(json.load(f))
+        except Exception:
+            pass
+    return _TUNE_CACHE
+
+
+def save_tune_table() -> None:
+    os.makedirs(os.path.dirname(_TUNE_FILE), exist_ok=True)
+    with open(_TUNE_FILE, "w") as f:
+        json.dump(dict(sorted(_TUNE_CACHE.items())), f, indent=0)
+
+
+def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, reps: int = 3) -> int:
+    """Block-tile choice for one conv launch.  Looked up in the committed table (tuned/gfx950_tiles.json, measured on
+    MI355X) first; a miss is timed on the spot under every sensible tile (best of 3 batches of `reps` launches) and
+    remembered for the process (bench.py --save-tuning writes the table back).  Returns the tile id (0 = heuristic)."""
     p = run.params  # type: ignore[attr-defined]
-    if hit is not None:
-        p.tile = hit
-        return hit
+    table = _tune_table()
+    if _TUNE_MODE != "force" and key in table:
+        p.tile = int(table[key])
+        return p.tile
+    if _TUNE_MODE == "0":
+        return 0
     cands = [0]
     for tid, (bm, bn) in _lib.TILES.items():
         padded = -(-Cout // bn) * bn
@@ -139,18 +166,19 @@ def autotune_conv(run: Callable[[], None], key: tuple, M: int, Cout: int, reps: 
     for tid in cands:
         p.tile = tid
         run()  # warm
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            run()
-        e1.record()
-        e1.synchronize()
-        t = e0.elapsed_time(e1) / reps
-        if t < best_t * 0.98 or best_t == float("inf"):  # prefer the earlier candidate on near-ties
-            if t < best_t:
-                best, best_t = tid, t
+        t = float("inf")
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record()
+            e1.synchronize()
+            t = min(t, e0.elapsed_time(e1) / reps)
+        if t < best_t * 0.985:  # an earlier candidate wins near-ties
+            best, best_t = tid, t
     p.tile = best
-    _TUNE_CACHE[key] = best
+    table[key] = best
     return best
 
 
