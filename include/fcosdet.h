@@ -62,7 +62,8 @@ const char* fd_last_error(void);
  *   torchvision resnet50 bottlenecks (reference model/backbone/resnet50.py:68-80),
  *   HalfInvertedStageFPN / HisBlock (model/od/HISFcos.py:77-179), HISFCOSHead (HISFcos.py:182-229),
  *   FeaturePyramidNetwork / HeadFCOS (model/od/Fcos.py:61-133).
- * w is packed [Cout][KH][KW][Cin] (K contiguous).  Cin % 32 == 0, x_cs % 4 == 0, x_co % 4 == 0.
+ * w is packed [Cout][Cin/32][KH][KW][32] (K contiguous, 32-channel chunk major, then filter tap).
+ * Cin % 32 == 0, x_cs % 4 == 0, x_co % 4 == 0.
  * in.nseg > 1 requires stride 1 and "same" padding (pad == dil*(K-1)/2).
  * mode FD_CONV_STEM: x is [N][H][W][4] (3 channels + zero pad), 7x7 stride 2 pad 3,
  *   w packed [Cout][7][8][4] (zeros at kw=7 and c=3).

@@ -1,9 +1,9 @@
 // fd_conv.hip — implicit-GEMM convolution for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32).
 //
 //   C[m][n] = sum_k A[m][k] * B[n][k]      m = output pixel (NHWC row), n = output channel,
-//                                          k = (r*KW + q)*Cin + c  (filter tap major, channel minor)
+//                                          k = ((c/32)*KH*KW + r*KW + q)*32 + c%32  (32-channel chunk, tap, channel)
 //   A is gathered on the fly from the NHWC input (zero outside the image), B is the weight tensor packed
-//   [Cout][KH][KW][Cin].  Both operands are staged as [rows][32 k] tiles in LDS (16-byte chunks XOR-swizzled
+//   [Cout][Cin/32][KH][KW][32].  Both operands are staged as [rows][32 k] tiles in LDS (16-byte chunks XOR-swizzled
 //   by (row>>1)&7, conflict-free for ds_read_b128 and ds_write_b128), global->register->LDS double buffered:
 //   the loads of k-tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after.
 //   Each of the 4 waves owns TM x TN sub-tiles of 32x32 (16 accumulator VGPRs each); a ds_read_b128 hands a
@@ -19,7 +19,7 @@ struct ConvArgs {
     const float* x; const float* w; const float* scale; const float* shift; const float* res; float* y;
     int x_cs, x_co, res_cs, res_co, y_cs, y_co;
     int Cin, Cout, KW, stride, pad, dil, act, act_c0;
-    int M, KT, ctiles, Kpacked;
+    int M, KT, ntaps, Kpacked;
     int nseg;
     int H[FD_MAX_SEG], W[FD_MAX_SEG], Ho[FD_MAX_SEG], Wo[FD_MAX_SEG];
     int m_in[FD_MAX_SEG];        // first input row of the segment
@@ -94,8 +94,11 @@ __global__ __launch_bounds__(256, (SB && TM * TN == 4) ? 3 : 1) void conv_igemm_
         int r, q, c0;
         if (STEM) { r = kt; q = chunk; c0 = 0; }
         else {
-            const int tap = kt / a.ctiles;
-            c0 = (kt - tap * a.ctiles) * 32 + chunk * 4;
+            // k-tile order = (32-channel chunk, tap): the 9 taps of one channel chunk are consecutive, so the
+            // shifted re-reads of the same input pixels hit L1/L2 instead of travelling from the Infinity Cache
+            const int cc = kt / a.ntaps;
+            const int tap = kt - cc * a.ntaps;
+            c0 = cc * 32 + chunk * 4;
             r = tap / a.KW;
             q = tap - r * a.KW;
         }
@@ -319,8 +322,8 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     a.M = (int)mo;
     FD_REQUIRE((long)p->in.m_start[p->in.nseg] * p->x_cs < (1L << 31) && mo * p->y_cs < (1L << 31), FD_E_UNSUPPORTED,
                "fd_conv2d: tensor exceeds 2^31 elements");
-    if (stem) { a.KT = 7; a.ctiles = 1; a.Kpacked = 7 * 32; }
-    else { a.ctiles = p->Cin / 32; a.KT = p->KH * p->KW * a.ctiles; a.Kpacked = p->KH * p->KW * p->Cin; }
+    if (stem) { a.KT = 7; a.ntaps = 7; a.Kpacked = 7 * 32; }
+    else { a.ntaps = p->KH * p->KW; a.KT = a.ntaps * (p->Cin / 32); a.Kpacked = p->KH * p->KW * p->Cin; }
     a.mtiles = a.ntiles = 0;
 
     a.vec_epi = (p->Cout % 4 == 0 && p->y_cs % 4 == 0 && p->y_co % 4 == 0 && ((uintptr_t)p->y & 15) == 0 &&

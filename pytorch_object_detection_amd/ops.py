@@ -62,8 +62,12 @@ def new_rows(rows: int, C_: int, device) -> Rows:
 
 # ---------------------------------------------------------------------------------------------------- weights
 def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
-    """OIHW -> [Cout][KH][KW][Cin] contiguous (K contiguous)."""
-    return w.detach().permute(0, 2, 3, 1).contiguous().float()
+    """OIHW -> [Cout][Cin/32][KH][KW][32] contiguous: K runs (32-channel chunk, tap, channel-in-chunk), the order the
+    conv kernel walks its K-tiles in (taps of one chunk adjacent -> shifted input re-reads stay in L1/L2)."""
+    o, i, kh, kw = w.shape
+    if i % 32:
+        raise FdError(f"conv weights need Cin % 32 == 0 (got {i})")
+    return w.detach().float().reshape(o, i // 32, 32, kh, kw).permute(0, 1, 3, 4, 2).contiguous()
 
 
 def pack_stem_weight(w: torch.Tensor) -> torch.Tensor:

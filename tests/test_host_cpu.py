@@ -85,7 +85,9 @@ def test_state_dict_contract():
 def test_weight_packing_and_bn_fold():
     w = torch.randn(8, 32, 3, 3)
     p = ops.pack_conv_weight(w)
-    assert p.shape == (8, 3, 3, 32) and torch.equal(p[3, 1, 2], w[3, :, 1, 2])
+    assert p.shape == (8, 1, 3, 3, 32) and torch.equal(p[3, 0, 1, 2], w[3, :, 1, 2])
+    w64 = torch.randn(4, 64, 3, 3)
+    assert torch.equal(ops.pack_conv_weight(w64)[2, 1, 0, 2], w64[2, 32:, 0, 2])
     st = ops.pack_stem_weight(torch.randn(64, 3, 7, 7))
     assert st.shape == (64, 7, 8, 4) and st[:, :, 7].abs().sum() == 0 and st[..., 3].abs().sum() == 0
     d = ops.pack_dw_weight(torch.arange(36.).reshape(4, 1, 3, 3))
