@@ -71,6 +71,15 @@ const char* fd_last_error(void);
 #define FD_CONV_GENERIC 0
 #define FD_CONV_STEM 1
 
+/* Arithmetic of the conv kernel.
+ *  FD_PREC_F32   : v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain (default, the parity baseline).
+ *  FD_PREC_F16X3 : every fp32 operand is split x = hi + lo*2^-11 (hi, lo f16) and a product is three
+ *                  v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulation): error ~2^-22 per product,
+ *                  operands must stay below f16's range (|x| < 65504).  Activations stay fp32 in HBM (split in the
+ *                  loader); w is the pre-split packing [Cout][Cin/32][KH][KW][2][32] f16 (hi plane, lo plane). */
+#define FD_PREC_F32 0
+#define FD_PREC_F16X3 1
+
 /* block tiles (output pixels x output channels) of the conv kernel */
 #define FD_TILE_AUTO 0
 #define FD_TILE_128x128 1
@@ -100,6 +109,7 @@ typedef struct fd_conv_params {
     int32_t mode;   /* FD_CONV_GENERIC | FD_CONV_STEM */
     int32_t tile;   /* 0 = built-in heuristic; FD_TILE_* forces a block tile (plan-time autotuning) */
     int32_t tag;    /* 1 = launch under a separate kernel symbol (<..., TAG=1>) so a profiler can isolate this layer */
+    int32_t precision; /* FD_PREC_F32 (exact fp32 MFMA) | FD_PREC_F16X3 (opt-in split-f16 products, see below) */
     float seg_param[FD_MAX_SEG]; /* per-level scalar for FD_ACT_EXP */
     fd_segs in;     /* input geometry */
 } fd_conv_params;

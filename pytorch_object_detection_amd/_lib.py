@@ -7,6 +7,7 @@ import os
 FD_MAX_SEG = 8
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_EXP, ACT_SIGMOID = 0, 1, 2, 3, 4
 CONV_GENERIC, CONV_STEM = 0, 1
+PREC_F32, PREC_F16X3 = 0, 1
 TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (128, 32), 6: (128, 96),
          7: (128, 128), 8: (128, 64), 9: (64, 128)}   # 7-9: single-LDS-buffer variants
 
@@ -49,7 +50,7 @@ class ConvParams(C.Structure):
                 ("y_cs", C.c_int32), ("y_co", C.c_int32),
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("dil", C.c_int32),
-                ("act", C.c_int32), ("act_c0", C.c_int32), ("mode", C.c_int32), ("tile", C.c_int32), ("tag", C.c_int32),
+                ("act", C.c_int32), ("act_c0", C.c_int32), ("mode", C.c_int32), ("tile", C.c_int32), ("tag", C.c_int32), ("precision", C.c_int32),
                 ("seg_param", C.c_float * FD_MAX_SEG), ("segs", Segs)]
 
 

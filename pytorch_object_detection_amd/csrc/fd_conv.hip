@@ -14,6 +14,10 @@
 #include "fd_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define FD_SPLIT_SCALE 2048.0f   // lo = (x - hi) * 2^11 keeps the low half in f16's normal range
 
 struct ConvArgs {
     const float* x; const float* w; const float* scale; const float* shift; const float* res; float* y;
@@ -31,15 +35,20 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
+// split-f16 planes: rows of 32 halves (64 B); c8 = 16-byte chunk (8 halves) 0..3, XOR-swizzled by (row>>2)&3
+__device__ __forceinline__ int lds_off_h(int row, int c8) { return row * 32 + ((c8 ^ ((row >> 2) & 3)) << 3); }
 
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG>
-__global__ __launch_bounds__(256, (SB && TM * TN == 4) ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT>
+__global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 1) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int AP = BM / 32, BP = BN / 32;  // loader passes (32 rows x 8 chunks per pass)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NBUF = SB ? 1 : 2;             // SB: one LDS buffer (2 barriers per K-tile, half the LDS -> more blocks/CU)
     float* As = reinterpret_cast<float*>(smem);  // [NBUF][BM*32]
     float* Bs = As + NBUF * BM * 32;             // [NBUF][BN*32]
+    // SPLIT (f16 x 3): the same bytes hold, per buffer, four f16 planes  A_hi | A_lo | B_hi | B_lo  of [rows][32 k]
+    _Float16* Hs = reinterpret_cast<_Float16*>(smem);
+    constexpr int HSTG = (BM + BN) * 64;         // halves per buffer
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -115,21 +124,48 @@ __global__ __launch_bounds__(256, (SB && TM * TN == 4) ? 3 : 1) void conv_igemm_
             rb[j] = b_ok[j] ? *reinterpret_cast<const float4*>(b_ptr[j] + kt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto store_tile = [&](int buf) {
+        if constexpr (SPLIT) {
+            _Float16* Ahi = Hs + buf * HSTG;
+            _Float16* Alo = Ahi + BM * 32;
+            _Float16* Bhi = Alo + BM * 32;
+            _Float16* Blo = Bhi + BN * 32;
 #pragma unroll
-        for (int i = 0; i < AP; ++i)
-            *reinterpret_cast<float4*>(As + buf * BM * 32 + lds_off(lrow + 32 * i, chunk)) = ra[i];
+            for (int i = 0; i < AP; ++i) {
+                const int row = lrow + 32 * i;
+                const f32x4 v = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                const h4 hi = __builtin_convertvector(v, h4);                       // round to nearest
+                const f32x4 rem = (v - __builtin_convertvector(hi, f32x4)) * FD_SPLIT_SCALE;   // exact residual
+                const h4 lo = __builtin_convertvector(rem, h4);
+                const int off = row * 32 + ((((chunk >> 1) ^ ((row >> 2) & 3)) << 3) | ((chunk & 1) << 2));
+                *reinterpret_cast<h4*>(Ahi + off) = hi;
+                *reinterpret_cast<h4*>(Alo + off) = lo;
+            }
 #pragma unroll
-        for (int j = 0; j < BP; ++j)
-            *reinterpret_cast<float4*>(Bs + buf * BN * 32 + lds_off(lrow + 32 * j, chunk)) = rb[j];
+            for (int j = 0; j < BP; ++j) {   // weights arrive pre-split: 16-B chunks 0-3 = hi, 4-7 = lo of this K-tile
+                const int row = lrow + 32 * j;
+                *reinterpret_cast<float4*>(((chunk & 4) ? Blo : Bhi) + lds_off_h(row, chunk & 3)) = rb[j];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AP; ++i)
+                *reinterpret_cast<float4*>(As + buf * BM * 32 + lds_off(lrow + 32 * i, chunk)) = ra[i];
+#pragma unroll
+            for (int j = 0; j < BP; ++j)
+                *reinterpret_cast<float4*>(Bs + buf * BN * 32 + lds_off(lrow + 32 * j, chunk)) = rb[j];
+        }
     };
 
     f32x16 acc[TM][TN];
+    f32x16 cor[SPLIT ? TM : 1][SPLIT ? TN : 1];   // SPLIT: hi*lo + lo*hi cross terms (scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                if constexpr (SPLIT) cor[i][j][e] = 0.f;
+            }
 
     const int l31 = lane & 31, lh = lane >> 5;
     load_tile(0);
@@ -138,24 +174,53 @@ __global__ __launch_bounds__(256, (SB && TM * TN == 4) ? 3 : 1) void conv_igemm_
     for (int kt = 0; kt < a.KT; ++kt) {
         const int buf = SB ? 0 : (kt & 1);
         if (kt + 1 < a.KT) load_tile(kt + 1);
-        const float* Ab = As + buf * BM * 32 + (wm * TM * 32) * 32;
-        const float* Bb = Bs + buf * BN * 32 + (wn * TN * 32) * 32;
+        if constexpr (SPLIT) {
+            const _Float16* Ahi = Hs + buf * HSTG + (wm * TM * 32) * 32;
+            const _Float16* Alo = Ahi + BM * 32;
+            const _Float16* Bhi = Hs + buf * HSTG + 2 * BM * 32 + (wn * TN * 32) * 32;
+            const _Float16* Blo = Bhi + BN * 32;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float4 fa[TM], fb[TN];
+            for (int ks = 0; ks < 2; ++ks) {   // two K=16 steps per 32-wide tile; lane half lh carries k = 8*lh .. 8*lh+7
+                h8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(Ab + lds_off(i * 32 + l31, 2 * s + lh));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(Bb + lds_off(j * 32 + l31, 2 * s + lh));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const h8*>(Ahi + lds_off_h(i * 32 + l31, 2 * ks + lh));
+                    al[i] = *reinterpret_cast<const h8*>(Alo + lds_off_h(i * 32 + l31, 2 * ks + lh));
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    bh[j] = *reinterpret_cast<const h8*>(Bhi + lds_off_h(j * 32 + l31, 2 * ks + lh));
+                    bl[j] = *reinterpret_cast<const h8*>(Blo + lds_off_h(j * 32 + l31, 2 * ks + lh));
                 }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], cor[i][j], 0, 0, 0);
+                        cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], cor[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+        const float* Ab = As + buf * BM * 32 + (wm * TM * 32) * 32;
+            const float* Bb = Bs + buf * BN * 32 + (wn * TN * 32) * 32;
+    #pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float4 fa[TM], fb[TN];
+    #pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(Ab + lds_off(i * 32 + l31, 2 * s + lh));
+    #pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(Bb + lds_off(j * 32 + l31, 2 * s + lh));
+    #pragma unroll
+                for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         if (SB) {
             __syncthreads();                       // every wave is done reading the tile
@@ -167,8 +232,8 @@ __global__ __launch_bounds__(256, (SB && TM * TN == 4) ? 3 : 1) void conv_igemm_
     }
 
     // residual tile prefetch (vector epilogue): all 16-byte loads of the wave's tile issued back to back right after the K loop (they fly while the first sub-tile is staged)
-    float4 rres[TM][TN][4];
-    if (a.res && a.vec_epi) {
+    float4 rres[SPLIT ? 1 : TM][SPLIT ? 1 : TN][4];
+    if (!SPLIT && a.res && a.vec_epi) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -186,6 +251,12 @@ __global__ __launch_bounds__(256, (SB && TM * TN == 4) ? 3 : 1) void conv_igemm_
     // Vector path: each 32x32 sub-tile is transposed through a per-wave LDS stage so that a lane owns 4 consecutive
     // channels of one pixel: residual loads / output stores are 16 B per lane, 8 full 128-B lines per instruction
     // (4x fewer memory instructions than storing straight from the accumulator layout).
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += cor[i][j] * (1.0f / FD_SPLIT_SCALE);
+    }
     float* stage = reinterpret_cast<float*>(smem) + wave * 1024;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -209,7 +280,9 @@ __global__ __launch_bounds__(256, (SB && TM * TN == 4) ? 3 : 1) void conv_igemm_
                     float4 v = *reinterpret_cast<const float4*>(stage + row * 32 + c4);
                     if (m < a.M && nn < a.Cout) {
                         if (a.res) {
-                            const float4 r = rres[i][j][p];
+                            float4 r;
+                            if constexpr (SPLIT) r = *reinterpret_cast<const float4*>(a.res + (size_t)m * a.res_cs + a.res_co + nn);
+                            else r = rres[i][j][p];
                             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                         }
                         if (a.act != FD_ACT_NONE) {
@@ -254,7 +327,7 @@ __global__ __launch_bounds__(256, (SB && TM * TN == 4) ? 3 : 1) void conv_igemm_
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0>
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int lds_ab = (SB ? 1 : 2) * (BM + BN) * 32 * 4;
@@ -262,7 +335,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG>;
+    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -333,6 +406,30 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     a.is_gemm = (!stem && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0) ? 1 : 0;
 
     if (stem) return launch_conv<2, 2, 2, 1, true>(a, stream);       // 128 x 64
+    if (p->precision == FD_PREC_F16X3) {   // split-f16: 3 f16 MFMAs per fp32 product (weights pre-split by the caller)
+        FD_REQUIRE(!stem, FD_E_UNSUPPORTED, "fd_conv2d: the stem runs in exact fp32 only");
+        const bool tg = p->tag == 1;
+        switch (p->tile) {
+            case FD_TILE_AUTO:
+                if (a.Cout <= 32) return launch_conv<4, 1, 1, 1, false, false, 0, true>(a, stream);
+                if (a.Cout <= 64) return launch_conv<2, 2, 1, 1, false, false, 0, true>(a, stream);
+                if (a.Cout <= 96) return launch_conv<4, 1, 1, 3, false, false, 0, true>(a, stream);
+                return launch_conv<2, 2, 1, 2, false, false, 0, true>(a, stream);
+            case FD_TILE_128x128:
+                return tg ? launch_conv<2, 2, 2, 2, false, false, 1, true>(a, stream) : launch_conv<2, 2, 2, 2, false, false, 0, true>(a, stream);
+            case FD_TILE_128x128_SB:
+                return tg ? launch_conv<2, 2, 2, 2, false, true, 1, true>(a, stream) : launch_conv<2, 2, 2, 2, false, true, 0, true>(a, stream);
+            case FD_TILE_128x64: return launch_conv<2, 2, 2, 1, false, false, 0, true>(a, stream);
+            case FD_TILE_64x128: return launch_conv<2, 2, 1, 2, false, false, 0, true>(a, stream);
+            case FD_TILE_64x64: return launch_conv<2, 2, 1, 1, false, false, 0, true>(a, stream);
+            case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true, 0, true>(a, stream);
+            case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true, 0, true>(a, stream);
+            case FD_TILE_128x32: return launch_conv<4, 1, 1, 1, false, false, 0, true>(a, stream);
+            case FD_TILE_128x96: return launch_conv<4, 1, 1, 3, false, false, 0, true>(a, stream);
+            default: fd_set_error("fd_conv2d: tile id %d has no split-f16 kernel", p->tile); return FD_E_UNSUPPORTED;
+        }
+    }
+    FD_REQUIRE(p->precision == FD_PREC_F32, FD_E_INVAL, "fd_conv2d: unknown precision %d", p->precision);
     if (p->tag == 1) {  // profiling tag: same code under its own kernel symbol (TAG = 1) so rocprofv3 --stats isolates it
         switch (p->tile) {
             case FD_TILE_128x128: return launch_conv<2, 2, 2, 2, false, false, 1>(a, stream);

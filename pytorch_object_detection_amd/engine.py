@@ -20,6 +20,11 @@ from ._lib import ACT_EXP, ACT_NONE, ACT_RELU, ACT_SILU, FdError, Segs
 from .ops import Rows
 
 
+import os as _os
+
+# Conv arithmetic: 'f32' = exact fp32 MFMA (default, parity baseline); 'f16x3' = opt-in split-f16 products for every
+# conv except the 7x7 stem (K = 147 is too short to matter).  See include/fcosdet.h FD_PREC_*.
+CONV_PRECISION = _os.environ.get("FD_CONV_PRECISION", "f32")
 AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see ops.autotune_conv, FD_AUTOTUNE)
 
 
@@ -58,7 +63,7 @@ class Pool:
 
 
 class Plan:
-    def __init__(self, device):
+    def __init__(self, device, precision: Optional[str] = None):
         self.device = device
         self.steps: List[Callable[[], None]] = []
         self.names: List[str] = []
@@ -68,6 +73,9 @@ class Plan:
         self.step_flops: Dict[int, int] = {}
         self.marks: Dict[str, Tuple[int, int]] = {}
         self.autotune = AUTOTUNE        # time block-tile candidates per conv at plan-build time
+        self.precision = precision or CONV_PRECISION
+        if self.precision not in ("f32", "f16x3"):
+            raise FdError(f"unknown conv precision '{self.precision}' (f32 | f16x3)")
         self.tiles: Dict[str, int] = {}
 
     def add(self, name: str, fn: Callable[[], None]) -> None:
@@ -113,7 +121,8 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     else:
         pad = pad[0]
     Cin, co = w.shape[1], (w.shape[0] if Cout is None else Cout)
-    wp = ops.pack_conv_weight(_dev(w, dev))
+    split = plan.precision == "f16x3"
+    wp = ops.pack_conv_weight_f16x3(_dev(w, dev)) if split else ops.pack_conv_weight(_dev(w, dev))
     scale = shift = None
     if bn is not None:
         scale, shift = ops.fold_bn(_dev(bn.weight, dev), _dev(bn.bias, dev), _dev(bn.running_mean, dev),
@@ -122,12 +131,15 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         shift = _dev(b, dev)
     plan.keep += [wp, scale, shift]
     call = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
-                         shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param, tag=tag)
+                         shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param, tag=tag,
+                         precision=1 if split else 0)
     plan.add(name, call)
     out = ops.conv_out_segs(segs, k, stride, pad, dil)
     if plan.autotune:
         hw = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
         key = f"B{segs.batch}|{hw}|{Cin}>{co}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{x.cs}|ycs{y.cs}"
+        if split:
+            key = "f16x3|" + key
         plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co)
     plan.flops += 2 * out.rows * co * Cin * k * k
     plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k

@@ -34,7 +34,7 @@ class FeaturePyramidNetwork(PlannedModule):
         key = ("FPN",) + tuple(tuple(t.shape) for t in x) + (str(c3.device),)
 
         def build():
-            plan = engine.Plan(c3.device)
+            plan = engine.Plan(c3.device, self.conv_precision)
             ins = []
             for t in (c3, c4, c5):
                 B, C, H, W = t.shape
@@ -72,7 +72,7 @@ class HeadFCOS(PlannedModule):
         key = ("head",) + shapes + (str(inputs[0].device),)
 
         def build():
-            plan = engine.Plan(inputs[0].device)
+            plan = engine.Plan(inputs[0].device, self.conv_precision)
             B, C = shapes[0][0], shapes[0][1]
             segs = Segs.make(B, [(s[2], s[3]) for s in shapes])
             pyr = plan.pool.get(segs.rows, C)
@@ -104,7 +104,7 @@ class FCOS(PlannedModule):
                         p.requires_grad = False
 
     def build_plan(self, B: int, H: int, W: int, device):
-        plan = engine.Plan(device)
+        plan = engine.Plan(device, self.conv_precision)
         plan.image_ref = [None]
         feats = engine.build_resnet50(plan, self.backbone.trunk, B, H, W, plan.image_ref)
         pyr, segs = engine.build_fcos_fpn(plan, self.FPN, feats)

@@ -30,6 +30,9 @@ class PlannedModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._plans: Dict[Tuple, Tuple[int, object]] = {}
+        # 'f32' (exact fp32 MFMA, default) | 'f16x3' (opt-in split-f16 products, ~1.6x faster, same 1e-4 parity bar);
+        # None = the FD_CONV_PRECISION environment default.  Sub-modules inherit the value of the module that plans.
+        self.conv_precision = None
 
     def _param_version(self) -> int:
         v = 0
@@ -39,6 +42,7 @@ class PlannedModule(nn.Module):
 
     def _get_plan(self, key: Tuple, build: Callable[[], object]):
         ver = self._param_version()
+        key = key + (self.conv_precision,)
         hit = self._plans.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]

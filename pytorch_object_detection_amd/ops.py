@@ -70,6 +70,18 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return w.detach().float().reshape(o, i // 32, 32, kh, kw).permute(0, 1, 3, 4, 2).contiguous()
 
 
+def pack_conv_weight_f16x3(w: torch.Tensor) -> torch.Tensor:
+    """OIHW fp32 -> [Cout][Cin/32][KH][KW][2][32] f16: per K-tile of 32 the hi plane then the lo plane, where
+    w = hi + lo * 2^-11 (hi = fp16(w) round-to-nearest, lo = fp16((w - hi) * 2^11)): FD_PREC_F16X3 operand format."""
+    o, i, kh, kw = w.shape
+    if i % 32:
+        raise FdError(f"conv weights need Cin % 32 == 0 (got {i})")
+    t = w.detach().float().reshape(o, i // 32, 32, kh, kw).permute(0, 1, 3, 4, 2)      # [O, I/32, KH, KW, 32]
+    hi = t.half()
+    lo = ((t - hi.float()) * 2048.0).half()
+    return torch.stack([hi, lo], dim=-2).contiguous()                                   # [O, I/32, KH, KW, 2, 32]
+
+
 def pack_stem_weight(w: torch.Tensor) -> torch.Tensor:
     """[Cout,3,7,7] -> [Cout][7][8][4], zero at kw=7 and c=3 (FD_CONV_STEM)."""
     co = w.shape[0]
@@ -97,7 +109,7 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
               pad: int = 0, dil: int = 1, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
               res: Optional[Rows] = None, act: int = ACT_NONE, act_c0: int = 0,
               seg_param: Optional[Sequence[float]] = None, stem: bool = False, tile: int = 0,
-              tag: int = 0) -> Callable[[], None]:
+              tag: int = 0, precision: int = 0) -> Callable[[], None]:
     """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream."""
     _need_gpu(w_packed, scale, shift)
     p = ConvParams()
@@ -110,7 +122,7 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
         p.res_cs, p.res_co = res.cs, res.co
     p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, k, stride, pad, dil
     p.act, p.act_c0, p.mode = act, act_c0, (_lib.CONV_STEM if stem else _lib.CONV_GENERIC)
-    p.tile, p.tag = tile, tag
+    p.tile, p.tag, p.precision = tile, tag, precision
     if seg_param is not None:
         for i, v in enumerate(seg_param):
             p.seg_param[i] = float(v)

@@ -41,8 +41,9 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_single_level(case):
+def test_conv_single_level(case, prec):
     Cin, Cout, k, stride, pad, dil, H, W, act, use_res, use_bn = case
     gen = torch.Generator().manual_seed(hash(case) % 1000)
     B = 2
@@ -61,9 +62,13 @@ def test_conv_single_level(case):
     xr = to_rows(x)
     y = ops.new_rows(B * Ho * Wo, Cout, DEV)
     rr = to_rows(res) if use_res else None
-    ops.conv_call(xr, segs, ops.pack_conv_weight(w.to(DEV)), y, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil,
-                  scale=scale.to(DEV) if use_bn else None, shift=shift.to(DEV), res=rr, act=act)()
-    np.testing.assert_allclose(from_rows(y, B, Ho, Wo).numpy(), ref.numpy(), atol=ATOL, rtol=RTOL)
+    wp = ops.pack_conv_weight_f16x3(w.to(DEV)) if prec == "f16x3" else ops.pack_conv_weight(w.to(DEV))
+    for tile in ([0] if prec == "f32" else [1, 2, 3, 4, 7, 8, 9]):
+        y.buf.fill_(float("nan"))
+        ops.conv_call(xr, segs, wp, y, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil,
+                      scale=scale.to(DEV) if use_bn else None, shift=shift.to(DEV), res=rr, act=act, tile=tile,
+                      precision=1 if prec == "f16x3" else 0)()
+        np.testing.assert_allclose(from_rows(y, B, Ho, Wo).numpy(), ref.numpy(), atol=ATOL, rtol=RTOL, err_msg=f"tile {tile}")
 
 
 def test_conv_stem_7x7():

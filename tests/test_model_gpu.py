@@ -69,11 +69,13 @@ def test_tiny_fcos_fpn_head_golden(golden):
         np.testing.assert_allclose(reg[i].cpu().numpy(), g[f"reg{i}"], **TOL)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("shape", [(2, 128, 128), (1, 256, 192)])
-def test_full_hisfcos_vs_oracle(shape):
+def test_full_hisfcos_vs_oracle(shape, prec):
     torch.manual_seed(0)
     B, H, W = shape
     model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).eval()
+    model.conv_precision = prec
     randomize_norms(model, 1)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     x = torch.randn(B, 3, H, W)
@@ -100,10 +102,12 @@ def test_full_hisfcos_vs_oracle(shape):
         np.testing.assert_allclose(s[bi, :n].cpu().numpy(), exp[bi][0], rtol=2e-6, atol=1e-7)
 
 
-def test_full_fcos_vs_oracle():
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_full_fcos_vs_oracle(prec):
     torch.manual_seed(1)
     B, H, W = 1, 128, 160
     model = FCOS([2048, 1024, 512], 20, 256).eval()
+    model.conv_precision = prec
     randomize_norms(model, 2)
     with torch.no_grad():
         for m in model.head.modules():
@@ -134,12 +138,14 @@ def test_plan_cache_follows_weight_updates():
     np.testing.assert_allclose((c - a).cpu().numpy(), 1.0, atol=1e-5)
 
 
-def test_baseline_config_640_batch2_vs_oracle():
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_baseline_config_640_batch2_vs_oracle(prec):
     """BASELINE configs[1] geometry (640x640, 80 classes; batch 2 keeps the CPU oracle to a few seconds):
     every head output within 1e-4 (abs + rel) of the oracle and detections identical to the oracle post-process
     applied to the device's own head outputs."""
     torch.manual_seed(5)
     model = HalfInvertedStageFCOS([512, 1024, 2048], 80, 256).eval()
+    model.conv_precision = prec
     randomize_norms(model, 6)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     x = torch.randn(2, 3, 640, 640)
