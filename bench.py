@@ -42,7 +42,7 @@ def build_model(num_classes: int, seed: int):
 
 def pmc_traffic():
     """HBM bytes per launch of the roofline kernel from the separate rocprofv3 --pmc passes of this same command
-    (tools_pmc.sh -> tools_pmc_summary.py -> profiles/pmc_traffic.json): 2 x FETCH_SIZE (gfx950 reports half of a
+    (tools/pmc.sh -> tools/pmc_summary.py -> profiles/pmc_traffic.json): 2 x FETCH_SIZE (gfx950 reports half of a
     16-B/lane stream; calibrated on kernels of known byte count) + WRITE_SIZE.  None when no PMC run is recorded
     for batch 16 / 640x640."""
     try:

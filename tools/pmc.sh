@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): bash tools_pmc.sh <tag>  -> gpurun_out/pmc_<tag>/{fetch,write,sq}/...
+# usage (GPU box, repo root): bash tools/pmc.sh <tag>  -> gpurun_out/pmc_<tag>/{fetch,write,sq}/...
 # counters are collected in their own passes (no tracing domains besides kernel-trace), as the guide prescribes
 set -e
 tag=${1:-r01}

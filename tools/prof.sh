@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools_prof.sh <tag>   -> gpurun_out/prof_<tag>/
+# usage (on the GPU box, from the repo root): bash tools/prof.sh <tag>   -> gpurun_out/prof_<tag>/
 set -e
 tag=${1:-r01}
 export TMPDIR=/tmp
