@@ -55,6 +55,22 @@ def _no_torch_forward(self, *a, **k):
     raise RuntimeError("the backbone runs inside the model's HIP plan; call the detector (model(x)) instead")
 
 
+def trunk_train_forward(trunk: nn.Module, x: torch.Tensor):
+    """Autograd-capable trunk forward on stock PyTorch-ROCm ops (training only; inference runs the HIP plan).
+    Returns (C3, C4, C5)."""
+    import torch.nn.functional as F
+    x = F.max_pool2d(F.relu(trunk.bn1(trunk.conv1(x))), 3, 2, 1)
+    feats = []
+    for li in (1, 2, 3, 4):
+        for blk in getattr(trunk, f"layer{li}"):
+            idt = x if blk.downsample is None else blk.downsample(x)
+            y = F.relu(blk.bn1(blk.conv1(x)))
+            y = F.relu(blk.bn2(blk.conv2(y)))
+            x = F.relu(blk.bn3(blk.conv3(y)) + idt)
+        feats.append(x)
+    return feats[1], feats[2], feats[3]
+
+
 class ResNet50v2(nn.Module):
     """Reference model/backbone/resnet50.py:59-97.  state_dict carries BOTH key sets the reference produces:
     backbone.{conv1,bn1,layer1}.* and backbone.extract_feature.{conv1,bn1,layer1..4}.* (shared parameters)."""

@@ -10,7 +10,9 @@ import torch.nn as nn
 
 from ... import engine
 from ..._lib import FdError, Segs
-from ..backbone.resnet50 import ResNet50
+import torch.nn.functional as F
+
+from ..backbone.resnet50 import ResNet50, trunk_train_forward
 from ..modules.modules import ScaleExp, init_conv_kaiming, init_conv_random_normal
 from ._planned import PlannedModule, copy_in_nchw, pyramid_out
 
@@ -28,8 +30,19 @@ class FeaturePyramidNetwork(PlannedModule):
         self.P7_c1 = nn.Conv2d(feature, feature, 3, 2, 1)
         self.apply(init_conv_kaiming)
 
+    def train_forward(self, x):
+        c3, c4, c5 = x
+        up = lambda t: F.interpolate(t, scale_factor=2.0, mode="nearest")  # noqa: E731
+        p5 = self.P5(c5)
+        p4 = self.P4_c1(up(p5) + self.P4(c4))
+        p3 = self.P3_c1(up(p4) + self.P3(c3))
+        p5 = self.P5_c1(p5)
+        p6 = F.relu(self.P6_c1(p5))          # the reference's in-place ReLU rectifies the returned P6 (Fcos.py:90)
+        return p3, p4, p5, p6, self.P7_c1(p6)
+
     def forward(self, x):
-        self._check_eval()
+        if self.training:
+            return self.train_forward(x)
         c3, c4, c5 = x
         key = ("FPN",) + tuple(tuple(t.shape) for t in x) + (str(c3.device),)
 
@@ -66,8 +79,18 @@ class HeadFCOS(PlannedModule):
         nn.init.constant_(self.cls_logits.bias, -np.log((1 - prior) / prior))
         self.scale_exp = nn.ModuleList([ScaleExp(1.0) for _ in range(5)])
 
+    def train_forward(self, inputs):
+        cls_l, cnt_l, reg_l = [], [], []
+        for i, f in enumerate(inputs):
+            c, r = self.cls_branch(f), self.reg_branch(f)
+            cls_l.append(self.cls_logits(c))
+            cnt_l.append(self.cnt_logits(r))
+            reg_l.append(torch.exp(self.reg_pred(r) * self.scale_exp[i].scale))
+        return cls_l, cnt_l, reg_l
+
     def forward(self, inputs):
-        self._check_eval()
+        if self.training:
+            return self.train_forward(inputs)
         shapes = tuple(tuple(t.shape) for t in inputs)
         key = ("head",) + shapes + (str(inputs[0].device),)
 
@@ -121,6 +144,9 @@ class FCOS(PlannedModule):
         return self._get_plan(("model", B, H, W, str(x.device)), lambda: self.build_plan(B, H, W, x.device))
 
     def forward(self, x: torch.Tensor, events=None):
+        if self.training:
+            self._check_train_input(x)
+            return self.head.train_forward(self.FPN.train_forward(trunk_train_forward(self.backbone.trunk, x)))
         plan = self.plan_for(x)
         plan.image_ref[0] = x.contiguous()
         plan.run(events)

@@ -12,7 +12,9 @@ import torch.nn as nn
 from ... import engine
 from ..._lib import FdError, Segs
 from ...ops import Rows
-from ..backbone.resnet50 import ResNet50v2
+import torch.nn.functional as F
+
+from ..backbone.resnet50 import ResNet50v2, trunk_train_forward
 from ..modules.modules import DepthWiseConv2d, PointWiseConv, ScaleExp, SEBlock
 from ._planned import PlannedModule, copy_in_nchw, pyramid_out
 
@@ -30,6 +32,15 @@ class HisBlock(nn.Module):
         self.bn1, self.bn2, self.bn3 = nn.BatchNorm2d(half), nn.BatchNorm2d(half), nn.BatchNorm2d(half)
         self.bn4 = nn.BatchNorm2d(feature)
 
+    def train_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Training-time forward on stock PyTorch-ROCm ops (autograd); inference runs engine._his_block."""
+        x1 = F.silu(self.bn1(self.conv1(x)))
+        se = self.conv1_2.excitation
+        gate = se(x1.mean((2, 3), keepdim=True))
+        left = torch.cat((F.relu(self.bn2(self.conv1_1(x1))), x1 * gate), 1)
+        mid = torch.cat((F.relu(self.bn3(self.conv3(left))), self.conv2(x)), 1)
+        return F.silu(self.bn4(self.conv4(mid)))
+
 
 class HalfInvertedStageFPN(PlannedModule):
     def __init__(self, feature_map: List[int], feature: int):
@@ -42,9 +53,26 @@ class HalfInvertedStageFPN(PlannedModule):
         # named gn* but BatchNorm2d, as in the reference (HISFcos.py:137-142); gn3 exists and is never used
         self.gn1, self.gn2, self.gn3 = nn.BatchNorm2d(feature), nn.BatchNorm2d(feature), nn.BatchNorm2d(feature)
 
+    def train_forward(self, x):
+        c3, c4, c5 = x
+        up = lambda t: F.interpolate(t, scale_factor=2.0, mode="nearest")  # noqa: E731
+        down = lambda t: F.max_pool2d(t, 2, 2)  # noqa: E731
+        a = F.relu(self.gn1(self.tf1(c5)))
+        x4 = down(a)
+        x5 = down(x4)
+        t3 = self.HisBlock1.train_forward(a)
+        t4 = self.HisBlock2.train_forward(up(t3) + F.relu(self.gn2(self.tf2(c4))))
+        p3 = self.HisBlock3.train_forward(up(t4) + F.relu(self.gn2(self.tf3(c3))))   # gn2 twice, as the reference
+        p4 = self.HisBlock4.train_forward(down(p3) + t4)
+        p5 = self.HisBlock5.train_forward(down(p4) + t3)
+        p6 = self.HisBlock6.train_forward(down(p5) + x4)
+        p7 = self.HisBlock7.train_forward(down(p6) + x5)
+        return p3, p4, p5, p6, p7
+
     def forward(self, x):
         """(C3, C4, C5) NCHW CUDA tensors -> PyramidOut of 5 NCHW-shaped maps (strides 8..128)."""
-        self._check_eval()
+        if self.training:
+            return self.train_forward(x)
         c3, c4, c5 = x
         key = ("fpn",) + tuple(tuple(t.shape) for t in x) + (str(c3.device),)
 
@@ -82,9 +110,21 @@ class HISFCOSHead(PlannedModule):
         nn.init.constant_(self.cls_logits.bias, -np.log((1 - prior) / prior))
         self.scale_exp = nn.ModuleList([ScaleExp(1.2) for _ in range(5)])
 
+    def train_forward(self, inputs):
+        cls_l, cnt_l, reg_l = [], [], []
+        for i, f in enumerate(inputs):
+            h = F.silu(self.gn2(self.dw1(F.relu(self.gn1(self.pw1(f))))))
+            z = self.pw2(h) + f
+            c, r = self.cls_conv(z), self.reg_conv(z)
+            cls_l.append(self.cls_logits(c))
+            cnt_l.append(self.cnt_logits(r))
+            reg_l.append(torch.exp(self.reg_pred(r) * self.scale_exp[i].scale))
+        return cls_l, cnt_l, reg_l
+
     def forward(self, inputs):
         """5 pyramid maps (PyramidOut or a list of NCHW CUDA tensors) -> (cls_logits, cnt_logits, reg_preds)."""
-        self._check_eval()
+        if self.training:
+            return self.train_forward(inputs)
         shapes = tuple(tuple(t.shape) for t in inputs)
         key = ("head",) + shapes + (str(inputs[0].device),)
 
@@ -141,6 +181,11 @@ class HalfInvertedStageFCOS(PlannedModule):
         """[B,3,H,W] fp32 CUDA -> (cls_logits, cnt_logits, reg_preds), each a list of 5 NCHW-shaped tensors
         (strides 8..128; reference HISFcos.py:70-74).  The tensors are views of plan-owned buffers and are
         overwritten by the next forward of the same shape."""
+        if self.training:
+            # training: autograd forward on stock PyTorch-ROCm ops (conv backward is MIOpen's); the losses, their
+            # gradients and the target assignment are the HIP kernels of model.loss / model.modules.head
+            self._check_train_input(x)
+            return self.head.train_forward(self.fpn.train_forward(trunk_train_forward(self.backbone.trunk, x)))
         plan = self.plan_for(x)
         plan.image_ref[0] = x.contiguous()
         plan.run(events)

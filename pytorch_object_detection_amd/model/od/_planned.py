@@ -69,8 +69,24 @@ class PlannedModule(nn.Module):
 
     def _check_eval(self) -> None:
         if self.training:
-            raise FdError("the HIP plan implements the frozen-BN inference forward; call model.eval() first "
-                          "(training forward/backward is not built yet)")
+            raise FdError("the HIP plan implements the frozen-BN inference forward; call model.eval() first")
+
+    def train(self, mode: bool = True):
+        """nn.Module.train, except that BatchNorm layers the constructor froze stay in eval mode (the reference freezes
+        them at construction, HISFcos.py:57-68, but its unguarded model.train() silently un-freezes the statistics;
+        SURVEY.md §2 C3)."""
+        super().train(mode)
+        if mode and getattr(self, "backbone_freeze", False):
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
+
+    @staticmethod
+    def _check_train_input(x: torch.Tensor) -> None:
+        if not x.is_cuda:
+            raise FdError("pytorch_object_detection_amd runs on the GPU only; there is no CPU fallback "
+                          "(got a CPU tensor)")
 
 
 def copy_in_nchw(dst: Rows, segs: Segs, level: int, x: torch.Tensor) -> None:
