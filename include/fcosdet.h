@@ -118,6 +118,14 @@ int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
 
 /* [N][3][H][W] fp32 (NCHW, the reference's input layout, dataset/voc.py:141-173) -> [N][H][W][4] (c=3 zero) */
 int32_t fd_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, fd_stream_t stream);
+/* Input pipeline tail on the device: uint8 [N][H][W][3] images, already resized and zero padded on
+ * the host (cv2.resize is third-party arithmetic and stays there, dataset/voc.py:110-139) -> normalised fp32
+ * [N][H][W][4] = ((u8/255) - mean) / std per channel (transforms.ToTensor + Normalize, voc.py:57-58,104,155),
+ * channel 3 = 0: the stem conv's input, no NCHW detour.  mean3 / std3 are HOST pointers to 3 floats. */
+int32_t fd_preprocess_u8_nhwc4(const uint8_t* x, float* y, int32_t N, int32_t H, int32_t W, const float* mean3,
+                               const float* std3, fd_stream_t stream);
+/* Output pipeline tail (Test_coco.py:147-151): boxes /= scale, then xyxy -> xywh (COCO), in place on [n][4]. */
+int32_t fd_boxes_rescale_xywh(float* boxes, int64_t n_boxes, float scale, fd_stream_t stream);
 /* NHWC rows -> NCHW copy (only for callers that insist on contiguous NCHW) */
 int32_t fd_nhwc_to_nchw(const float* x, int32_t x_cs, int32_t x_co, float* y, int32_t N, int32_t HW,
                         int32_t C, fd_stream_t stream);

@@ -196,3 +196,18 @@ void ref_clip_boxes(float* boxes, int n, int img_h, int img_w) {
         boxes[4 * i + 3] = fminf(boxes[4 * i + 3], (float)(img_h - 1));
     }
 }
+
+/* dataset/voc.py:57-58,104,155: transforms.ToTensor (u8/255) + Normalize ((v-mean)/std); out [H*W][3] */
+void ref_normalize_u8(const uint8_t* img, int n_pix, const float* mean3, const float* std3, float* out) {
+    for (int i = 0; i < n_pix; ++i)
+        for (int c = 0; c < 3; ++c) out[3 * i + c] = ((float)img[3 * i + c] / 255.0f - mean3[c]) / std3[c];
+}
+
+/* Test_coco.py:147-151: boxes /= scale; xyxy -> xywh */
+void ref_boxes_rescale_xywh(float* boxes, int n, float scale) {
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < 4; ++k) boxes[4 * i + k] = boxes[4 * i + k] / scale;
+        boxes[4 * i + 2] = boxes[4 * i + 2] - boxes[4 * i + 0];
+        boxes[4 * i + 3] = boxes[4 * i + 3] - boxes[4 * i + 1];
+    }
+}

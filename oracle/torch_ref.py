@@ -401,3 +401,20 @@ def gen_targets(level_hw: Sequence[Tuple[int, int]], strides: Sequence[int], ran
         reg[~any_pos] = -1
         cls_t.append(cls); cnt_t.append(cnt); reg_t.append(reg)
     return torch.cat(cls_t, 1), torch.cat(cnt_t, 1), torch.cat(reg_t, 1)
+
+
+def normalize_u8(img_u8: np.ndarray, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> np.ndarray:
+    """ToTensor + Normalize of dataset/voc.py:57-58,104,155 on an [..., 3] uint8 array -> float32 [..., 3]."""
+    a = np.ascontiguousarray(img_u8, np.uint8)
+    out = np.empty(a.shape, np.float32)
+    clib().ref_normalize_u8(_p(a), a.size // 3, _p(np.asarray(mean, np.float32)), _p(np.asarray(std, np.float32)), _p(out))
+    return out
+
+
+def boxes_rescale_xywh(boxes: np.ndarray, scale: float) -> np.ndarray:
+    """Test_coco.py:147-151."""
+    lib = clib()
+    lib.ref_boxes_rescale_xywh.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float]
+    out = np.ascontiguousarray(boxes, np.float32).copy()
+    lib.ref_boxes_rescale_xywh(_p(out), out.size // 4, scale)
+    return out

@@ -63,6 +63,8 @@ _SIGS = {
     "fd_conv2d_nhwc_f32": (_I, [C.POINTER(ConvParams), _P]),
     "fd_nchw3_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _P]),
     "fd_nhwc_to_nchw": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),
+    "fd_preprocess_u8_nhwc4": (_I, [_P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
+    "fd_boxes_rescale_xywh": (_I, [_P, _L, _F, _P]),
     "fd_maxpool_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fd_upsample2x_add_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fd_dwconv3x3_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(Segs), _P]),

@@ -33,6 +33,49 @@ extern "C" int32_t fd_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_
     return FD_OK;
 }
 
+// uint8 HWC image (already resized + zero padded, dataset/voc.py:110-139) -> normalised fp32 [N][H][W][4]:
+// ToTensor (u8 / 255) then Normalize ((v - mean) / std), voc.py:57-58,104,155; channel 3 = 0.  Same fp32 op order.
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ x, float4* __restrict__ y,
+                                                             float m0, float m1, float m2, float s0, float s1, float s2,
+                                                             long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const unsigned char* p = x + 3 * i;
+        y[i] = make_float4(((float)p[0] / 255.0f - m0) / s0, ((float)p[1] / 255.0f - m1) / s1,
+                           ((float)p[2] / 255.0f - m2) / s2, 0.f);
+    }
+}
+
+extern "C" int32_t fd_preprocess_u8_nhwc4(const uint8_t* x, float* y, int32_t N, int32_t H, int32_t W, const float* mean3,
+                                          const float* std3, fd_stream_t stream) {
+    FD_REQUIRE(x && y && mean3 && std3 && N >= 1 && H >= 1 && W >= 1, FD_E_INVAL, "fd_preprocess_u8_nhwc4: bad argument");
+    FD_REQUIRE(((uintptr_t)y & 15) == 0, FD_E_INVAL, "fd_preprocess_u8_nhwc4: y not 16-byte aligned");
+    FD_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, FD_E_INVAL, "fd_preprocess_u8_nhwc4: zero std");
+    const long total = (long)N * H * W;
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, (float4*)y,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], total);
+    FD_CHECK_LAUNCH("fd_preprocess_u8_nhwc4");
+    return FD_OK;
+}
+
+// detections back to source-image scale, xyxy -> xywh (Test_coco.py:147-151): boxes /= scale; w = x2 - x1; h = y2 - y1
+__global__ __launch_bounds__(256) void boxes_to_xywh_kernel(float4* boxes, long n, float scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 b = boxes[i];
+    b.x = b.x / scale; b.y = b.y / scale; b.z = b.z / scale; b.w = b.w / scale;
+    b.z = b.z - b.x; b.w = b.w - b.y;
+    boxes[i] = b;
+}
+
+extern "C" int32_t fd_boxes_rescale_xywh(float* boxes, int64_t n_boxes, float scale, fd_stream_t stream) {
+    FD_REQUIRE(boxes && ((uintptr_t)boxes & 15) == 0 && scale != 0.f, FD_E_INVAL, "fd_boxes_rescale_xywh: bad argument");
+    if (n_boxes <= 0) return FD_OK;
+    hipLaunchKernelGGL(boxes_to_xywh_kernel, dim3((unsigned)((n_boxes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (float4*)boxes, (long)n_boxes, scale);
+    FD_CHECK_LAUNCH("fd_boxes_rescale_xywh");
+    return FD_OK;
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, int x_cs, int x_co,
                                                             float* __restrict__ y, int HW, int C) {
     __shared__ float tile[32][33];

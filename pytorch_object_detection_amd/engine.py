@@ -151,7 +151,11 @@ def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: Lis
     """torchvision-style ResNet-50 v1.5 trunk -> (C3, C4, C5) as (Rows, Segs).  `trunk` has conv1, bn1, layer1..4."""
     dev, pool = plan.device, plan.pool
     x4 = pool.get(batch * H * W, 4)
-    plan.add("input.nchw3_to_nhwc4", lambda: ops.nchw3_to_nhwc4(image_ref[0], x4.buf))
+    if getattr(plan, "input_u8", None):   # uint8 NHWC images: normalise on the device straight into the stem layout
+        mean, std = plan.input_u8
+        plan.add("input.preprocess_u8", lambda: ops.preprocess_u8(image_ref[0], x4.buf, mean, std))
+    else:
+        plan.add("input.nchw3_to_nhwc4", lambda: ops.nchw3_to_nhwc4(image_ref[0], x4.buf))
     s_in = Segs.make(batch, [(H, W)])
     # stem 7x7 s2 + BN + ReLU
     wp = ops.pack_stem_weight(_dev(trunk.conv1.weight, dev))

@@ -212,6 +212,24 @@ def nchw3_to_nhwc4(x: torch.Tensor, y: torch.Tensor) -> None:
     check(_lib.lib().fd_nchw3_to_nhwc4(x.data_ptr(), y.data_ptr(), N, H, W, _stream()), "fd_nchw3_to_nhwc4")
 
 
+def preprocess_u8(x: torch.Tensor, y: torch.Tensor, mean, std) -> None:
+    """uint8 [N,H,W,3] (resized + zero padded) -> normalised fp32 [N*H*W, 4] (stem input)."""
+    _need_gpu(x, y)
+    N, H, W, c = x.shape
+    assert c == 3 and x.dtype == torch.uint8 and x.is_contiguous()
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s_ = (C.c_float * 3)(*[float(v) for v in std])
+    check(_lib.lib().fd_preprocess_u8_nhwc4(x.data_ptr(), y.data_ptr(), N, H, W, m, s_, _stream()), "fd_preprocess_u8_nhwc4")
+
+
+def boxes_rescale_xywh_(boxes: torch.Tensor, scale: float) -> torch.Tensor:
+    """In place: boxes /= scale; (x1, y1, x2, y2) -> (x, y, w, h)  (Test_coco.py:147-151)."""
+    _need_gpu(boxes)
+    assert boxes.is_contiguous() and boxes.shape[-1] == 4 and boxes.dtype == torch.float32
+    check(_lib.lib().fd_boxes_rescale_xywh(boxes.data_ptr(), boxes.numel() // 4, float(scale), _stream()), "fd_boxes_rescale_xywh")
+    return boxes
+
+
 def nhwc_to_nchw(x: Rows, N: int, HW: int, out: torch.Tensor) -> None:
     check(_lib.lib().fd_nhwc_to_nchw(x.ptr, x.cs, x.co, out.data_ptr(), N, HW, x.C, _stream()), "fd_nhwc_to_nchw")
 

@@ -206,3 +206,18 @@ def test_se_block():
     got = out[:, C:].reshape(B, H, W, C).permute(0, 3, 1, 2).cpu()
     np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-5, rtol=1e-5)
     assert out[:, :C].abs().sum() == 0
+
+
+def test_preprocess_u8_and_box_rescale_bit_exact():
+    from oracle import torch_ref as R
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (2, 64, 96, 3), dtype=np.uint8)
+    img[:, 50:, :, :] = 0                                    # zero padding rows normalise to -mean/std, as in the reference
+    y = torch.empty(2 * 64 * 96, 4, device=DEV)
+    ops.preprocess_u8(torch.from_numpy(img).to(DEV), y, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+    got = y.cpu().numpy().reshape(2, 64, 96, 4)
+    np.testing.assert_array_equal(got[..., :3], R.normalize_u8(img))
+    assert (got[..., 3] == 0).all()
+    boxes = rng.uniform(0, 600, (3, 40, 4)).astype(np.float32)
+    out = ops.boxes_rescale_xywh_(torch.from_numpy(boxes).to(DEV), 1.7)
+    np.testing.assert_array_equal(out.cpu().numpy(), R.boxes_rescale_xywh(boxes, 1.7))

@@ -197,3 +197,15 @@ def test_mixed_aspect_832x1344_pyramid():
     assert n == len(exp[0][0])
     np.testing.assert_array_equal(c[0, :n].cpu().numpy(), exp[0][1])
     np.testing.assert_array_equal(b[0, :n].cpu().numpy(), exp[0][2])
+
+
+def test_uint8_input_matches_normalised_float_input():
+    """model(uint8 NHWC) == model(ToTensor+Normalize(NCHW float)) — the device-side pipeline tail."""
+    torch.manual_seed(11)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).eval().to(DEV)
+    img = torch.randint(0, 256, (2, 128, 160, 3), dtype=torch.uint8)
+    xf = torch.from_numpy(R.normalize_u8(img.numpy())).permute(0, 3, 1, 2).contiguous()
+    a = [t.clone() for t in model(xf.to(DEV))[0]]
+    b = model(img.to(DEV))[0]
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

@@ -136,3 +136,15 @@ def test_g8_tiny_fcos(golden):
         np.testing.assert_allclose(cls[i].numpy(), g[f"cls{i}"], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(cnt[i].numpy(), g[f"cnt{i}"], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(reg[i].numpy(), g[f"reg{i}"], rtol=1e-5, atol=1e-5)
+
+
+def test_normalize_and_box_rescale_against_numpy():
+    """Pipeline-tail restatements against their one-line numpy / torch definitions."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    mean, std = np.float32([0.485, 0.456, 0.406]), np.float32([0.229, 0.224, 0.225])
+    exp = (torch.from_numpy(img).float().div(255).sub(torch.from_numpy(mean)).div(torch.from_numpy(std))).numpy()
+    np.testing.assert_array_equal(R.normalize_u8(img), exp)
+    boxes = rng.uniform(0, 600, (9, 4)).astype(np.float32)
+    e = boxes.copy(); e /= 1.3; e[:, 2] -= e[:, 0]; e[:, 3] -= e[:, 1]
+    np.testing.assert_array_equal(R.boxes_rescale_xywh(boxes, 1.3), e)
