@@ -227,9 +227,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL (must precede HIP initialisation)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -320,7 +320,8 @@ def main():
         }
         if world == 1 and not args.no_fast_mode:
             line["fast_mode"] = fast_mode(model, head, clip, x, args, res)
-        line["nms_micro"] = nms_micro(dev, args.batch, with_cpu=sd_cpu is not None)
+        if world == 1:
+            line["nms_micro"] = nms_micro(dev, args.batch, with_cpu=sd_cpu is not None)
         if sd_cpu is not None:
             line["cpu_baseline"] = cpu_baseline(sd_cpu, args.classes, args.size)
         print(json.dumps(line), flush=True)

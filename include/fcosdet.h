@@ -109,12 +109,18 @@ typedef struct fd_conv_params {
     int32_t mode;   /* FD_CONV_GENERIC | FD_CONV_STEM */
     int32_t tile;   /* 0 = built-in heuristic; FD_TILE_* forces a block tile (plan-time autotuning) */
     int32_t tag;    /* 1 = launch under a separate kernel symbol (<..., TAG=1>) so a profiler can isolate this layer */
+    int32_t ksplit; /* <= 1: off.  > 1: split the K loop over `ksplit` workgroups per tile (finer work units for maps
+                       with fewer tiles than CU slots); partial sums go to `workspace`, a second launch combines them
+                       in slice order (deterministic) and applies the epilogue */
+    void* workspace;           /* split-K scratch, fd_conv_workspace_bytes(out_rows, Cout, ksplit) bytes, 16-B aligned */
+    int64_t workspace_bytes;
     int32_t precision; /* FD_PREC_F32 (exact fp32 MFMA) | FD_PREC_F16X3 (opt-in split-f16 products, see below) */
     float seg_param[FD_MAX_SEG]; /* per-level scalar for FD_ACT_EXP */
     fd_segs in;     /* input geometry */
 } fd_conv_params;
 
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
+int64_t fd_conv_workspace_bytes(int64_t out_rows, int32_t Cout, int32_t ksplit);
 
 /* [N][3][H][W] fp32 (NCHW, the reference's input layout, dataset/voc.py:141-173) -> [N][H][W][4] (c=3 zero) */
 int32_t fd_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, fd_stream_t stream);

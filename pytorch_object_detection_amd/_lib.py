@@ -50,7 +50,8 @@ class ConvParams(C.Structure):
                 ("y_cs", C.c_int32), ("y_co", C.c_int32),
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("dil", C.c_int32),
-                ("act", C.c_int32), ("act_c0", C.c_int32), ("mode", C.c_int32), ("tile", C.c_int32), ("tag", C.c_int32), ("precision", C.c_int32),
+                ("act", C.c_int32), ("act_c0", C.c_int32), ("mode", C.c_int32), ("tile", C.c_int32), ("tag", C.c_int32), ("ksplit", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("precision", C.c_int32),
                 ("seg_param", C.c_float * FD_MAX_SEG), ("segs", Segs)]
 
 
@@ -61,6 +62,7 @@ _SIGS = {
     "fd_version": (_I, []),
     "fd_last_error": (C.c_char_p, []),
     "fd_conv2d_nhwc_f32": (_I, [C.POINTER(ConvParams), _P]),
+    "fd_conv_workspace_bytes": (_L, [_L, _I, _I]),
     "fd_nchw3_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _P]),
     "fd_nhwc_to_nchw": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),
     "fd_preprocess_u8_nhwc4": (_I, [_P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),

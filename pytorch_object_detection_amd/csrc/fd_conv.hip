@@ -32,6 +32,9 @@ struct ConvArgs {
     int mtiles, ntiles;
     int vec_epi;   // output / residual views are 16-byte addressable: transposed float4 epilogue
     int is_gemm;   // 1x1 stride-1 unpadded conv: pure GEMM addressing
+    int Cout_epi;  // output-channel bound of the epilogue (= Cout, or the padded row length of a split-K slab)
+    int kt_per;    // K-tiles per split-K slice (blockIdx.y = slice); KT when split-K is off
+    long slice_stride;  // elements between consecutive split-K slabs in the workspace
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -168,12 +171,16 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
             }
 
     const int l31 = lane & 31, lh = lane >> 5;
-    load_tile(0);
+    // split-K: slice blockIdx.y owns K-tiles [kt0, kt1) and writes raw partial sums to its slab of the workspace
+    const int kt0 = blockIdx.y * a.kt_per;
+    const int kt1 = min(a.KT, kt0 + a.kt_per);
+    float* const ybase = a.y + (size_t)blockIdx.y * a.slice_stride;   // (never write to the kernarg struct itself)
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < a.KT; ++kt) {
-        const int buf = SB ? 0 : (kt & 1);
-        if (kt + 1 < a.KT) load_tile(kt + 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = SB ? 0 : ((kt - kt0) & 1);
+        if (kt + 1 < kt1) load_tile(kt + 1);
         if constexpr (SPLIT) {
             const _Float16* Ahi = Hs + buf * HSTG + (wm * TM * 32) * 32;
             const _Float16* Alo = Ahi + BM * 32;
@@ -224,8 +231,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
         }
         if (SB) {
             __syncthreads();                       // every wave is done reading the tile
-            if (kt + 1 < a.KT) store_tile(0);
-        } else if (kt + 1 < a.KT) {
+            if (kt + 1 < kt1) store_tile(0);
+        } else if (kt + 1 < kt1) {
             store_tile(buf ^ 1);
         }
         __syncthreads();
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
                 for (int p = 0; p < 4; ++p) {
                     const int m = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * p;
                     const int nn = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
-                    rres[i][j][p] = (m < a.M && nn < a.Cout)
+                    rres[i][j][p] = (m < a.M && nn < a.Cout_epi)
                                         ? *reinterpret_cast<const float4*>(a.res + (size_t)m * a.res_cs + a.res_co + nn)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
     for (int j = 0; j < TN; ++j) {
         const int nb = n0 + (wn * TN + j) * 32;
         const int n = nb + l31;
-        const bool n_ok = n < a.Cout;
+        const bool n_ok = n < a.Cout_epi;
         const float sc = (a.scale && n_ok) ? a.scale[n] : 1.0f;
         const float sf = (a.shift && n_ok) ? a.shift[n] : 0.0f;
 #pragma unroll
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
                     const int row = (lane >> 3) + 8 * p, c4 = (lane & 7) * 4;
                     const int m = mb + row, nn = nb + c4;
                     float4 v = *reinterpret_cast<const float4*>(stage + row * 32 + c4);
-                    if (m < a.M && nn < a.Cout) {
+                    if (m < a.M && nn < a.Cout_epi) {
                         if (a.res) {
                             float4 r;
                             if constexpr (SPLIT) r = *reinterpret_cast<const float4*>(a.res + (size_t)m * a.res_cs + a.res_co + nn);
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
                             if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, prm);
                             if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, prm);
                         }
-                        *reinterpret_cast<float4*>(a.y + (size_t)m * a.y_cs + a.y_co + nn) = v;
+                        *reinterpret_cast<float4*>(ybase + (size_t)m * a.y_cs + a.y_co + nn) = v;
                     }
                 }
                 __syncthreads();
@@ -319,10 +326,44 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
                                 if (t < a.nseg && m >= a.m_out[t]) s = t;
                             prm = a.seg_param[s];
                         }
-                        a.y[(size_t)m * a.y_cs + a.y_co + n] = fd_act(v, act, prm);
+                        ybase[(size_t)m * a.y_cs + a.y_co + n] = fd_act(v, act, prm);
                     }
                 }
             }
+        }
+    }
+}
+
+// split-K combine: y = act(sum_slices(ws) * scale + shift + res); one float4 of output channels per thread, slices
+// added in index order (deterministic).  `a` is the ORIGINAL conv (real y / scale / shift / res / act).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, const float* __restrict__ ws, int nslice, int ldw,
+                                                             long slab) {
+    const int q4 = ldw >> 2;
+    const long total = (long)a.M * q4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / q4;
+        const int nn = (int)(i - m * q4) * 4;
+        float4 v = *reinterpret_cast<const float4*>(ws + m * ldw + nn);
+        for (int s = 1; s < nslice; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(ws + s * slab + m * ldw + nn);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        float o[4] = {v.x, v.y, v.z, v.w};
+        float prm = 0.f;
+        if (a.act == FD_ACT_EXP) {
+            int sg = 0;
+#pragma unroll
+            for (int t = 1; t < FD_MAX_SEG; ++t)
+                if (t < a.nseg && m >= a.m_out[t]) sg = t;
+            prm = a.seg_param[sg];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = nn + e;
+            if (n >= a.Cout) continue;
+            float r = o[e] * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
+            if (a.res) r += a.res[(size_t)m * a.res_cs + a.res_co + n];
+            a.y[(size_t)m * a.y_cs + a.y_co + n] = fd_act(r, n >= a.act_c0 ? a.act : FD_ACT_NONE, prm);
         }
     }
 }
@@ -341,9 +382,16 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles), dim3(256), lds, stream, b);
+    hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles, (a.KT + a.kt_per - 1) / a.kt_per), dim3(256), lds, stream, b);
     FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32");
     return FD_OK;
+}
+
+static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStream_t stream);
+
+extern "C" int64_t fd_conv_workspace_bytes(int64_t out_rows, int32_t Cout, int32_t ksplit) {
+    if (out_rows < 1 || Cout < 1 || ksplit < 1) return -1;
+    return ksplit > 1 ? (int64_t)ksplit * out_rows * ((Cout + 3) & ~3) * 4 : 0;
 }
 
 extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream_) {
@@ -404,6 +452,32 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
                     ? 1 : 0;
 
     a.is_gemm = (!stem && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0) ? 1 : 0;
+    a.Cout_epi = a.Cout; a.kt_per = a.KT; a.slice_stride = 0;
+
+    const int ksplit = p->ksplit > 1 ? p->ksplit : 1;
+    if (ksplit > 1) {
+        FD_REQUIRE(!stem && ksplit <= 64 && a.KT >= ksplit, FD_E_INVAL, "fd_conv2d: ksplit=%d needs 1 < ksplit <= min(64, K-tiles=%d)", ksplit, a.KT);
+        const ConvArgs orig = a;
+        const int ldw = (a.Cout + 3) & ~3;
+        const long slab = (long)a.M * ldw;
+        FD_REQUIRE(p->workspace && ((uintptr_t)p->workspace & 15) == 0 && p->workspace_bytes >= (int64_t)ksplit * slab * 4, FD_E_INVAL,
+                   "fd_conv2d: split-K needs a 16-byte aligned workspace of fd_conv_workspace_bytes() bytes");
+        a.kt_per = (a.KT + ksplit - 1) / ksplit;
+        a.y = (float*)p->workspace; a.y_cs = ldw; a.y_co = 0; a.slice_stride = slab; a.Cout_epi = ldw;
+        a.scale = a.shift = a.res = nullptr; a.act = FD_ACT_NONE; a.vec_epi = 1;
+        const int rc = dispatch_conv(p, a, stem, stream);
+        if (rc != FD_OK) return rc;
+        const int nslice = (a.KT + a.kt_per - 1) / a.kt_per;
+        long g = ((long)orig.M * (ldw >> 2) + 255) / 256;
+        if (g > 16384) g = 16384;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, orig, (const float*)p->workspace, nslice, ldw, slab);
+        FD_CHECK_LAUNCH("fd_conv2d (split-K reduce)");
+        return FD_OK;
+    }
+    return dispatch_conv(p, a, stem, stream);
+}
+
+static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStream_t stream) {
 
     if (stem) return launch_conv<2, 2, 2, 1, true>(a, stream);       // 128 x 64
     if (p->precision == FD_PREC_F16X3) {   // split-f16: 3 f16 MFMAs per fp32 product (weights pre-split by the caller)

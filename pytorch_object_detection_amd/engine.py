@@ -130,17 +130,22 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     elif b is not None:
         shift = _dev(b, dev)
     plan.keep += [wp, scale, shift]
+    out = ops.conv_out_segs(segs, k, stride, pad, dil)
+    # split-K scratch: taken from the pool and handed straight back (stream order makes the sharing safe)
+    ws_rows = ops.KSPLIT_MAX * out.rows
+    ws = plan.pool.get(ws_rows, (co + 3) & ~3) if (plan.autotune and ws_rows * ((co + 3) & ~3) <= 64 * 1024 * 1024) else None
     call = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                          shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param, tag=tag,
-                         precision=1 if split else 0)
+                         precision=1 if split else 0, workspace=ws.buf if ws is not None else None)
     plan.add(name, call)
-    out = ops.conv_out_segs(segs, k, stride, pad, dil)
+    if ws is not None:
+        plan.pool.put(ws)
     if plan.autotune:
         hw = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
         key = f"B{segs.batch}|{hw}|{Cin}>{co}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{x.cs}|ycs{y.cs}"
         if split:
             key = "f16x3|" + key
-        plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co)
+        plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co, (Cin // 32) * k * k)
     plan.flops += 2 * out.rows * co * Cin * k * k
     plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k
     return out

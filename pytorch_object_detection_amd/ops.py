@@ -109,7 +109,8 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
               pad: int = 0, dil: int = 1, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
               res: Optional[Rows] = None, act: int = ACT_NONE, act_c0: int = 0,
               seg_param: Optional[Sequence[float]] = None, stem: bool = False, tile: int = 0,
-              tag: int = 0, precision: int = 0) -> Callable[[], None]:
+              tag: int = 0, precision: int = 0, ksplit: int = 1,
+              workspace: Optional[torch.Tensor] = None) -> Callable[[], None]:
     """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream."""
     _need_gpu(w_packed, scale, shift)
     p = ConvParams()
@@ -122,14 +123,17 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
         p.res_cs, p.res_co = res.cs, res.co
     p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, k, stride, pad, dil
     p.act, p.act_c0, p.mode = act, act_c0, (_lib.CONV_STEM if stem else _lib.CONV_GENERIC)
-    p.tile, p.tag, p.precision = tile, tag, precision
+    p.tile, p.tag, p.precision, p.ksplit = tile, tag, precision, ksplit
+    if workspace is not None:
+        _need_gpu(workspace)
+        p.workspace, p.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     if seg_param is not None:
         for i, v in enumerate(seg_param):
             p.seg_param[i] = float(v)
     p.segs = segs
     fn = _lib.lib().fd_conv2d_nhwc_f32
     ref = C.byref(p)
-    keep = (x, w_packed, y, scale, shift, res, p)
+    keep = (x, w_packed, y, scale, shift, res, p, workspace)
 
     def run(_keep=keep):
         check(fn(ref, _stream()), "fd_conv2d_nhwc_f32")
@@ -162,25 +166,40 @@ def save_tune_table() -> None:
         json.dump(dict(sorted(_TUNE_CACHE.items())), f, indent=0)
 
 
-def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, reps: int = 3) -> int:
-    """Block-tile choice for one conv launch.  Looked up in the committed table (tuned/gfx950_tiles.json, measured on
-    MI355X) first; a miss is timed on the spot under every sensible tile (best of 3 batches of `reps` launches) and
-    remembered for the process (bench.py --save-tuning writes the table back).  Returns the tile id (0 = heuristic)."""
+KSPLIT_MAX = 8
+
+
+def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int, reps: int = 3) -> int:
+    """Block-tile (+ split-K factor) choice for one conv launch.  Looked up in the committed table
+    (tuned/gfx950_tiles.json, measured on MI355X) first; a miss is timed on the spot under every sensible tile — and,
+    for maps with few tiles, K split 2/4/8 ways — (best of 3 batches of `reps` launches) and remembered for the
+    process (bench.py --save-tuning writes the table back).  Returns tile | ksplit << 8 (tile 0 = heuristic)."""
     p = run.params  # type: ignore[attr-defined]
     table = _tune_table()
+
+    def apply(code: int) -> int:
+        p.tile, p.ksplit = code & 0xFF, max(1, code >> 8)
+        if p.ksplit > 1 and not p.workspace:
+            p.ksplit = 1
+        return code
+
     if _TUNE_MODE != "force" and key in table:
-        p.tile = int(table[key])
-        return p.tile
+        return apply(int(table[key]))
     if _TUNE_MODE == "0":
-        return 0
-    cands = [0]
+        return apply(0)
+    cands = [(0, 1)]
     for tid, (bm, bn) in _lib.TILES.items():
         padded = -(-Cout // bn) * bn
         if padded <= max(32, int(Cout * 1.34)) and not (bn == 32 and Cout > 32):
-            cands.append(tid)
+            cands.append((tid, 1))
+            ntile = -(-M // bm) * -(-Cout // bn)
+            if p.workspace:
+                for ks in (2, 4, 8):
+                    if ks <= KSPLIT_MAX and KT >= 4 * ks and ntile * ks <= 2048 and ntile < 1024:
+                        cands.append((tid, ks))
     best, best_t = 0, float("inf")
-    for tid in cands:
-        p.tile = tid
+    for tid, ks in cands:
+        apply(tid | (ks << 8))
         run()  # warm
         t = float("inf")
         for _ in range(3):
@@ -191,11 +210,10 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, reps: in
             e1.record()
             e1.synchronize()
             t = min(t, e0.elapsed_time(e1) / reps)
-        if t < best_t * 0.985:  # an earlier candidate wins near-ties
-            best, best_t = tid, t
-    p.tile = best
+        if t < best_t * 0.985:  # an earlier (simpler) candidate wins near-ties
+            best, best_t = tid | ((ks if ks > 1 else 0) << 8), t
     table[key] = best
-    return best
+    return apply(best)
 
 
 def conv_out_segs(segs: Segs, k: int, stride: int, pad: int, dil: int) -> Segs:

@@ -71,6 +71,36 @@ def test_conv_single_level(case, prec):
         np.testing.assert_allclose(from_rows(y, B, Ho, Wo).numpy(), ref.numpy(), atol=ATOL, rtol=RTOL, err_msg=f"tile {tile}")
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("ksplit", [2, 3, 8])
+def test_conv_split_k(ksplit, prec):
+    """K split over several workgroups per tile + deterministic combine launch (epilogue incl. residual / act / odd Cout)."""
+    gen = torch.Generator().manual_seed(21 + ksplit)
+    B, Cin, H, W = 2, 256, 10, 10
+    for Cout, act, use_res in ((128, ACT_RELU, True), (5, ACT_NONE, False)):
+        x = torch.randn(B, Cin, H, W, generator=gen)
+        w = torch.randn(Cout, Cin, 3, 3, generator=gen) / np.sqrt(Cin * 9)
+        scale, shift = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen)
+        res = torch.randn(B, Cout, H, W, generator=gen) if use_res else None
+        ref = F.conv2d(x, w, None, 1, 2, 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        ref = act_ref(ref + res if use_res else ref, act)
+        segs = Segs.make(B, [(H, W)])
+        y = ops.new_rows(B * H * W, 8 if Cout == 5 else Cout, DEV)
+        yv = ops.Rows(y.buf, 0, Cout)
+        ws = torch.empty(ksplit * B * H * W * ((Cout + 3) & ~3), device=DEV)
+        wp = ops.pack_conv_weight_f16x3(w.to(DEV)) if prec == "f16x3" else ops.pack_conv_weight(w.to(DEV))
+        outs = []
+        for _ in range(2):
+            y.buf.fill_(float("nan"))
+            ops.conv_call(to_rows(x), segs, wp, yv, Cin=Cin, Cout=Cout, k=3, pad=2, dil=2, scale=scale.to(DEV),
+                          shift=shift.to(DEV), res=to_rows(res) if use_res else None, act=act, tile=4, ksplit=ksplit,
+                          workspace=ws, precision=1 if prec == "f16x3" else 0)()
+            outs.append(yv.tensor().clone())
+        assert torch.equal(outs[0], outs[1])                     # fixed combine order: bitwise reproducible
+        got = outs[0].reshape(B, H, W, Cout).permute(0, 3, 1, 2).cpu()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=ATOL, rtol=RTOL)
+
+
 def test_conv_stem_7x7():
     gen = torch.Generator().manual_seed(7)
     B, H, W = 2, 64, 96
