@@ -18,7 +18,7 @@ def test_ltrb_loss_golden(golden, mode, P):
     tgt = torch.from_numpy(g[f"P{P}_tgt"])[None].to(DEV)
     mask = torch.ones(1, P, dtype=torch.bool, device=DEV)
     loss = ltrb_reg_loss(pred, tgt, mask, mode)           # [1] = sum / P
-    np.testing.assert_allclose(float(loss[0]) * P, float(g[f"P{P}_{mode}_loss"]), rtol=2e-6)
+    np.testing.assert_allclose(float(loss[0].detach()) * P, float(g[f"P{P}_{mode}_loss"]), rtol=2e-6)
     (loss.sum() * P).backward()
     np.testing.assert_allclose(pred.grad[0].cpu().numpy(), g[f"P{P}_{mode}_grad"], rtol=2e-5, atol=1e-7)
 

@@ -192,3 +192,33 @@ def test_dataencoder_api(golden):
     np.testing.assert_array_equal(keep.cpu().numpy(), g[f"p{c}_keep"])
     g4 = golden("g4_pairwise_iou")
     np.testing.assert_array_equal(enc._box_iou(_t(g4["a"]), _t(g4["b"])).cpu().numpy(), g4["iou_plus1"])
+
+
+def test_edge_shapes_and_errors():
+    from pytorch_object_detection_amd._lib import FdError
+    rng = np.random.default_rng(3)
+    # K not a multiple of 64, single box, single location, non-multiple-of-4 class count (scalar decode path)
+    for K in (1, 65, 1000, 1024):
+        boxes = _rand_boxes(rng, K, True)[None]
+        scores = np.sort(rng.uniform(0.06, 1, (1, K)).astype(np.float32), axis=1)[:, ::-1].copy()
+        classes = rng.integers(1, 4, (1, K)).astype(np.int64)
+        _, _, _, keep, counts = ops.batched_nms(_t(scores), _t(classes), _t(boxes), 0.05, 0.6)
+        exp = R.post_process(scores, classes, boxes, 0.05, 0.6)[0]
+        np.testing.assert_array_equal(keep[0, :int(counts[0])].cpu().numpy(), exp)
+    ts, tc, tb, ti = ops.fcos_topk(_t(np.float32([[0.3]])), _t(np.int32([[7]])), _t(np.float32([[[1, 2, 3, 4]]])), 1, want_idx=True)
+    assert float(ts) == np.float32(0.3) and int(tc) == 7 and int(ti) == 0
+    gen = torch.Generator().manual_seed(4)
+    outs = [[torch.randn(1, c, 3, 5, generator=gen).to(DEV)] for c in (21, 1)] + [[torch.rand(1, 4, 3, 5, generator=gen).to(DEV) * 9]]
+    s, c, b = FCOSHead(0.05, 0.6, 1000, [8]).decode_topk(outs)
+    coords = R.coords_fcos(3, 5, 8)
+    es, ec, eb = R.decode(R.flatten_levels([o.cpu() for o in outs[0]], 1), R.flatten_levels([o.cpu() for o in outs[1]], 1),
+                          R.flatten_levels([o.cpu() for o in outs[2]], 1), coords)
+    idx = R.topk(es, 15)
+    np.testing.assert_array_equal(c.cpu().numpy()[0], ec[0][idx[0]])
+    np.testing.assert_array_equal(b.cpu().numpy()[0], eb[0][idx[0]])
+    # documented limits fail loudly instead of silently truncating
+    big = [[torch.zeros(1, c, 40, 40, device=DEV)] for c in (20, 1, 4)]
+    with pytest.raises(FdError, match="1024"):
+        FCOSHead(0.05, 0.6, 1500, [8])(big)
+    with pytest.raises(FdError):
+        ops.fcos_topk(_t(np.zeros((1, 10), np.float32)), _t(np.zeros((1, 10), np.int32)), _t(np.zeros((1, 10, 4), np.float32)), 11)
