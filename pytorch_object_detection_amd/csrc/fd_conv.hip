@@ -102,17 +102,18 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
     }
 
     float4 ra[AP], rb[BP];
+    // k-tile order = (32-channel chunk, tap): the 9 taps of one channel chunk are consecutive, so the shifted re-reads
+    // of the same input pixels hit L1/L2 instead of travelling from the Infinity Cache.  load_tile() is called with
+    // consecutive kt, so (chunk, filter row, filter column) advance as counters (no divisions in the K loop).
+    int ld_cc = 0, ld_r = 0, ld_q = 0;
     auto load_tile = [&](int kt) {
         int r, q, c0;
         if (STEM) { r = kt; q = chunk; c0 = 0; }
         else {
-            // k-tile order = (32-channel chunk, tap): the 9 taps of one channel chunk are consecutive, so the
-            // shifted re-reads of the same input pixels hit L1/L2 instead of travelling from the Infinity Cache
-            const int cc = kt / a.ntaps;
-            const int tap = kt - cc * a.ntaps;
-            c0 = cc * 32 + chunk * 4;
-            r = tap / a.KW;
-            q = tap - r * a.KW;
+            c0 = ld_cc * 32 + chunk * 4;
+            r = ld_r;
+            q = ld_q;
+            if (++ld_q == a.KW) { ld_q = 0; if (++ld_r * a.KW == a.ntaps) { ld_r = 0; ++ld_cc; } }
         }
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
@@ -174,6 +175,12 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
     // split-K: slice blockIdx.y owns K-tiles [kt0, kt1) and writes raw partial sums to its slab of the workspace
     const int kt0 = blockIdx.y * a.kt_per;
     const int kt1 = min(a.KT, kt0 + a.kt_per);
+    if (!STEM) {
+        ld_cc = kt0 / a.ntaps;
+        const int tap0 = kt0 - ld_cc * a.ntaps;
+        ld_r = tap0 / a.KW;
+        ld_q = tap0 - ld_r * a.KW;
+    }
     float* const ybase = a.y + (size_t)blockIdx.y * a.slice_stride;   // (never write to the kernarg struct itself)
     load_tile(kt0);
     store_tile(0);
