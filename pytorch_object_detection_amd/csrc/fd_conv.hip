@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
         } else {
         const float* Ab = As + buf * BM * 32 + (wm * TM * 32) * 32;
             const float* Bb = Bs + buf * BN * 32 + (wn * TN * 32) * 32;
-    #pragma unroll
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float4 fa[TM], fb[TN];
     #pragma unroll
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                     }
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         if (SB) {
             __syncthreads();                       // every wave is done reading the tile
