@@ -33,14 +33,17 @@ def test_struct_layout_matches_c():
     #include <stdio.h>
     #include <stddef.h>
     #include "fcosdet.h"
-    int main(void){ printf("%zu %zu %zu %zu %zu\n", sizeof(fd_segs), sizeof(fd_conv_params),
-        offsetof(fd_conv_params, x_cs), offsetof(fd_conv_params, seg_param), offsetof(fd_conv_params, in)); return 0; }'''
+    int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(fd_segs), sizeof(fd_conv_params),
+        offsetof(fd_conv_params, x_cs), offsetof(fd_conv_params, seg_param), offsetof(fd_conv_params, in),
+        offsetof(fd_conv_params, tile), offsetof(fd_conv_params, ksplit), offsetof(fd_conv_params, workspace),
+        offsetof(fd_conv_params, workspace_bytes), offsetof(fd_conv_params, precision)); return 0; }'''
     exe = os.path.join(ROOT, "oracle", "_build", "abi_probe")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
     vals = [int(v) for v in subprocess.check_output([exe]).split()]
-    assert vals == [ctypes.sizeof(_lib.Segs), ctypes.sizeof(_lib.ConvParams), _lib.ConvParams.x_cs.offset,
-                    _lib.ConvParams.seg_param.offset, _lib.ConvParams.segs.offset]
+    P = _lib.ConvParams
+    assert vals == [ctypes.sizeof(_lib.Segs), ctypes.sizeof(P), P.x_cs.offset, P.seg_param.offset, P.segs.offset,
+                    P.tile.offset, P.ksplit.offset, P.workspace.offset, P.workspace_bytes.offset, P.precision.offset]
 
 
 def test_segs_table():
