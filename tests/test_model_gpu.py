@@ -209,3 +209,32 @@ def test_uint8_input_matches_normalised_float_input():
     b = model(img.to(DEV))[0]
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_full_size_batch16_is_per_image_independent():
+    """BASELINE configs[1] at full size (B=16, 640x640, 80 classes) through a size-independent property: every image of
+    the batch gives the outputs and detections it gives alone (frozen BN, per-sample GroupNorm / SE, per-image
+    post-process), i.e. the batched plan (grouped levels, tiles, split-K) mixes nothing across images."""
+    torch.manual_seed(21)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 80, 256).eval()
+    randomize_norms(model, 22)
+    model.to(DEV)
+    x = torch.randn(16, 3, 640, 640, device=DEV)
+    head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
+    out = model(x)
+    full = [[t.clone() for t in grp] for grp in out]
+    s, c, b, n = head.detect_padded(out)
+    for i in (0, 7, 15):
+        oi = model(x[i:i + 1].contiguous())
+        for g_full, g_one in zip(full, oi):
+            for tf, to in zip(g_full, g_one):
+                np.testing.assert_allclose(tf[i:i + 1].cpu().numpy(), to.cpu().numpy(), atol=2e-5, rtol=2e-5)
+        si, ci, bi, ni = head.detect_padded(oi)
+        k = int(ni[0])
+        assert k == int(n[i])
+        # random-init scores are nearly tied, so 1e-7 differences (split-K summation order) may swap neighbours in the
+        # score ordering and swap a candidate at the top-1000 cut: compare the detections as sets of (class, box) rows
+        def rows(cls, box):
+            return {(int(cl),) + tuple(np.round(bx.astype(np.float64), 2)) for cl, bx in zip(cls, box)}
+        ra, rb = rows(ci[0, :k].cpu().numpy(), bi[0, :k].cpu().numpy()), rows(c[i, :k].cpu().numpy(), b[i, :k].cpu().numpy())
+        assert len(ra & rb) >= 0.99 * k, (len(ra & rb), k)
