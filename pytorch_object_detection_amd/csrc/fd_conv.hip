@@ -42,9 +42,12 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + (
 __device__ __forceinline__ int lds_off_h(int row, int c8) { return row * 32 + ((c8 ^ ((row >> 2) & 3)) << 3); }
 
 template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT>
-__global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 1) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WGM * WGN * 64, (TM * TN == 4) ? ((SPLIT || WGM * WGN == 8) ? 2 : (SB ? 3 : 1)) : 1)
+void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    constexpr int AP = BM / 32, BP = BN / 32;  // loader passes (32 rows x 8 chunks per pass)
+    constexpr int NT = WGM * WGN * 64;         // threads: 4 waves (256) or 8 waves (512: the 256x128 tile)
+    constexpr int RPP = NT / 8;                // rows per loader pass (8 lanes fetch one 128-byte row segment)
+    constexpr int AP = BM / RPP, BP = BN / RPP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NBUF = SB ? 1 : 2;             // SB: one LDS buffer (2 barriers per K-tile, half the LDS -> more blocks/CU)
     float* As = reinterpret_cast<float*>(smem);  // [NBUF][BM*32]
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
     int a_base[AP], a_hi0[AP], a_wi0[AP], a_H[AP], a_W[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + RPP * i;
         if (a.is_gemm) {  // 1x1, stride 1, no padding: the input row IS the output row (no divisions)
             a_base[i] = m; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = (m < a.M) ? 1 : 0; a_W[i] = 1;
             continue;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
     bool b_ok[BP];
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
-        const int n = n0 + lrow + 32 * j;
+        const int n = n0 + lrow + RPP * j;
         b_ok[j] = n < a.Cout;
         b_ptr[j] = a.w + (size_t)(b_ok[j] ? n : 0) * a.Kpacked + chunk * 4;
     }
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
             _Float16* Blo = Bhi + BN * 32;
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
-                const int row = lrow + 32 * i;
+                const int row = lrow + RPP * i;
                 const f32x4 v = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
                 const h4 hi = __builtin_convertvector(v, h4);                       // round to nearest
                 const f32x4 rem = (v - __builtin_convertvector(hi, f32x4)) * FD_SPLIT_SCALE;   // exact residual
@@ -146,16 +149,16 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? (SPLIT ? 2 : (SB ? 3 : 1)) : 
             }
 #pragma unroll
             for (int j = 0; j < BP; ++j) {   // weights arrive pre-split: 16-B chunks 0-3 = hi, 4-7 = lo of this K-tile
-                const int row = lrow + 32 * j;
+                const int row = lrow + RPP * j;
                 *reinterpret_cast<float4*>(((chunk & 4) ? Blo : Bhi) + lds_off_h(row, chunk & 3)) = rb[j];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < AP; ++i)
-                *reinterpret_cast<float4*>(As + buf * BM * 32 + lds_off(lrow + 32 * i, chunk)) = ra[i];
+                *reinterpret_cast<float4*>(As + buf * BM * 32 + lds_off(lrow + RPP * i, chunk)) = ra[i];
 #pragma unroll
             for (int j = 0; j < BP; ++j)
-                *reinterpret_cast<float4*>(Bs + buf * BN * 32 + lds_off(lrow + 32 * j, chunk)) = rb[j];
+                *reinterpret_cast<float4*>(Bs + buf * BN * 32 + lds_off(lrow + RPP * j, chunk)) = rb[j];
         }
     };
 
@@ -381,7 +384,9 @@ template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG 
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int lds_ab = (SB ? 1 : 2) * (BM + BN) * 32 * 4;
-    constexpr int lds = lds_ab > 16384 ? lds_ab : 16384;   // the epilogue stages 4 x 4 KiB
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int lds_epi = (NT / 64) * 4096;              // the epilogue stages one 4 KiB sub-tile per wave
+    constexpr int lds = lds_ab > lds_epi ? lds_ab : lds_epi;
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
@@ -391,7 +396,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles, (a.KT + a.kt_per - 1) / a.kt_per), dim3(256), lds, stream, b);
+    hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles, (a.KT + a.kt_per - 1) / a.kt_per), dim3(NT), lds, stream, b);
     FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32");
     return FD_OK;
 }
@@ -509,6 +514,10 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
             case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true, 0, true>(a, stream);
             case FD_TILE_128x32: return launch_conv<4, 1, 1, 1, false, false, 0, true>(a, stream);
             case FD_TILE_128x96: return launch_conv<4, 1, 1, 3, false, false, 0, true>(a, stream);
+            case FD_TILE_256x128:
+                return tg ? launch_conv<4, 2, 2, 2, false, false, 1, true>(a, stream) : launch_conv<4, 2, 2, 2, false, false, 0, true>(a, stream);
+            case FD_TILE_256x128_SB:
+                return tg ? launch_conv<4, 2, 2, 2, false, true, 1, true>(a, stream) : launch_conv<4, 2, 2, 2, false, true, 0, true>(a, stream);
             default: fd_set_error("fd_conv2d: tile id %d has no split-f16 kernel", p->tile); return FD_E_UNSUPPORTED;
         }
     }
@@ -533,6 +542,8 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
         case FD_TILE_128x128_SB: return launch_conv<2, 2, 2, 2, false, true>(a, stream);
         case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true>(a, stream);
         case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true>(a, stream);
+        case FD_TILE_256x128: return launch_conv<4, 2, 2, 2, false, false>(a, stream);
+        case FD_TILE_256x128_SB: return launch_conv<4, 2, 2, 2, false, true>(a, stream);
         default: fd_set_error("fd_conv2d: unknown tile id %d", p->tile); return FD_E_INVAL;
     }
     if (a.Cout <= 32) return launch_conv<4, 1, 1, 1, false>(a, stream);   // 128 x 32
