@@ -35,6 +35,7 @@ struct ConvArgs {
     int Cout_epi;  // output-channel bound of the epilogue (= Cout, or the padded row length of a split-K slab)
     int kt_per;    // K-tiles per split-K slice (blockIdx.y = slice); KT when split-K is off
     long slice_stride;  // elements between consecutive split-K slabs in the workspace
+    unsigned x_bytes, w_bytes;   // extents of the input / packed-weight buffers (raw buffer descriptors: OOB reads return 0)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -70,13 +71,21 @@ void conv_igemm_kernel(ConvArgs a) {
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- per-thread A rows: decode (segment, image, ho, wo) once ----
+    // Operands are fetched with raw buffer loads: an out-of-range byte offset returns zeros, so padding taps, rows past
+    // M and channels past Cout need no exec-mask branch and no zero fill; per K-tile a row costs one 24-bit mad, two
+    // adds, two compares and a select.
     const int lrow = tid >> 3, chunk = tid & 7;
-    int a_base[AP], a_hi0[AP], a_wi0[AP], a_H[AP], a_W[AP];
+    constexpr unsigned OOB = 0xC0000000u;       // >= any buffer size (host checks < 3 GiB): reads as zero
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, (int)a.w_bytes, 0x00020000);
+    unsigned a_off[AP];                         // byte offset of tap (0, 0), channel chunk 0 (may wrap below zero)
+    int a_wcs[AP], a_hi0[AP], a_wi0[AP], a_H[AP], a_W[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + lrow + RPP * i;
         if (a.is_gemm) {  // 1x1, stride 1, no padding: the input row IS the output row (no divisions)
-            a_base[i] = m; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = (m < a.M) ? 1 : 0; a_W[i] = 1;
+            a_off[i] = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) * 4u;
+            a_wcs[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = (m < a.M) ? 1 : 0; a_W[i] = 1;
             continue;
         }
         int s = 0;
@@ -89,19 +98,19 @@ void conv_igemm_kernel(ConvArgs a) {
         const int n = local / hw;
         const int rem = local - n * hw;
         const int ho = rem / Wo, wo = rem - ho * Wo;
-        a_base[i] = a.m_in[s] + n * H * W;
         a_hi0[i] = ho * a.stride - a.pad;
         a_wi0[i] = wo * a.stride - a.pad;
         a_H[i] = (m < a.M) ? H : 0;  // H = 0 makes every tap invalid for rows past M
         a_W[i] = W;
+        a_wcs[i] = W * a.x_cs * 4;   // bytes per input image row
+        a_off[i] = ((unsigned)(a.m_in[s] + n * H * W + a_hi0[i] * W + a_wi0[i]) * (unsigned)a.x_cs +
+                    (unsigned)(a.x_co + chunk * 4)) * 4u;
     }
-    const float* b_ptr[BP];
-    bool b_ok[BP];
+    unsigned b_off[BP];
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
         const int n = n0 + lrow + RPP * j;
-        b_ok[j] = n < a.Cout;
-        b_ptr[j] = a.w + (size_t)(b_ok[j] ? n : 0) * a.Kpacked + chunk * 4;
+        b_off[j] = (n < a.Cout) ? ((unsigned)n * (unsigned)a.Kpacked + (unsigned)(chunk * 4)) * 4u : OOB;
     }
 
     float4 ra[AP], rb[BP];
@@ -110,25 +119,27 @@ void conv_igemm_kernel(ConvArgs a) {
     // consecutive kt, so (chunk, filter row, filter column) advance as counters (no divisions in the K loop).
     int ld_cc = 0, ld_r = 0, ld_q = 0;
     auto load_tile = [&](int kt) {
-        int r, q, c0;
-        if (STEM) { r = kt; q = chunk; c0 = 0; }
+        int dr, dq;          // tap displacement in input rows / columns
+        unsigned dbytes;     // uniform byte displacement: column shift + channel chunk
+        if (STEM) { dr = kt; dq = 0; dbytes = 0; }
         else {
-            c0 = ld_cc * 32 + chunk * 4;
-            r = ld_r;
-            q = ld_q;
+            dr = ld_r * a.dil;
+            dq = ld_q * a.dil;
+            dbytes = (unsigned)(dq * a.x_cs + ld_cc * 32) * 4u;
             if (++ld_q == a.KW) { ld_q = 0; if (++ld_r * a.KW == a.ntaps) { ld_r = 0; ++ld_cc; } }
         }
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            const int hi = a_hi0[i] + r * a.dil, wi = a_wi0[i] + q * a.dil;
+            const int hi = a_hi0[i] + dr, wi = a_wi0[i] + dq + (STEM ? chunk : 0);
             bool ok = (unsigned)hi < (unsigned)a_H[i] && (unsigned)wi < (unsigned)a_W[i];
             if (STEM) ok = ok && (chunk < 7);
-            const unsigned off = (unsigned)(a_base[i] + hi * a_W[i] + wi) * (unsigned)a.x_cs + (unsigned)(a.x_co + c0);
-            ra[i] = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned off = a_off[i] + (unsigned)__mul24(dr, a_wcs[i]) + dbytes;
+            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : OOB), 0, 0));
         }
+        const unsigned kb = (unsigned)kt * 128u;
 #pragma unroll
         for (int j = 0; j < BP; ++j)
-            rb[j] = b_ok[j] ? *reinterpret_cast<const float4*>(b_ptr[j] + kt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(b_off[j] + kb), 0, 0));
     };
     auto store_tile = [&](int buf) {
         if constexpr (SPLIT) {
@@ -466,6 +477,13 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
                     ? 1 : 0;
 
     a.is_gemm = (!stem && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0) ? 1 : 0;
+    {
+        const long xb = (long)p->in.m_start[p->in.nseg] * p->x_cs * 4, wb = (long)p->Cout * a.Kpacked * 4;
+        FD_REQUIRE(xb < 0xC0000000L && wb < 0xC0000000L, FD_E_UNSUPPORTED, "fd_conv2d: input / weight buffer exceeds 3 GiB");
+        a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+        for (int sg = 0; sg < p->in.nseg; ++sg)
+            FD_REQUIRE((long)p->in.W[sg] * p->x_cs * 4 < (1L << 23), FD_E_UNSUPPORTED, "fd_conv2d: image row of %ld bytes exceeds the 24-bit row-stride path", (long)p->in.W[sg] * p->x_cs * 4);
+    }
     a.Cout_epi = a.Cout; a.kt_per = a.KT; a.slice_stride = 0;
 
     const int ksplit = p->ksplit > 1 ? p->ksplit : 1;
