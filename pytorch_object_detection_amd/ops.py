@@ -144,7 +144,9 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
 
 _TUNE_CACHE: dict = {}
 _TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_tiles.json")
-_TUNE_MODE = os.environ.get("FD_AUTOTUNE", "1")   # "1": table, then tune misses; "0": table / heuristic only; "force": re-tune
+# FD_AUTOTUNE: "0" (default) = committed table, misses use the shape heuristic (no first-call latency);
+#              "1" = time the misses on the spot; "force" = re-time everything (bench.py --save-tuning writes the table)
+_TUNE_MODE = os.environ.get("FD_AUTOTUNE", "0")
 _TUNE_LOADED = False
 
 
@@ -169,6 +171,32 @@ def save_tune_table() -> None:
 KSPLIT_MAX = 8
 
 
+def heuristic_conv(M: int, Cout: int, KT: int, have_ws: bool) -> int:
+    """Tile | ksplit << 8 for a shape that is not in the tuned table, distilled from the table: single-LDS-buffer
+    tiles (3-4 blocks/CU) whenever they still give >= 2 workgroups per CU, otherwise 64x64 tiles with the K loop
+    split so that about 2-4 workgroups per CU exist."""
+    if Cout <= 32:
+        return 5
+    if Cout <= 64:
+        tiles, bm, bn = 4, 64, 64
+    elif Cout <= 96:
+        return 6
+    else:
+        def nblk(bm_, bn_):
+            return -(-M // bm_) * -(-Cout // bn_)
+        if nblk(128, 128) >= 768:
+            return 7
+        if nblk(64, 128) >= 512:
+            return 9
+        tiles, bm, bn = 4, 64, 64
+    n = -(-M // bm) * -(-Cout // bn)
+    ks = 1
+    if have_ws:
+        while ks < KSPLIT_MAX and n * ks < 512 and KT >= 8 * ks:
+            ks *= 2
+    return tiles | ((ks if ks > 1 else 0) << 8)
+
+
 def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int, reps: int = 3) -> int:
     """Block-tile (+ split-K factor) choice for one conv launch.  Looked up in the committed table
     (tuned/gfx950_tiles.json, measured on MI355X) first; a miss is timed on the spot under every sensible tile — and,
@@ -186,7 +214,7 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
     if _TUNE_MODE != "force" and key in table:
         return apply(int(table[key]))
     if _TUNE_MODE == "0":
-        return apply(0)
+        return apply(heuristic_conv(M, Cout, KT, bool(p.workspace)))
     cands = [(0, 1)]
     for tid, (bm, bn) in _lib.TILES.items():
         padded = -(-Cout // bn) * bn
