@@ -28,10 +28,13 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md "Pe
 PEAK_HBM_GBS = 8000.0
 
 
-def build_model(num_classes: int, seed: int):
-    from pytorch_object_detection_amd.model.od import HalfInvertedStageFCOS
+def build_model(num_classes: int, seed: int, name: str = "HISFCOS"):
+    from pytorch_object_detection_amd.model.od import FCOS, HalfInvertedStageFCOS
     torch.manual_seed(seed)
-    model = HalfInvertedStageFCOS([512, 1024, 2048], num_classes, 256).eval()
+    if name == "FCOS":   # the baseline detector behind the same API; diagnostic, not the headline
+        model = FCOS([2048, 1024, 512], num_classes, 256).eval()
+    else:
+        model = HalfInvertedStageFCOS([512, 1024, 2048], num_classes, 256).eval()
     gen = torch.Generator().manual_seed(seed + 1)
     for m in model.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
@@ -218,6 +221,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--classes", type=int, default=80)
+    ap.add_argument("--model", default="HISFCOS", choices=["HISFCOS", "FCOS"], help="FCOS = diagnostic run of the baseline detector")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra opt-in f16x3 measurement")
     ap.add_argument("--save-tuning", action="store_true", help="write the conv tile table measured in this run back to tuned/gfx950_tiles.json")
@@ -247,7 +251,9 @@ def main():
     from pytorch_object_detection_amd.model.modules.head import ClipBoxes, FCOSHead
     _lib.lib()
 
-    model = build_model(args.classes, seed=0)
+    model = build_model(args.classes, seed=0, name=args.model)
+    if args.model != "HISFCOS":
+        args.no_cpu_baseline = True   # the CPU-baseline leg restates HISFCOS only
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     model.to(dev)
     head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
@@ -302,11 +308,11 @@ def main():
         achieved = tower_flops / (tower_ms * 1e-3) / 1e12
         ms_step = el / args.steps * 1e3
         line = {
-            "metric": "images/sec HISFCOS-R50 640x640 inference",
+            "metric": f"images/sec {args.model}-R50 {args.size}x{args.size} inference",
             "value": round(images / el, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"HISFCOS-R50 {args.size}x{args.size} batch={args.batch}/GPU inference on MI355X, "
+            "config": {"workload": f"{args.model}-R50 {args.size}x{args.size} batch={args.batch}/GPU inference on MI355X, "
                                    f"fused conv head + HIP NMS ({args.classes} classes, score>=0.05, IoU 0.6, top-1000)"
                                    + (", RCCL detection all-gather" if world > 1 else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (image-sharded)"},
