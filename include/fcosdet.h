@@ -124,6 +124,28 @@ typedef struct fd_conv_params {
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
 int64_t fd_conv_workspace_bytes(int64_t out_rows, int32_t Cout, int32_t ksplit);
 
+/* Convolution backward for the train step (reference train.py:175-181: scaler.scale(loss).backward() runs torch's
+ * convolution_backward through cuDNN / MIOpen).
+ *  - weight gradient: fd_conv2d_bwd_weight_f32, a pixel-reduction GEMM on the fp32 MFMA:
+ *        dw[co][r][q][ci] = sum_m dy[m][co] * x[pix(m, r, q)][ci]          (dw is [Cout][KH][KW][Cin], OHWI)
+ *    any stride / padding / dilation, pyramids included; Cin % 4 == 0, Cout % 4 == 0.
+ *  - data gradient of a stride-1 layer: fd_conv2d_nhwc_f32 itself on dy with the weights flipped and transposed
+ *    (w'[ci][co][r][q] = w[co][ci][KH-1-r][KW-1-q], pad' = dil*(K-1) - pad); needs Cout % 32 == 0.
+ */
+typedef struct fd_conv_wgrad_params {
+    const float* x;  /* forward input rows  */
+    const float* dy; /* gradient w.r.t. the forward output rows */
+    float* dw;       /* [Cout][KH][KW][Cin] */
+    int32_t x_cs, x_co, dy_cs, dy_co;
+    int32_t Cin, Cout, KH, KW, stride, pad, dil;
+    void* workspace; /* fd_conv_wgrad_workspace_bytes(out_rows, Cin, Cout, KH, KW) bytes, 16-B aligned */
+    int64_t workspace_bytes;
+    fd_segs in;      /* forward INPUT geometry */
+} fd_conv_wgrad_params;
+
+int64_t fd_conv_wgrad_workspace_bytes(int64_t out_rows, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
+int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_stream_t stream);
+
 /* [N][3][H][W] fp32 (NCHW, the reference's input layout, dataset/voc.py:141-173) -> [N][H][W][4] (c=3 zero) */
 int32_t fd_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, fd_stream_t stream);
 /* Input pipeline tail on the device: uint8 [N][H][W][3] images, already resized and zero padded on
@@ -158,6 +180,16 @@ int32_t fd_upsample2x_add_nhwc(const float* x, int32_t x_cs, int32_t x_co, const
 int32_t fd_dwconv3x3_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w, const float* scale,
                           const float* shift, float* y, int32_t y_cs, int32_t y_co, int32_t C, int32_t act,
                           const fd_segs* segs, fd_stream_t stream);
+
+/* Weight gradient of the depthwise 3x3 conv above (stride 1, pad 1): dw[t][c] = sum_m x[pix(m, t)][c] * dy[m][c],
+ * t = 3*r + q, same [9][C] layout as `w`.  Replaces the depthwise half of torch's convolution_backward in the
+ * reference's train step (train.py:175-181, modules.py:40-49).  The data gradient is fd_dwconv3x3_nhwc itself with the
+ * taps reversed (w'[t] = w[8-t]).  Deterministic: fixed row partition, fixed-order fp64 final sum.
+ * workspace: fd_dwconv3x3_wgrad_workspace_bytes(segs, C).  C/4 must divide 256 or be a multiple of 256. */
+int64_t fd_dwconv3x3_wgrad_workspace_bytes(const fd_segs* segs, int32_t C);
+int32_t fd_dwconv3x3_bwd_weight_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs,
+                                     int32_t dy_co, float* dw, int32_t C, const fd_segs* segs, void* workspace,
+                                     fd_stream_t stream);
 
 /* GroupNorm(G, C) + activation (nn.GroupNorm in HISFCOSHead / HeadFCOS, HISFcos.py:190-204, Fcos.py:102-109).
  * Two launches: partial moments (fp64 accumulation, fixed order) then normalise+affine+act.

@@ -56,6 +56,14 @@ class ConvParams(C.Structure):
                 ("seg_param", C.c_float * FD_MAX_SEG), ("segs", Segs)]
 
 
+class WgradParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p),
+                ("x_cs", C.c_int32), ("x_co", C.c_int32), ("dy_cs", C.c_int32), ("dy_co", C.c_int32),
+                ("Cin", C.c_int32), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
+                ("pad", C.c_int32), ("dil", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("segs", Segs)]
+
+
 _lib = None
 
 _P, _I, _F, _D, _L = C.c_void_p, C.c_int32, C.c_float, C.c_double, C.c_int64
@@ -64,6 +72,8 @@ _SIGS = {
     "fd_last_error": (C.c_char_p, []),
     "fd_conv2d_nhwc_f32": (_I, [C.POINTER(ConvParams), _P]),
     "fd_conv_workspace_bytes": (_L, [_L, _I, _I]),
+    "fd_conv_wgrad_workspace_bytes": (_L, [_L, _I, _I, _I, _I]),
+    "fd_conv2d_bwd_weight_f32": (_I, [C.POINTER(WgradParams), _P]),
     "fd_nchw3_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _P]),
     "fd_nhwc_to_nchw": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),
     "fd_preprocess_u8_nhwc4": (_I, [_P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
@@ -71,6 +81,8 @@ _SIGS = {
     "fd_maxpool_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fd_upsample2x_add_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fd_dwconv3x3_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(Segs), _P]),
+    "fd_dwconv3x3_wgrad_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
+    "fd_dwconv3x3_bwd_weight_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, C.POINTER(Segs), _P, _P]),
     "fd_groupnorm_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
     "fd_groupnorm_act_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _I, C.POINTER(Segs), _P, _P]),
     "fd_se_workspace_bytes": (_L, [_I, _I, _I]),

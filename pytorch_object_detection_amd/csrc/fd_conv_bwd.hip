@@ -1,0 +1,257 @@
+// fd_conv_bwd.hip — convolution weight gradient on v_mfma_f32_32x32x2_f32 (exact fp32), gfx950.
+//
+//   dW[co][r][q][ci] = sum_m dY[m][co] * X[pix(m, r, q)][ci]            (m = output pixel of the forward conv)
+//
+// i.e. a GEMM whose reduction runs over PIXELS: C[co][ci] (per filter tap) = dY^T * X_shifted.  Both operands are
+// NHWC rows, so a K-tile is simply 32 consecutive pixel rows of dY (128 output channels wide) and the 32 shifted
+// pixel rows of X (BN input channels wide); they are staged as [pixel][channel] in LDS and the MFMA operands are
+// single floats: lane (i = l&31, k = l>>5) reads LDS[pixel 2p + k][channel i] — 32 consecutive floats per half
+// wave, conflict-free.  The pixel range is split over `nsplit` workgroups per (co, tap, ci) tile; each writes its
+// partial tile to a slab and a second launch adds the slabs in order (deterministic).  The data gradient needs no
+// kernel of its own: for stride-1 layers it is the forward kernel run on dY with the flipped / transposed weights.
+// Replaces the weight-gradient half of torch's convolution_backward for the reference's train step (train.py:175-181).
+#include "fd_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+    const float* x; const float* dy; float* out;
+    int x_cs, x_co, dy_cs, dy_co;
+    int Cin, Cout, KW, stride, pad, dil, ntaps;
+    int M, Ktot;
+    int nseg;
+    int H[FD_MAX_SEG], W[FD_MAX_SEG], Ho[FD_MAX_SEG], Wo[FD_MAX_SEG];
+    int m_in[FD_MAX_SEG], m_out[FD_MAX_SEG + 1];
+    int co_tiles, ci_tiles;      // tiles of 128 output channels, tiles of BN input channels (per tap)
+    int rows_per_split;          // multiple of 32
+    long slab;                   // elements per split slab (= Cout * Ktot)
+    unsigned x_bytes, dy_bytes;
+    int is_gemm;
+};
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int BM = 128;                       // output channels per tile
+    constexpr int TN = BN / 64;                   // 32-wide ci sub-tiles per wave (wave tile 64 co x BN/2 ci)
+    constexpr int BTPR = BN / 4;                  // threads per B row (float4 each)
+    constexpr int BRPP = 256 / BTPR;              // B rows per pass
+    constexpr int BP = 32 / BRPP;                 // passes for the 32 pixel rows
+    __shared__ __attribute__((aligned(16))) float As[32 * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[32 * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int t = blockIdx.x;
+    const int cit = t % a.ci_tiles; t /= a.ci_tiles;
+    const int tap = t % a.ntaps;
+    const int cot = t / a.ntaps;
+    const int co0 = cot * BM, ci0 = cit * BN;
+    const int fr = tap / a.KW, fq = tap - fr * a.KW;
+    const int m_begin = blockIdx.y * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+
+    constexpr unsigned OOB = 0xC0000000u;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, (short)0, (int)a.dy_bytes, 0x00020000);
+
+    // A rows (dY): 32 threads per pixel row of 128 channels, 8 rows per pass, 4 passes
+    const int arow = tid >> 5, ac4 = tid & 31;
+    const bool a_col_ok = co0 + ac4 * 4 < a.Cout;
+    // B rows (X): BTPR threads per pixel row
+    const int brow = tid / BTPR, bc4 = tid % BTPR;
+    const bool b_col_ok = ci0 + bc4 * 4 < a.Cin;
+
+    float4 ra[4], rb[BP];
+    auto load_tile = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + arow + 8 * i;
+            const unsigned off = ((unsigned)m * (unsigned)a.dy_cs + (unsigned)(a.dy_co + co0 + ac4 * 4)) * 4u;
+            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(yrsrc, (int)((m < m_end && a_col_ok) ? off : OOB), 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const int m = m0 + brow + BRPP * i;
+            unsigned off = OOB;
+            if (m < m_end && b_col_ok) {
+                if (a.is_gemm) {
+                    off = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + bc4 * 4)) * 4u;
+                } else {
+                    int s = 0;
+#pragma unroll
+                    for (int k = 1; k < FD_MAX_SEG; ++k)
+                        if (k < a.nseg && m >= a.m_out[k]) s = k;
+                    const int Wo = a.Wo[s], hw = a.Ho[s] * Wo, H = a.H[s], W = a.W[s];
+                    const int local = m - a.m_out[s];
+                    const int n = local / hw;
+                    const int rem = local - n * hw;
+                    const int ho = rem / Wo, wo = rem - ho * Wo;
+                    const int hi = ho * a.stride - a.pad + fr * a.dil, wi = wo * a.stride - a.pad + fq * a.dil;
+                    if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                        off = ((unsigned)(a.m_in[s] + (n * H + hi) * W + wi) * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + bc4 * 4)) * 4u;
+                }
+            }
+            rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(As + (arow + 8 * i) * BM + ac4 * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BP; ++i) *reinterpret_cast<float4*>(Bs + (brow + BRPP * i) * BN + bc4 * 4) = rb[i];
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (m_begin < m_end) {
+        load_tile(m_begin);
+        for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+            __syncthreads();                 // previous tile fully consumed
+            store_tile();
+            __syncthreads();
+            if (m0 + 32 < m_end) load_tile(m0 + 32);
+            const float* Ab = As + wm * 64 + l31;
+            const float* Bb = Bs + wn * (BN / 2) + l31;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int k = 2 * p + lh;
+                float fa[2], fb[TN];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = Ab[k * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = Bb[k * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    // C[row = co][col = ci]: reg e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), col l&31 -> 128-byte runs along ci
+    float* out = a.out + (size_t)blockIdx.y * a.slab;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ci = ci0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wm * 64 + i * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+                if (co < a.Cout && ci < a.Cin) out[(size_t)co * a.Ktot + tap * a.Cin + ci] = acc[i][j][e];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4,
+                                                            int nsplit, long slab) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(ws)[i];
+        for (int s = 1; s < nsplit; ++s) {
+            const float4 u = reinterpret_cast<const float4*>(ws + s * slab)[i];
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        reinterpret_cast<float4*>(dw)[i] = v;
+    }
+}
+
+static int wgrad_splits(long M, int tiles) {
+    // Workgroups run 4 per CU (VGPR-bound), i.e. 1024 resident on 256 CUs.  Pick the split count whose total
+    // workgroup count fills whole rounds of 256 best (1026 workgroups would run as 1024 + 2: half the machine idle
+    // for the second half of the launch), preferring fewer splits; every split keeps >= 8 K-tiles of 32 pixels.
+    long maxs = M / 256;
+    if (maxs < 1) maxs = 1;
+    if (maxs > 256) maxs = 256;
+    int best = 1;
+    double best_score = -1.0;
+    for (long s = 1; s <= maxs; ++s) {
+        const long wg = (long)tiles * s;
+        if (wg > 1024 && s > 1) break;
+        const long rounds = (wg + 255) / 256;
+        const double fill = (double)wg / (double)(rounds * 256);          // CU balance
+        const double par = wg >= 1024 ? 1.0 : (wg >= 512 ? 0.97 : (wg >= 256 ? 0.90 : 0.90 * wg / 256.0));  // latency hiding
+        const double score = fill * par;
+        if (score > best_score + 1e-9) { best_score = score; best = (int)s; }
+    }
+    return best;
+}
+
+extern "C" int64_t fd_conv_wgrad_workspace_bytes(int64_t out_rows, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW) {
+    if (out_rows < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1) return -1;
+    const int bn = (Cin % 128 == 0) ? 128 : 64;
+    const int tiles = ((Cout + 127) / 128) * KH * KW * ((Cin + bn - 1) / bn);
+    return (int64_t)wgrad_splits(out_rows, tiles) * Cout * KH * KW * Cin * 4;
+}
+
+extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FD_REQUIRE(p && p->x && p->dy && p->dw && p->workspace, FD_E_INVAL, "fd_conv2d_bwd_weight: null pointer");
+    FD_REQUIRE(fd_segs_ok(&p->in), FD_E_INVAL, "fd_conv2d_bwd_weight: bad segment table");
+    FD_REQUIRE(p->Cin >= 4 && p->Cin % 4 == 0 && p->Cout >= 4 && p->Cout % 4 == 0, FD_E_UNSUPPORTED,
+               "fd_conv2d_bwd_weight: Cin=%d / Cout=%d must be multiples of 4", p->Cin, p->Cout);
+    FD_REQUIRE(p->x_cs % 4 == 0 && p->x_co % 4 == 0 && p->dy_cs % 4 == 0 && p->dy_co % 4 == 0, FD_E_INVAL,
+               "fd_conv2d_bwd_weight: channel views must be 4-aligned");
+    FD_REQUIRE((((uintptr_t)p->x | (uintptr_t)p->dy | (uintptr_t)p->dw | (uintptr_t)p->workspace) & 15) == 0, FD_E_INVAL,
+               "fd_conv2d_bwd_weight: pointers not 16-byte aligned");
+    FD_REQUIRE(p->KH >= 1 && p->KW >= 1 && p->stride >= 1 && p->dil >= 1 && p->pad >= 0, FD_E_INVAL, "fd_conv2d_bwd_weight: bad geometry");
+    WgradArgs a;
+    a.x = p->x; a.dy = p->dy;
+    a.x_cs = p->x_cs; a.x_co = p->x_co; a.dy_cs = p->dy_cs; a.dy_co = p->dy_co;
+    a.Cin = p->Cin; a.Cout = p->Cout; a.KW = p->KW; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;
+    a.ntaps = p->KH * p->KW;
+    a.Ktot = a.ntaps * p->Cin;
+    a.nseg = p->in.nseg;
+    long mo = 0;
+    for (int s = 0; s < FD_MAX_SEG; ++s) {
+        if (s < p->in.nseg) {
+            a.H[s] = p->in.H[s]; a.W[s] = p->in.W[s];
+            a.Ho[s] = (p->in.H[s] + 2 * p->pad - p->dil * (p->KH - 1) - 1) / p->stride + 1;
+            a.Wo[s] = (p->in.W[s] + 2 * p->pad - p->dil * (p->KW - 1) - 1) / p->stride + 1;
+            FD_REQUIRE(a.Ho[s] >= 1 && a.Wo[s] >= 1, FD_E_INVAL, "fd_conv2d_bwd_weight: empty output");
+            a.m_in[s] = p->in.m_start[s];
+            a.m_out[s] = (int)mo;
+            mo += (long)p->in.batch * a.Ho[s] * a.Wo[s];
+        } else { a.H[s] = a.W[s] = a.Ho[s] = a.Wo[s] = 1; a.m_in[s] = 0; a.m_out[s] = (int)mo; }
+    }
+    a.m_out[FD_MAX_SEG] = (int)mo;
+    FD_REQUIRE(mo > 0 && mo < (1L << 31), FD_E_INVAL, "fd_conv2d_bwd_weight: row count out of range");
+    a.M = (int)mo;
+    const long xb = (long)p->in.m_start[p->in.nseg] * p->x_cs * 4, yb = mo * p->dy_cs * 4;
+    FD_REQUIRE(xb < 0xC0000000L && yb < 0xC0000000L, FD_E_UNSUPPORTED, "fd_conv2d_bwd_weight: buffer exceeds 3 GiB");
+    a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+    a.is_gemm = (p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0) ? 1 : 0;
+    const int bn = (p->Cin % 128 == 0) ? 128 : 64;
+    a.co_tiles = (p->Cout + 127) / 128;
+    a.ci_tiles = (p->Cin + bn - 1) / bn;
+    const int tiles = a.co_tiles * a.ntaps * a.ci_tiles;
+    const int nsplit = wgrad_splits(mo, tiles);
+    a.rows_per_split = (int)(((mo + nsplit - 1) / nsplit + 31) / 32 * 32);
+    a.slab = (long)p->Cout * a.Ktot;
+    FD_REQUIRE(p->workspace_bytes >= (int64_t)nsplit * a.slab * 4, FD_E_INVAL,
+               "fd_conv2d_bwd_weight: workspace too small (need fd_conv_wgrad_workspace_bytes())");
+    a.out = (nsplit == 1) ? p->dw : (float*)p->workspace;
+    const dim3 grid(tiles, (unsigned)((mo + a.rows_per_split - 1) / a.rows_per_split));
+    if (bn == 128) hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, stream, a);
+    FD_CHECK_LAUNCH("fd_conv2d_bwd_weight");
+    if (nsplit > 1) {
+        const long n4 = a.slab / 4;
+        long g = (n4 + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)p->workspace, p->dw, n4,
+                           (int)grid.y, a.slab);
+        FD_CHECK_LAUNCH("fd_conv2d_bwd_weight (reduce)");
+    }
+    return FD_OK;
+}

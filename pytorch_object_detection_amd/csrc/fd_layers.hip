@@ -252,6 +252,105 @@ extern "C" int32_t fd_dwconv3x3_nhwc(const float* x, int32_t x_cs, int32_t x_co,
     return FD_OK;
 }
 
+// ---- depthwise 3x3 weight gradient: dw[t][c] = sum_m x[pix(m, t)][c] * dy[m][c]  (HBM-bound; x and dy read once)
+// pass 1: one workgroup per row chunk; a thread owns one channel quad and every R-th row of the chunk, keeps the
+//         9 tap sums in registers, lanes are combined through LDS in lane order -> partial[chunk][9][C]
+// pass 2: fixed-order fp64 sum of the chunk partials -> dw[9][C]
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_partial_kernel(const float* __restrict__ x, int x_cs, int x_co,
+                                                                       const float* __restrict__ dy, int dy_cs, int dy_co,
+                                                                       int C, int QW, long chunk_rows, SegTab tab,
+                                                                       float* __restrict__ part) {
+    __shared__ float4 red[256];
+    const int tid = threadIdx.x;
+    const int R = 256 / QW;                                  // row lanes
+    const int ql = tid % QW, rl = tid / QW;
+    const int q = blockIdx.y * QW + ql;                      // channel quad
+    const long rows = tab.s.m_start[tab.s.nseg];
+    const long m0 = (long)blockIdx.x * chunk_rows;
+    const long m1 = min(rows, m0 + chunk_rows);
+    float4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long m = m0 + rl; m < m1; m += R) {
+        int H, W, h, w;
+        long r0;
+        seg_decode(tab.s, m, H, W, r0, h, w);
+        const float4 g = *reinterpret_cast<const float4*>(dy + m * dy_cs + dy_co + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = h + r - 1;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int wi = w + c - 1;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 u = *reinterpret_cast<const float4*>(x + (r0 + hi * W + wi) * x_cs + x_co + 4 * q);
+                float4& a = acc[r * 3 + c];
+                a.x = fmaf(u.x, g.x, a.x); a.y = fmaf(u.y, g.y, a.y);
+                a.z = fmaf(u.z, g.z, a.z); a.w = fmaf(u.w, g.w, a.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        red[tid] = acc[t];
+        __syncthreads();
+        if (rl == 0) {
+            float4 v = red[ql];
+            for (int j = 1; j < R; ++j) {
+                const float4 u = red[j * QW + ql];
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            *reinterpret_cast<float4*>(part + ((long)blockIdx.x * 9 + t) * C + 4 * q) = v;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_final_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                     int n, int nchunk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += (double)part[(long)k * n + i];
+    dw[i] = (float)s;
+}
+
+static inline int dw_wgrad_chunks(long rows) {
+    long n = (rows + 63) / 64;
+    if (n > 1024) n = 1024;
+    if (n < 1) n = 1;
+    return (int)n;
+}
+
+extern "C" int64_t fd_dwconv3x3_wgrad_workspace_bytes(const fd_segs* segs, int32_t C) {
+    if (!fd_segs_ok(segs) || C < 4) return -1;
+    return (int64_t)dw_wgrad_chunks(segs->m_start[segs->nseg]) * 9 * C * 4;
+}
+
+extern "C" int32_t fd_dwconv3x3_bwd_weight_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs,
+                                                int32_t dy_co, float* dw, int32_t C, const fd_segs* segs, void* workspace,
+                                                fd_stream_t stream) {
+    FD_REQUIRE(fd_segs_ok(segs), FD_E_INVAL, "fd_dwconv3x3_bwd_weight: bad segment table");
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(dy, dy_cs, dy_co, C) && dw && workspace && ((uintptr_t)workspace & 15) == 0,
+               FD_E_INVAL, "fd_dwconv3x3_bwd_weight: channel views must be 4-aligned (C=%d)", C);
+    const int C4 = C / 4;
+    const int QW = C4 < 256 ? C4 : 256;
+    FD_REQUIRE((C4 < 256 && 256 % C4 == 0) || C4 % 256 == 0, FD_E_UNSUPPORTED,
+               "fd_dwconv3x3_bwd_weight: C/4 = %d must divide 256 or be a multiple of it", C4);
+    const long rows = segs->m_start[segs->nseg];
+    const int nchunk = dw_wgrad_chunks(rows);
+    const long chunk_rows = (rows + nchunk - 1) / nchunk;
+    SegTab tab; tab.s = *segs;
+    hipLaunchKernelGGL(dwconv3x3_wgrad_partial_kernel, dim3(nchunk, C4 / QW), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co,
+                       dy, dy_cs, dy_co, C, QW, chunk_rows, tab, (float*)workspace);
+    FD_CHECK_LAUNCH("fd_dwconv3x3_bwd_weight_nhwc (partial)");
+    hipLaunchKernelGGL(dwconv3x3_wgrad_final_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, dw, 9 * C, nchunk);
+    FD_CHECK_LAUNCH("fd_dwconv3x3_bwd_weight_nhwc (final)");
+    return FD_OK;
+}
+
 // ------------------------------------------------------------------------------ GroupNorm + activation
 // pass 1: per (level, image, row-chunk) partial (sum, sumsq) per group, fp64, fixed order
 // pass 2: per (level, image) finalise mean / rstd from the partials, normalise + affine + act

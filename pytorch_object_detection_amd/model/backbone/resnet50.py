@@ -56,17 +56,24 @@ def _no_torch_forward(self, *a, **k):
 
 
 def trunk_train_forward(trunk: nn.Module, x: torch.Tensor):
-    """Autograd-capable trunk forward on stock PyTorch-ROCm ops (training only; inference runs the HIP plan).
-    Returns (C3, C4, C5)."""
+    """Autograd-capable trunk forward (training only; inference runs the HIP plan).  Every bottleneck conv is one fused
+    HIP launch (conv + frozen BN + residual + ReLU, train_ops.conv_bn_act) differentiated by the HIP data- / weight-
+    gradient kernels; a frozen stem (freeze_stages(1)) runs on the inference kernels.  Returns (C3, C4, C5)."""
     import torch.nn.functional as F
-    x = F.max_pool2d(F.relu(trunk.bn1(trunk.conv1(x))), 3, 2, 1)
+
+    from ...ops import ACT_NONE, ACT_RELU
+    from ...train_ops import conv_bn_act, stem_frozen, stem_is_frozen
+    if stem_is_frozen(trunk, x):
+        x = stem_frozen(trunk, x)
+    else:                                                     # trainable 7x7 stem (Cin = 3): stock ops
+        x = F.max_pool2d(F.relu(trunk.bn1(trunk.conv1(x))), 3, 2, 1)
     feats = []
     for li in (1, 2, 3, 4):
         for blk in getattr(trunk, f"layer{li}"):
-            idt = x if blk.downsample is None else blk.downsample(x)
-            y = F.relu(blk.bn1(blk.conv1(x)))
-            y = F.relu(blk.bn2(blk.conv2(y)))
-            x = F.relu(blk.bn3(blk.conv3(y)) + idt)
+            idt = x if blk.downsample is None else conv_bn_act(blk.downsample[0], blk.downsample[1], x, ACT_NONE)
+            y = conv_bn_act(blk.conv1, blk.bn1, x, ACT_RELU)
+            y = conv_bn_act(blk.conv2, blk.bn2, y, ACT_RELU)
+            x = conv_bn_act(blk.conv3, blk.bn3, y, ACT_RELU, residual=idt)
         feats.append(x)
     return feats[1], feats[2], feats[3]
 

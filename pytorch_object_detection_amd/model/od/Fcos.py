@@ -12,6 +12,8 @@ from ... import engine
 from ..._lib import FdError, Segs
 import torch.nn.functional as F
 
+from ...ops import ACT_RELU
+from ...train_ops import conv2d as tconv, conv_bn_act as cba
 from ..backbone.resnet50 import ResNet50, trunk_train_forward
 from ..modules.modules import ScaleExp, init_conv_kaiming, init_conv_random_normal
 from ._planned import PlannedModule, copy_in_nchw, pyramid_out
@@ -33,12 +35,12 @@ class FeaturePyramidNetwork(PlannedModule):
     def train_forward(self, x):
         c3, c4, c5 = x
         up = lambda t: F.interpolate(t, scale_factor=2.0, mode="nearest")  # noqa: E731
-        p5 = self.P5(c5)
-        p4 = self.P4_c1(up(p5) + self.P4(c4))
-        p3 = self.P3_c1(up(p4) + self.P3(c3))
-        p5 = self.P5_c1(p5)
-        p6 = F.relu(self.P6_c1(p5))          # the reference's in-place ReLU rectifies the returned P6 (Fcos.py:90)
-        return p3, p4, p5, p6, self.P7_c1(p6)
+        p5 = tconv(self.P5, c5)
+        p4 = tconv(self.P4_c1, up(p5) + tconv(self.P4, c4))
+        p3 = tconv(self.P3_c1, up(p4) + tconv(self.P3, c3))
+        p5 = tconv(self.P5_c1, p5)
+        p6 = cba(self.P6_c1, None, p5, ACT_RELU)   # the reference's in-place ReLU rectifies the returned P6 (Fcos.py:90)
+        return p3, p4, p5, p6, tconv(self.P7_c1, p6)
 
     def forward(self, x):
         if self.training:
@@ -82,10 +84,13 @@ class HeadFCOS(PlannedModule):
     def train_forward(self, inputs):
         cls_l, cnt_l, reg_l = [], [], []
         for i, f in enumerate(inputs):
-            c, r = self.cls_branch(f), self.reg_branch(f)
-            cls_l.append(self.cls_logits(c))
-            cnt_l.append(self.cnt_logits(r))
-            reg_l.append(torch.exp(self.reg_pred(r) * self.scale_exp[i].scale))
+            c, r = f, f
+            for k in range(4):                               # 3x3 conv (HIP) -> GroupNorm -> ReLU, four times per branch
+                c = self.cls_branch[3 * k + 2](self.cls_branch[3 * k + 1](tconv(self.cls_branch[3 * k], c)))
+                r = self.reg_branch[3 * k + 2](self.reg_branch[3 * k + 1](tconv(self.reg_branch[3 * k], r)))
+            cls_l.append(tconv(self.cls_logits, c))
+            cnt_l.append(self.cnt_logits(r))                 # Cout = 1: stock op
+            reg_l.append(torch.exp(tconv(self.reg_pred, r) * self.scale_exp[i].scale))
         return cls_l, cnt_l, reg_l
 
     def forward(self, inputs):

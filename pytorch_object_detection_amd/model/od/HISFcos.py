@@ -14,6 +14,8 @@ from ..._lib import FdError, Segs
 from ...ops import Rows
 import torch.nn.functional as F
 
+from ...ops import ACT_NONE, ACT_RELU
+from ...train_ops import conv2d as tconv, conv_bn_act as cba
 from ..backbone.resnet50 import ResNet50v2, trunk_train_forward
 from ..modules.modules import DepthWiseConv2d, PointWiseConv, ScaleExp, SEBlock
 from ._planned import PlannedModule, copy_in_nchw, pyramid_out
@@ -33,13 +35,13 @@ class HisBlock(nn.Module):
         self.bn4 = nn.BatchNorm2d(feature)
 
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
-        """Training-time forward on stock PyTorch-ROCm ops (autograd); inference runs engine._his_block."""
-        x1 = F.silu(self.bn1(self.conv1(x)))
+        """Training-time autograd forward (dense convs on the HIP kernels via train_ops); inference runs engine._his_block."""
+        x1 = F.silu(cba(self.conv1, self.bn1, x))              # conv + frozen BN fused; SiLU stock (needs pre-activation)
         se = self.conv1_2.excitation
         gate = se(x1.mean((2, 3), keepdim=True))
-        left = torch.cat((F.relu(self.bn2(self.conv1_1(x1))), x1 * gate), 1)
-        mid = torch.cat((F.relu(self.bn3(self.conv3(left))), self.conv2(x)), 1)
-        return F.silu(self.bn4(self.conv4(mid)))
+        left = torch.cat((cba(self.conv1_1, self.bn2, x1, ACT_RELU), x1 * gate), 1)
+        mid = torch.cat((cba(self.conv3, self.bn3, left, ACT_RELU), tconv(self.conv2, x)), 1)
+        return F.silu(cba(self.conv4, self.bn4, mid))
 
 
 class HalfInvertedStageFPN(PlannedModule):
@@ -57,12 +59,12 @@ class HalfInvertedStageFPN(PlannedModule):
         c3, c4, c5 = x
         up = lambda t: F.interpolate(t, scale_factor=2.0, mode="nearest")  # noqa: E731
         down = lambda t: F.max_pool2d(t, 2, 2)  # noqa: E731
-        a = F.relu(self.gn1(self.tf1(c5)))
+        a = cba(self.tf1, self.gn1, c5, ACT_RELU)
         x4 = down(a)
         x5 = down(x4)
         t3 = self.HisBlock1.train_forward(a)
-        t4 = self.HisBlock2.train_forward(up(t3) + F.relu(self.gn2(self.tf2(c4))))
-        p3 = self.HisBlock3.train_forward(up(t4) + F.relu(self.gn2(self.tf3(c3))))   # gn2 twice, as the reference
+        t4 = self.HisBlock2.train_forward(up(t3) + cba(self.tf2, self.gn2, c4, ACT_RELU))
+        p3 = self.HisBlock3.train_forward(up(t4) + cba(self.tf3, self.gn2, c3, ACT_RELU))   # gn2 twice, as the reference
         p4 = self.HisBlock4.train_forward(down(p3) + t4)
         p5 = self.HisBlock5.train_forward(down(p4) + t3)
         p6 = self.HisBlock6.train_forward(down(p5) + x4)
@@ -113,12 +115,13 @@ class HISFCOSHead(PlannedModule):
     def train_forward(self, inputs):
         cls_l, cnt_l, reg_l = [], [], []
         for i, f in enumerate(inputs):
-            h = F.silu(self.gn2(self.dw1(F.relu(self.gn1(self.pw1(f))))))
-            z = self.pw2(h) + f
-            c, r = self.cls_conv(z), self.reg_conv(z)
-            cls_l.append(self.cls_logits(c))
-            cnt_l.append(self.cnt_logits(r))
-            reg_l.append(torch.exp(self.reg_pred(r) * self.scale_exp[i].scale))
+            h = F.silu(self.gn2(tconv(self.dw1, F.relu(self.gn1(tconv(self.pw1, f))))))
+            z = cba(self.pw2, None, h, ACT_NONE, residual=f)
+            c = self.cls_conv[2](self.cls_conv[1](tconv(self.cls_conv[0], z)))
+            r = self.reg_conv[2](self.reg_conv[1](tconv(self.reg_conv[0], z)))
+            cls_l.append(tconv(self.cls_logits, c))
+            cnt_l.append(self.cnt_logits(r))                 # Cout = 1: stock op
+            reg_l.append(torch.exp(tconv(self.reg_pred, r) * self.scale_exp[i].scale))
         return cls_l, cnt_l, reg_l
 
     def forward(self, inputs):

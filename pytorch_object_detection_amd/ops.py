@@ -244,6 +244,29 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
     return apply(best)
 
 
+def conv_wgrad(x: Rows, dy: Rows, segs_in: Segs, *, Cin: int, Cout: int, k: int, stride: int = 1, pad: int = 0,
+               dil: int = 1) -> torch.Tensor:
+    """Weight gradient [Cout, k, k, Cin] (OHWI) of conv(x) w.r.t. its weights given dy (rows in output geometry)."""
+    out_rows = conv_out_segs(segs_in, k, stride, pad, dil).rows
+    dev = x.buf.device
+    dw = torch.empty(Cout, k, k, Cin, dtype=torch.float32, device=dev)
+    nb = _lib.lib().fd_conv_wgrad_workspace_bytes(out_rows, Cin, Cout, k, k)
+    ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=dev)
+    p = _lib.WgradParams()
+    p.x, p.dy, p.dw = x.ptr, dy.ptr, dw.data_ptr()
+    p.x_cs, p.x_co, p.dy_cs, p.dy_co = x.cs, x.co, dy.cs, dy.co
+    p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, k, stride, pad, dil
+    p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    p.segs = segs_in
+    check(_lib.lib().fd_conv2d_bwd_weight_f32(C.byref(p), _stream()), "fd_conv2d_bwd_weight_f32")
+    return dw
+
+
+def dgrad_weight(w: torch.Tensor) -> torch.Tensor:
+    """Packed weights of the stride-1 data-gradient conv: w'[ci][co][r][q] = w[co][ci][K-1-r][K-1-q]."""
+    return pack_conv_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous())
+
+
 def conv_out_segs(segs: Segs, k: int, stride: int, pad: int, dil: int) -> Segs:
     hw = [((h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1)
           for h, w in segs.level_hw()]
@@ -296,6 +319,19 @@ def dwconv3x3(x: Rows, w9c: torch.Tensor, y: Rows, segs: Segs, scale=None, shift
                                        scale.data_ptr() if scale is not None else None,
                                        shift.data_ptr() if shift is not None else None, y.ptr, y.cs, y.co, x.C, act,
                                        C.byref(segs), _stream()), "fd_dwconv3x3_nhwc")
+
+
+def dwconv3x3_wgrad(x: Rows, dy: Rows, segs: Segs) -> torch.Tensor:
+    """Weight gradient [9][C] of the depthwise 3x3 conv (stride 1, pad 1) given dy."""
+    dev = x.buf.device
+    nb = _lib.lib().fd_dwconv3x3_wgrad_workspace_bytes(C.byref(segs), x.C)
+    if nb < 0:
+        raise FdError("fd_dwconv3x3_wgrad_workspace_bytes: bad arguments")
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+    dw = torch.empty(9, x.C, dtype=torch.float32, device=dev)
+    check(_lib.lib().fd_dwconv3x3_bwd_weight_nhwc(x.ptr, x.cs, x.co, dy.ptr, dy.cs, dy.co, dw.data_ptr(), x.C,
+                                                  C.byref(segs), ws.data_ptr(), _stream()), "fd_dwconv3x3_bwd_weight_nhwc")
+    return dw
 
 
 def groupnorm_workspace(segs: Segs, G: int, device) -> torch.Tensor:

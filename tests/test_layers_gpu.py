@@ -1,5 +1,7 @@
 """GPU parity of the layer kernels (C-ABI) against torch fp32 CPU references of the same op.
 Tolerance for conv / norm outputs: 1e-4 absolute + 1e-5 relative (north_star: 'conv ... within 1e-4 fp32')."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -251,3 +253,139 @@ def test_preprocess_u8_and_box_rescale_bit_exact():
     boxes = rng.uniform(0, 600, (3, 40, 4)).astype(np.float32)
     out = ops.boxes_rescale_xywh_(torch.from_numpy(boxes).to(DEV), 1.7)
     np.testing.assert_array_equal(out.cpu().numpy(), R.boxes_rescale_xywh(boxes, 1.7))
+
+
+WGRAD_CASES = [
+    # Cin, Cout, k, stride, pad, dil, H, W
+    (64, 64, 1, 1, 0, 1, 12, 20),
+    (128, 256, 3, 1, 1, 1, 10, 14),
+    (256, 256, 3, 1, 2, 2, 9, 9),
+    (64, 128, 3, 2, 1, 1, 13, 21),
+    (256, 128, 1, 2, 0, 1, 10, 10),
+    (256, 80, 3, 1, 1, 1, 6, 6),
+    (512, 256, 1, 1, 0, 1, 5, 5),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_backward_weight_and_data(case):
+    """Weight gradient kernel (any stride) and data gradient through the forward kernel (stride 1) vs torch autograd."""
+    Cin, Cout, k, stride, pad, dil, H, W = case
+    gen = torch.Generator().manual_seed(sum(case))
+    B = 3
+    x = torch.randn(B, Cin, H, W, generator=gen, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * k * k)).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, pad, dil)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    Ho, Wo = y.shape[2:]
+    segs = Segs.make(B, [(H, W)])
+    dw = ops.conv_wgrad(to_rows(x.detach()), to_rows(dy), segs, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil)
+    ref_dw = w.grad.permute(0, 2, 3, 1)
+    scale = float(ref_dw.abs().max())
+    np.testing.assert_allclose(dw.cpu().numpy() / scale, ref_dw.numpy() / scale, atol=2e-5)
+    if stride == 1 and Cout % 32 == 0:
+        dx = ops.new_rows(B * H * W, Cin, DEV)
+        ops.conv_call(to_rows(dy), Segs.make(B, [(Ho, Wo)]), ops.dgrad_weight(w.to(DEV)), dx, Cin=Cout, Cout=Cin, k=k,
+                      stride=1, pad=dil * (k - 1) - pad, dil=dil)()
+        scale = float(x.grad.abs().max())
+        np.testing.assert_allclose(from_rows(dx, B, H, W).numpy() / scale, x.grad.numpy() / scale, atol=2e-5)
+
+
+def test_conv_backward_weight_pyramid():
+    gen = torch.Generator().manual_seed(77)
+    B, Cin, Cout = 2, 256, 128
+    hw = [(12, 20), (6, 10), (3, 5), (1, 1)]
+    segs = Segs.make(B, hw)
+    xs = [torch.randn(B, Cin, h, w, generator=gen) for h, w in hw]
+    wt = (torch.randn(Cout, Cin, 3, 3, generator=gen) / 48).requires_grad_(True)
+    dys = [torch.randn(B, Cout, h, w, generator=gen) for h, w in hw]
+    sum((F.conv2d(x, wt, None, 1, 1) * dy).sum() for x, dy in zip(xs, dys)).backward()
+    xb = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cin) for t in xs]).contiguous().to(DEV)
+    db = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cout) for t in dys]).contiguous().to(DEV)
+    dw = ops.conv_wgrad(ops.Rows(xb), ops.Rows(db), segs, Cin=Cin, Cout=Cout, k=3, pad=1)
+    ref = wt.grad.permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(dw.cpu().numpy() / scale, ref.numpy() / scale, atol=2e-5)
+
+
+@pytest.mark.parametrize("C", [128, 512, 1024])
+def test_dwconv3x3_backward_weight_pyramid(C):
+    """Depthwise 3x3 weight gradient over a pyramid vs torch autograd (CPU fp32 reference)."""
+    gen = torch.Generator().manual_seed(C)
+    B = 2
+    hw = [(9, 14), (5, 7), (2, 3), (1, 1)]
+    segs = Segs.make(B, hw)
+    xs = [torch.randn(B, C, h, w, generator=gen) for h, w in hw]
+    wt = torch.randn(C, 1, 3, 3, generator=gen).requires_grad_(True)
+    dys = [torch.randn(B, C, h, w, generator=gen) for h, w in hw]
+    sum((F.conv2d(x, wt, None, 1, 1, 1, C) * dy).sum() for x, dy in zip(xs, dys)).backward()
+    xb = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, C) for t in xs]).contiguous().to(DEV)
+    db = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, C) for t in dys]).contiguous().to(DEV)
+    dw = ops.dwconv3x3_wgrad(ops.Rows(xb), ops.Rows(db), segs)            # [9][C]
+    ref = wt.grad.reshape(C, 9).t()
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(dw.cpu().numpy() / scale, ref.numpy() / scale, atol=2e-5)
+
+
+def _frozen_bn(C, gen):
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=gen) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=gen) * 0.2)
+        bn.running_mean.copy_(torch.randn(C, generator=gen) * 0.3)
+        bn.running_var.copy_(torch.rand(C, generator=gen) + 0.5)
+    bn.eval()
+    for p in bn.parameters():
+        p.requires_grad = False
+    return bn
+
+
+@pytest.mark.parametrize("case", [
+    # Cin, Cout, k, stride, dil, bias, groups, act, residual
+    (64, 96, 3, 1, 1, False, 1, "relu", True),
+    (64, 64, 1, 1, 1, True, 1, "relu", False),
+    (128, 64, 3, 2, 1, False, 1, "relu", False),     # strided: stock data gradient, HIP weight gradient
+    (64, 64, 3, 1, 2, False, 1, "none", True),
+    (128, 128, 3, 1, 1, False, 128, "relu", False),  # depthwise
+    (128, 128, 3, 1, 1, False, 128, "none", False),
+])
+def test_fused_conv_bn_act_autograd(case):
+    """train_ops.conv_bn_act (one fused HIP launch + HIP backward kernels) vs the stock module chain on the CPU."""
+    from pytorch_object_detection_amd import train_ops
+    Cin, Cout, k, stride, dil, bias, groups, act, use_res = case
+    gen = torch.Generator().manual_seed(sum(c if isinstance(c, int) else 0 for c in case))
+    B, H, W = 2, 12, 10
+    conv = torch.nn.Conv2d(Cin, Cout, k, stride, dil * (k - 1) // 2, dil, groups, bias)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) / np.sqrt(Cin // groups * k * k))
+    bn = _frozen_bn(Cout, gen)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    Ho = (H + 2 * (dil * (k - 1) // 2) - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * (dil * (k - 1) // 2) - dil * (k - 1) - 1) // stride + 1
+    res = torch.randn(B, Cout, Ho, Wo, generator=gen) if use_res else None
+    dy = torch.randn(B, Cout, Ho, Wo, generator=gen)
+
+    def run(dev, fused):
+        c, b = copy.deepcopy(conv).to(dev), copy.deepcopy(bn).to(dev)
+        xx = x.detach().clone().to(dev).requires_grad_(True)
+        rr = res.detach().clone().to(dev).requires_grad_(True) if use_res else None
+        if fused:
+            y = train_ops.conv_bn_act(c, b, xx, ops.ACT_RELU if act == "relu" else ops.ACT_NONE, rr)
+        else:
+            y = b(c(xx))
+            if rr is not None:
+                y = y + rr
+            y = F.relu(y) if act == "relu" else y
+        y.backward(dy.to(dev))
+        grads = [xx.grad, c.weight.grad] + ([c.bias.grad] if bias else []) + ([rr.grad] if use_res else [])
+        return y.detach().cpu(), [g.cpu() for g in grads], y
+
+    y_ref, g_ref, _ = run("cpu", False)
+    y_hip, g_hip, y_node = run(DEV, True)
+    assert "Hip" in type(y_node.grad_fn).__name__, type(y_node.grad_fn).__name__
+    np.testing.assert_allclose(y_hip.numpy(), y_ref.numpy(), atol=2e-5, rtol=1e-5)
+    for a, b_ in zip(g_hip, g_ref):
+        scale = float(b_.abs().max())
+        np.testing.assert_allclose(a.numpy() / scale, b_.numpy() / scale, atol=3e-5)
+    assert train_ops.STATS["cl_copies"] >= 0

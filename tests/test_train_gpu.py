@@ -1,5 +1,6 @@
-"""Cfg4 plumbing: one training step on the GPU — autograd forward of the conv stack (stock PyTorch-ROCm ops),
-FCOSGenTargets + FCOSLoss('giou') as HIP kernels, backward, SGD — against the CPU oracle's autograd."""
+"""Cfg4: one training step on the GPU — autograd forward whose dense convolutions run on the HIP conv kernel (forward,
+data gradient, weight gradient; train_ops.py), FCOSGenTargets + FCOSLoss('giou') as HIP kernels, backward, SGD —
+against the CPU oracle's autograd."""
 import numpy as np
 import pytest
 import torch
@@ -41,6 +42,16 @@ def test_train_step_matches_oracle_autograd():
     opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-2, momentum=0.9, weight_decay=1e-4)
     opt.zero_grad()
     out = model(x.to(DEV))
+    # the training graph runs its dense convolutions on the HIP kernels (forward + both backward passes)
+    seen, stack, hip = set(), [out[0][0].grad_fn], 0
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        hip += type(fn).__name__ == "_HipConv2dBackward"
+        stack.extend(f for f, _ in fn.next_functions)
+    assert hip >= 60, hip
     target = FCOSGenTargets(strides, ranges)([out, gt.to(DEV), labels.to(DEV)])
     for a, b in zip(target, tg):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-6)
@@ -70,6 +81,21 @@ def test_train_step_matches_oracle_autograd():
     model.eval()
     cls_hip = model(x.to(DEV))[0][0]
     assert torch.isfinite(cls_hip).all()
+
+
+def test_fcos_baseline_train_step_runs():
+    from pytorch_object_detection_amd.model.od import FCOS
+    torch.manual_seed(3)
+    model = FCOS([2048, 1024, 512], 20, 256).to(DEV).train()
+    out = model(torch.randn(1, 3, 128, 128, device=DEV))
+    gt = torch.tensor([[[10., 12., 60., 70.]]], device=DEV)
+    labels = torch.tensor([[3]], device=DEV)
+    ranges = [[-1, 64], [64, 128], [128, 256], [256, 512], [512, 9999999]]
+    target = FCOSGenTargets([8, 16, 32, 64, 128], ranges)([out, gt, labels])
+    loss = FCOSLoss("iou")([out, target])[-1]
+    loss.backward()
+    g = model.head.cls_branch[0].weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
 
 
 def test_builder_train_objects():
