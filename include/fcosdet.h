@@ -140,6 +140,8 @@ typedef struct fd_conv_wgrad_params {
     int32_t Cin, Cout, KH, KW, stride, pad, dil;
     void* workspace; /* fd_conv_wgrad_workspace_bytes(out_rows, Cin, Cout, KH, KW) bytes, 16-B aligned */
     int64_t workspace_bytes;
+    int32_t nsplit;  /* 0 = library chooses; else the pixel-range split count (workspace >= nsplit * |dw| * 4 bytes) */
+    int32_t reserved;
     fd_segs in;      /* forward INPUT geometry */
 } fd_conv_wgrad_params;
 

@@ -61,7 +61,8 @@ class WgradParams(C.Structure):
                 ("x_cs", C.c_int32), ("x_co", C.c_int32), ("dy_cs", C.c_int32), ("dy_co", C.c_int32),
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("dil", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("segs", Segs)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("nsplit", C.c_int32), ("reserved", C.c_int32),
+                ("segs", Segs)]
 
 
 _lib = None

@@ -10,6 +10,8 @@
 // partial tile to a slab and a second launch adds the slabs in order (deterministic).  The data gradient needs no
 // kernel of its own: for stride-1 layers it is the forward kernel run on dY with the flipped / transposed weights.
 // Replaces the weight-gradient half of torch's convolution_backward for the reference's train step (train.py:175-181).
+#include <algorithm>
+
 #include "fd_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -22,6 +24,8 @@ struct WgradArgs {
     int nseg;
     int H[FD_MAX_SEG], W[FD_MAX_SEG], Ho[FD_MAX_SEG], Wo[FD_MAX_SEG];
     int m_in[FD_MAX_SEG], m_out[FD_MAX_SEG + 1];
+    unsigned mg_hw[FD_MAX_SEG], mg_w[FD_MAX_SEG];   // division by Ho*Wo / Wo as mulhi + shift (0 = divisor 1)
+    int sh_hw[FD_MAX_SEG], sh_w[FD_MAX_SEG];
     int co_tiles, ci_tiles;      // tiles of 128 output channels, tiles of BN input channels (per tap)
     int rows_per_split;          // multiple of 32
     long slab;                   // elements per split slab (= Cout * Ktot)
@@ -29,7 +33,12 @@ struct WgradArgs {
     int is_gemm;
 };
 
-template <int BN>
+// floor(n / d) for 0 <= n < 2^31 with (m, sh) from magic_div(): m = ceil(2^(31+l) / d), l = ceil(log2 d), sh = l - 1
+__device__ __forceinline__ int fast_div(int n, unsigned m, int sh) {
+    return m ? (int)(__umulhi((unsigned)n, m) >> sh) : n;
+}
+
+template <int BN, bool ONESEG>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int BM = 128;                       // output channels per tile
     constexpr int TN = BN / 64;                   // 32-wide ci sub-tiles per wave (wave tile 64 co x BN/2 ci)
@@ -79,18 +88,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 if (a.is_gemm) {
                     off = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + bc4 * 4)) * 4u;
                 } else {
-                    int s = 0;
+                    int Wo, hw, H, W, local, m_in;
+                    unsigned mgh, mgw;
+                    int shh, shw;
+                    if (ONESEG) {
+                        Wo = a.Wo[0]; hw = a.Ho[0] * Wo; H = a.H[0]; W = a.W[0]; local = m; m_in = a.m_in[0];
+                        mgh = a.mg_hw[0]; shh = a.sh_hw[0]; mgw = a.mg_w[0]; shw = a.sh_w[0];
+                    } else {
+                        int s = 0;
 #pragma unroll
-                    for (int k = 1; k < FD_MAX_SEG; ++k)
-                        if (k < a.nseg && m >= a.m_out[k]) s = k;
-                    const int Wo = a.Wo[s], hw = a.Ho[s] * Wo, H = a.H[s], W = a.W[s];
-                    const int local = m - a.m_out[s];
-                    const int n = local / hw;
+                        for (int k = 1; k < FD_MAX_SEG; ++k)
+                            if (k < a.nseg && m >= a.m_out[k]) s = k;
+                        Wo = a.Wo[s]; hw = a.Ho[s] * Wo; H = a.H[s]; W = a.W[s]; local = m - a.m_out[s]; m_in = a.m_in[s];
+                        mgh = a.mg_hw[s]; shh = a.sh_hw[s]; mgw = a.mg_w[s]; shw = a.sh_w[s];
+                    }
+                    const int n = fast_div(local, mgh, shh);
                     const int rem = local - n * hw;
-                    const int ho = rem / Wo, wo = rem - ho * Wo;
+                    const int ho = fast_div(rem, mgw, shw), wo = rem - ho * Wo;
                     const int hi = ho * a.stride - a.pad + fr * a.dil, wi = wo * a.stride - a.pad + fq * a.dil;
                     if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
-                        off = ((unsigned)(a.m_in[s] + (n * H + hi) * W + wi) * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + bc4 * 4)) * 4u;
+                        off = ((unsigned)(m_in + (n * H + hi) * W + wi) * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + bc4 * 4)) * 4u;
                 }
             }
             rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
@@ -121,19 +138,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             const float* Ab = As + wm * 64 + l31;
             const float* Bb = Bs + wn * (BN / 2) + l31;
             __builtin_amdgcn_s_setprio(1);
+            float fa[2][2], fb[2][TN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[0][i] = Ab[lh * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = Bb[lh * BN + j * 32];
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                const int k = 2 * p + lh;
-                float fa[2], fb[TN];
+                const int cur = p & 1, nxt = cur ^ 1;
+                if (p + 1 < 16) {                 // operands of the next k-step are in flight while this one multiplies
+                    const int k = 2 * (p + 1) + lh;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = Ab[k * BM + i * 32];
+                    for (int i = 0; i < 2; ++i) fa[nxt][i] = Ab[k * BM + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = Bb[k * BN + j * 32];
+                    for (int j = 0; j < TN; ++j) fb[nxt][j] = Bb[k * BN + j * 32];
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // LDS reads of step p+1 ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);   // ... ahead of the MFMAs of step p
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -166,21 +192,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-static int wgrad_splits(long M, int tiles) {
-    // Workgroups run 4 per CU (VGPR-bound), i.e. 1024 resident on 256 CUs.  Pick the split count whose total
-    // workgroup count fills whole rounds of 256 best (1026 workgroups would run as 1024 + 2: half the machine idle
-    // for the second half of the launch), preferring fewer splits; every split keeps >= 8 K-tiles of 32 pixels.
-    long maxs = M / 256;
+static void magic_div(int d, unsigned& m, int& sh) {
+    if (d <= 1) { m = 0; sh = 0; return; }
+    int l = 0;
+    while ((1L << l) < d) ++l;
+    m = (unsigned)(((1ULL << (31 + l)) + (unsigned long long)d - 1) / (unsigned long long)d);
+    sh = l - 1;
+}
+
+static int wgrad_splits(long M, int tiles, bool gemm) {
+    // Three workgroups are resident per CU (VGPR-bound).  Pick the split count whose total workgroup count fills whole
+    // rounds of 256 CUs best (1026 workgroups would run as 1024 + 2), preferring fewer splits.  Measured on MI355X
+    // (tools/time_wgrad.py): 1x1 layers want <= 768 workgroups with >= 10 K-tiles of 32 pixels each (their per-tile
+    // work is small next to the slab write + ordered reduce), 3x3 layers are best near 756-1017 workgroups.
+    const long min_rows = gemm ? 320 : 256;
+    const long max_wg = gemm ? 768 : 1024;
+    long maxs = M / min_rows;
     if (maxs < 1) maxs = 1;
     if (maxs > 256) maxs = 256;
     int best = 1;
     double best_score = -1.0;
     for (long s = 1; s <= maxs; ++s) {
         const long wg = (long)tiles * s;
-        if (wg > 1024 && s > 1) break;
+        if (wg > max_wg && s > 1) break;
         const long rounds = (wg + 255) / 256;
         const double fill = (double)wg / (double)(rounds * 256);          // CU balance
-        const double par = wg >= 1024 ? 1.0 : (wg >= 512 ? 0.97 : (wg >= 256 ? 0.90 : 0.90 * wg / 256.0));  // latency hiding
+        const double par = wg >= 512 ? 0.97 : (wg >= 256 ? 0.90 : 0.90 * wg / 256.0);   // latency hiding
         const double score = fill * par;
         if (score > best_score + 1e-9) { best_score = score; best = (int)s; }
     }
@@ -191,7 +228,9 @@ extern "C" int64_t fd_conv_wgrad_workspace_bytes(int64_t out_rows, int32_t Cin, 
     if (out_rows < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1) return -1;
     const int bn = (Cin % 128 == 0) ? 128 : 64;
     const int tiles = ((Cout + 127) / 128) * KH * KW * ((Cin + bn - 1) / bn);
-    return (int64_t)wgrad_splits(out_rows, tiles) * Cout * KH * KW * Cin * 4;
+    // upper bound over both split rules (the launcher knows stride / padding, this query does not)
+    const int ns = std::max(wgrad_splits(out_rows, tiles, false), wgrad_splits(out_rows, tiles, true));
+    return (int64_t)ns * Cout * KH * KW * Cin * 4;
 }
 
 extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_stream_t stream_) {
@@ -223,6 +262,8 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
             a.m_out[s] = (int)mo;
             mo += (long)p->in.batch * a.Ho[s] * a.Wo[s];
         } else { a.H[s] = a.W[s] = a.Ho[s] = a.Wo[s] = 1; a.m_in[s] = 0; a.m_out[s] = (int)mo; }
+        magic_div(a.Ho[s] * a.Wo[s], a.mg_hw[s], a.sh_hw[s]);
+        magic_div(a.Wo[s], a.mg_w[s], a.sh_w[s]);
     }
     a.m_out[FD_MAX_SEG] = (int)mo;
     FD_REQUIRE(mo > 0 && mo < (1L << 31), FD_E_INVAL, "fd_conv2d_bwd_weight: row count out of range");
@@ -235,15 +276,19 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
     a.co_tiles = (p->Cout + 127) / 128;
     a.ci_tiles = (p->Cin + bn - 1) / bn;
     const int tiles = a.co_tiles * a.ntaps * a.ci_tiles;
-    const int nsplit = wgrad_splits(mo, tiles);
+    const int nsplit = p->nsplit > 0 ? p->nsplit : wgrad_splits(mo, tiles, a.is_gemm != 0);
+    FD_REQUIRE(nsplit <= 65535, FD_E_INVAL, "fd_conv2d_bwd_weight: nsplit too large");
     a.rows_per_split = (int)(((mo + nsplit - 1) / nsplit + 31) / 32 * 32);
     a.slab = (long)p->Cout * a.Ktot;
     FD_REQUIRE(p->workspace_bytes >= (int64_t)nsplit * a.slab * 4, FD_E_INVAL,
                "fd_conv2d_bwd_weight: workspace too small (need fd_conv_wgrad_workspace_bytes())");
     a.out = (nsplit == 1) ? p->dw : (float*)p->workspace;
     const dim3 grid(tiles, (unsigned)((mo + a.rows_per_split - 1) / a.rows_per_split));
-    if (bn == 128) hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, stream, a);
+    const bool one = p->in.nseg == 1;
+    if (bn == 128 && one) hipLaunchKernelGGL((conv_wgrad_kernel<128, true>), grid, dim3(256), 0, stream, a);
+    else if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), grid, dim3(256), 0, stream, a);
+    else if (one) hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), grid, dim3(256), 0, stream, a);
     FD_CHECK_LAUNCH("fd_conv2d_bwd_weight");
     if (nsplit > 1) {
         const long n4 = a.slab / 4;

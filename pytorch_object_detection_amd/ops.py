@@ -245,14 +245,15 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
 
 
 def conv_wgrad(x: Rows, dy: Rows, segs_in: Segs, *, Cin: int, Cout: int, k: int, stride: int = 1, pad: int = 0,
-               dil: int = 1) -> torch.Tensor:
+               dil: int = 1, nsplit: int = 0) -> torch.Tensor:
     """Weight gradient [Cout, k, k, Cin] (OHWI) of conv(x) w.r.t. its weights given dy (rows in output geometry)."""
     out_rows = conv_out_segs(segs_in, k, stride, pad, dil).rows
     dev = x.buf.device
     dw = torch.empty(Cout, k, k, Cin, dtype=torch.float32, device=dev)
-    nb = _lib.lib().fd_conv_wgrad_workspace_bytes(out_rows, Cin, Cout, k, k)
+    nb = _lib.lib().fd_conv_wgrad_workspace_bytes(out_rows, Cin, Cout, k, k) if nsplit <= 0 else nsplit * dw.numel() * 4
     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=dev)
     p = _lib.WgradParams()
+    p.nsplit = max(nsplit, 0)
     p.x, p.dy, p.dw = x.ptr, dy.ptr, dw.data_ptr()
     p.x_cs, p.x_co, p.dy_cs, p.dy_co = x.cs, x.co, dy.cs, dy.co
     p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, k, stride, pad, dil
