@@ -201,6 +201,18 @@ int32_t fd_groupnorm_act_nhwc(const float* x, int32_t x_cs, int32_t x_co, const 
                               float* y, int32_t y_cs, int32_t y_co, int32_t C, int32_t G, float eps, int32_t act,
                               const fd_segs* segs, void* workspace, fd_stream_t stream);
 
+/* Backward of the call above for the train step (reference train.py:175-181 differentiates nn.GroupNorm + ReLU / SiLU,
+ * HISFcos.py:190-222): given dy (gradient w.r.t. the activated output) writes dx, dgamma[C], dbeta[C].
+ * `fwd_workspace` is the forward call's workspace, unmodified (its partial moments give mean / rstd);
+ * `workspace`: fd_groupnorm_bwd_workspace_bytes(segs, C).  act in {NONE, RELU, SILU}.  dx may alias dy.
+ * fp64 partial sums in fixed order: deterministic. */
+int64_t fd_groupnorm_bwd_workspace_bytes(const fd_segs* segs, int32_t C);
+int32_t fd_groupnorm_act_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs,
+                                  int32_t dy_co, const float* gamma, const float* beta, float* dx, int32_t dx_cs,
+                                  int32_t dx_co, float* dgamma, float* dbeta, int32_t C, int32_t G, float eps,
+                                  int32_t act, const fd_segs* segs, const void* fwd_workspace, void* workspace,
+                                  fd_stream_t stream);
+
 /* Squeeze-excitation (SEBlock, modules.py:107-121): y = x * sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2).
  * w1 [Cr][C], w2 [C][Cr].  workspace: fd_se_workspace_bytes(N, HW, C). */
 int64_t fd_se_workspace_bytes(int32_t N, int32_t HW, int32_t C);

@@ -86,6 +86,9 @@ _SIGS = {
     "fd_dwconv3x3_bwd_weight_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, C.POINTER(Segs), _P, _P]),
     "fd_groupnorm_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
     "fd_groupnorm_act_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _I, C.POINTER(Segs), _P, _P]),
+    "fd_groupnorm_bwd_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
+    "fd_groupnorm_act_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, C.POINTER(Segs), _P, _P,
+                                       _P]),
     "fd_se_workspace_bytes": (_L, [_I, _I, _I]),
     "fd_se_scale_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "fd_fcos_decode": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, C.POINTER(Segs), C.POINTER(_I), _P, _P, _P, _P]),

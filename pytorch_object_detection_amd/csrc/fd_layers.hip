@@ -477,6 +477,201 @@ extern "C" int32_t fd_groupnorm_act_nhwc(const float* x, int32_t x_cs, int32_t x
     return FD_OK;
 }
 
+// ---- GroupNorm + activation backward (train step): dz = dy * act'(z), z = xhat * gamma + beta,
+//        dx = rstd * (dz * gamma - mean_g(dz * gamma) - xhat * mean_g(dz * gamma * xhat)),  dgamma = sum dz * xhat,  dbeta = sum dz
+// pass 1: per (level, image, row-chunk): per-channel sums A = sum dz, B = sum dz * xhat (fp64, fixed order)
+// pass 2: per (level, image): chunk sums -> group sums -> dx; block 0 also leaves the per-image channel sums
+// pass 3: dgamma / dbeta = fixed-order sum over (level, image)
+// mean / rstd come from the forward call's partial moments (its workspace), so x is not re-reduced.
+__device__ __forceinline__ float fd_act_grad(float z, int act) {
+    switch (act) {
+        case FD_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case FD_ACT_SILU: { const float sg = fd_sigmoid(z); return sg * (1.f + z * (1.f - sg)); }
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ void gn_channel_stats(const double* __restrict__ fpart, int img, int nchunk, int G, int cg, int HW,
+                                                 float eps, int C, int tid, float* s_mean, float* s_rstd) {
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cg;
+        double a = 0, b = 0;
+        for (int k = 0; k < nchunk; ++k) {
+            const double* p = fpart + (((long)img * GN_MAXCHUNK + k) * G + g) * 2;
+            a += p[0]; b += p[1];
+        }
+        const double cnt = (double)HW * cg;
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0) var = 0;
+        s_mean[c] = (float)mean;
+        s_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, int x_cs, int x_co,
+                                                              const float* __restrict__ dy, int dy_cs, int dy_co,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int C, int G, float eps, int act, SegTab tab,
+                                                              const double* __restrict__ fpart, double* __restrict__ part) {
+    __shared__ double s_a[256 * 4];
+    __shared__ double s_b[256 * 4];
+    __shared__ float s_mean[1024], s_rstd[1024];
+    const int img = blockIdx.y;
+    const int s = img / tab.s.batch, n = img - s * tab.s.batch;
+    const int HW = tab.s.H[s] * tab.s.W[s];
+    const int nchunk = min(GN_MAXCHUNK, (HW + 63) / 64);
+    const int chunk = blockIdx.x;
+    if (chunk >= nchunk) return;
+    const int tid = threadIdx.x, cg = C / G;
+    gn_channel_stats(fpart, img, nchunk, G, cg, HW, eps, C, tid, s_mean, s_rstd);
+    __syncthreads();
+    const int rows_per = (HW + nchunk - 1) / nchunk;
+    const int r_begin = chunk * rows_per, r_end = min(HW, r_begin + rows_per);
+    const int C4 = C >> 2, RT = 256 / C4;
+    const int q = tid % C4, rt = tid / C4;
+    double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    if (rt < RT) {
+        const long row0 = (long)tab.s.m_start[s] + (long)n * HW;
+        float mean[4], rstd[4], gm[4], bt[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mean[e] = s_mean[4 * q + e]; rstd[e] = s_rstd[4 * q + e]; gm[e] = gamma[4 * q + e]; bt[e] = beta[4 * q + e];
+        }
+        for (int r = r_begin + rt; r < r_end; r += RT) {
+            const float4 v4 = *reinterpret_cast<const float4*>(x + (row0 + r) * x_cs + x_co + 4 * q);
+            const float4 g4 = *reinterpret_cast<const float4*>(dy + (row0 + r) * dy_cs + dy_co + 4 * q);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (v[e] - mean[e]) * rstd[e];
+                const float dz = g[e] * fd_act_grad(xh * gm[e] + bt[e], act);
+                sa[e] += dz; sb[e] += (double)dz * xh;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s_a[rt * C + 4 * q + e] = sa[e]; s_b[rt * C + 4 * q + e] = sb[e]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        double a = 0, b = 0;
+        for (int r = 0; r < RT; ++r) { a += s_a[r * C + c]; b += s_b[r * C + c]; }
+        double* o = part + ((long)img * GN_MAXCHUNK + chunk) * 2 * C;
+        o[c] = a; o[C + c] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, int x_cs, int x_co,
+                                                            const float* __restrict__ dy, int dy_cs, int dy_co,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ dx, int dx_cs, int dx_co, int C, int G, float eps,
+                                                            int act, SegTab tab, const double* __restrict__ fpart,
+                                                            const double* __restrict__ part, double* __restrict__ img_sums) {
+    __shared__ float s_mean[1024], s_rstd[1024], s_k1[1024], s_p[1024], s_q[1024];
+    __shared__ double s_ga[1024], s_gb[1024];
+    const int img = blockIdx.y;
+    const int s = img / tab.s.batch, n = img - s * tab.s.batch;
+    const int HW = tab.s.H[s] * tab.s.W[s];
+    const int nchunk = min(GN_MAXCHUNK, (HW + 63) / 64);
+    const int nblk = gridDim.x;
+    const int rows_per = (HW + nblk - 1) / nblk;
+    const int r_begin = blockIdx.x * rows_per, r_end = min(HW, r_begin + rows_per);
+    if (r_begin >= r_end && blockIdx.x != 0) return;
+    const int cg = C / G, tid = threadIdx.x;
+    gn_channel_stats(fpart, img, nchunk, G, cg, HW, eps, C, tid, s_mean, s_rstd);
+    for (int c = tid; c < C; c += 256) {
+        double a = 0, b = 0;
+        for (int k = 0; k < nchunk; ++k) {
+            const double* p = part + ((long)img * GN_MAXCHUNK + k) * 2 * C;
+            a += p[c]; b += p[C + c];
+        }
+        if (blockIdx.x == 0) { img_sums[(long)img * 2 * C + c] = a; img_sums[(long)img * 2 * C + C + c] = b; }
+        s_ga[c] = a * (double)gamma[c]; s_gb[c] = b * (double)gamma[c];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cg;
+        double s1 = 0, s2 = 0;
+        for (int k = 0; k < cg; ++k) { s1 += s_ga[g * cg + k]; s2 += s_gb[g * cg + k]; }
+        const double cnt = (double)HW * cg;
+        const double rstd = (double)s_rstd[c], mean = (double)s_mean[c];
+        s_k1[c] = (float)(rstd * (double)gamma[c]);
+        s_p[c] = (float)(-rstd * rstd * s2 / cnt);
+        s_q[c] = (float)(-rstd * s1 / cnt + rstd * rstd * mean * s2 / cnt);
+    }
+    __syncthreads();
+    const int C4 = C >> 2;
+    const long row0 = (long)tab.s.m_start[s] + (long)n * HW;
+    const long total = (long)(r_end - r_begin) * C4;
+    for (long i = tid; i < total; i += 256) {
+        const int q = (int)(i % C4);
+        const long m = row0 + r_begin + i / C4;
+        const float4 v4 = *reinterpret_cast<const float4*>(x + m * x_cs + x_co + 4 * q);
+        const float4 g4 = *reinterpret_cast<const float4*>(dy + m * dy_cs + dy_co + 4 * q);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * q + e;
+            const float xh = (v[e] - s_mean[c]) * s_rstd[c];
+            const float dz = g[e] * fd_act_grad(xh * gamma[c] + beta[c], act);
+            o[e] = s_k1[c] * dz + s_p[c] * v[e] + s_q[c];
+        }
+        *reinterpret_cast<float4*>(dx + m * dx_cs + dx_co + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const double* __restrict__ img_sums, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int C, int imgs) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int i = 0; i < imgs; ++i) { a += img_sums[(long)i * 2 * C + c]; b += img_sums[(long)i * 2 * C + C + c]; }
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)b;
+}
+
+extern "C" int64_t fd_groupnorm_bwd_workspace_bytes(const fd_segs* segs, int32_t C) {
+    if (!fd_segs_ok(segs) || C < 4) return -1;
+    const int64_t imgs = (int64_t)segs->nseg * segs->batch;
+    return (imgs * GN_MAXCHUNK + imgs) * 2 * C * (int64_t)sizeof(double);
+}
+
+extern "C" int32_t fd_groupnorm_act_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs,
+                                             int32_t dy_co, const float* gamma, const float* beta, float* dx, int32_t dx_cs,
+                                             int32_t dx_co, float* dgamma, float* dbeta, int32_t C, int32_t G, float eps,
+                                             int32_t act, const fd_segs* segs, const void* fwd_workspace, void* workspace,
+                                             fd_stream_t stream) {
+    FD_REQUIRE(fd_segs_ok(segs), FD_E_INVAL, "fd_groupnorm_bwd: bad segment table");
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(dy, dy_cs, dy_co, C) && view_ok(dx, dx_cs, dx_co, C) && gamma && beta &&
+                   dgamma && dbeta && fwd_workspace && workspace,
+               FD_E_INVAL, "fd_groupnorm_bwd: bad pointer / channel view (C=%d)", C);
+    FD_REQUIRE(G >= 1 && C % G == 0 && C <= 1024 && 256 % (C / 4) == 0, FD_E_UNSUPPORTED,
+               "fd_groupnorm_bwd: C=%d G=%d unsupported (C/4 must divide 256, C <= 1024)", C, G);
+    FD_REQUIRE(act == FD_ACT_NONE || act == FD_ACT_RELU || act == FD_ACT_SILU, FD_E_UNSUPPORTED,
+               "fd_groupnorm_bwd: activation %d has no backward", act);
+    FD_REQUIRE((long)segs->nseg * segs->batch <= 65535, FD_E_UNSUPPORTED, "fd_groupnorm_bwd: too many (level, image) pairs");
+    SegTab tab; tab.s = *segs;
+    const int imgs = segs->nseg * segs->batch;
+    int maxhw = 0;
+    for (int s = 0; s < segs->nseg; ++s) maxhw = max(maxhw, segs->H[s] * segs->W[s]);
+    const int nchunk = min(GN_MAXCHUNK, (maxhw + 63) / 64);
+    double* part = (double*)workspace;
+    double* img_sums = part + (long)imgs * GN_MAXCHUNK * 2 * C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, imgs), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, gamma, beta, C,
+                       G, eps, act, tab, (const double*)fwd_workspace, part);
+    FD_CHECK_LAUNCH("fd_groupnorm_bwd (partial)");
+    const int ablk = max(1, min(64, (maxhw * (C / 4) + 2047) / 2048));
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ablk, imgs), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, gamma, beta, dx,
+                       dx_cs, dx_co, C, G, eps, act, tab, (const double*)fwd_workspace, (const double*)part, img_sums);
+    FD_CHECK_LAUNCH("fd_groupnorm_bwd (apply)");
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)img_sums, dgamma, dbeta, C,
+                       imgs);
+    FD_CHECK_LAUNCH("fd_groupnorm_bwd (params)");
+    return FD_OK;
+}
+
 // ------------------------------------------------------------------------------ squeeze-excitation
 #define SE_MAXCHUNK 64
 

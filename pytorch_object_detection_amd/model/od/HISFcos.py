@@ -14,7 +14,8 @@ from ..._lib import FdError, Segs
 from ...ops import Rows
 import torch.nn.functional as F
 
-from ...ops import ACT_NONE, ACT_RELU
+from ...ops import ACT_NONE, ACT_RELU, ACT_SILU
+from ... import train_ops as T
 from ...train_ops import conv2d as tconv, conv_bn_act as cba
 from ..backbone.resnet50 import ResNet50v2, trunk_train_forward
 from ..modules.modules import DepthWiseConv2d, PointWiseConv, ScaleExp, SEBlock
@@ -94,6 +95,15 @@ class HalfInvertedStageFPN(PlannedModule):
         return pyramid_out(pyr, segs)
 
 
+class _RegCnt:
+    """reg_pred (4) and cnt_logits (1) as one 5-output conv for train_ops.conv_rows (same geometry, same input)."""
+
+    def __init__(self, reg: nn.Conv2d, cnt: nn.Conv2d):
+        self.weight = torch.cat((reg.weight, cnt.weight), 0)
+        self.bias = torch.cat((reg.bias, cnt.bias), 0)
+        self.stride, self.padding, self.dilation, self.kernel_size = reg.stride, reg.padding, reg.dilation, reg.kernel_size
+
+
 class HISFCOSHead(PlannedModule):
     def __init__(self, feature: int, num_class: int, prior: float = 0.01):
         super().__init__()
@@ -113,6 +123,29 @@ class HISFCOSHead(PlannedModule):
         self.scale_exp = nn.ModuleList([ScaleExp(1.2) for _ in range(5)])
 
     def train_forward(self, inputs):
+        """Training-time autograd forward.  The five levels share the head's weights, so they are concatenated into one
+        rows buffer (the inference layout) and every layer is ONE HIP launch over the whole pyramid, forward and
+        backward: 1x1 / 3x3 convs (train_ops.conv_rows), the depthwise conv, GroupNorm + ReLU / SiLU.  The three narrow
+        predictors are zero-padded to 32 output channels inside so their data gradients stay on the HIP conv kernel;
+        centre-ness and box regression share one launch (both read the regression tower)."""
+        x0 = inputs[0]
+        if (not T.covered(self.pw1, None, x0) or not T.covered(self.dw1, None, torch.empty(0, dtype=x0.dtype))
+                or not all(T._gn_ok(g, x0) for g in (self.gn1, self.gn2, self.cls_conv[1], self.reg_conv[1]))):
+            return self._train_forward_stock(inputs)
+        f, segs = T.pyramid_rows(inputs)
+        h = T.groupnorm_rows(self.gn1, T.conv_rows(self.pw1, f, segs), segs, ACT_RELU)
+        h = T.groupnorm_rows(self.gn2, T.dw_rows(self.dw1, h, segs), segs, ACT_SILU)
+        z = T.conv_rows(self.pw2, h, segs, residual=f)
+        c = T.groupnorm_rows(self.cls_conv[1], T.conv_rows(self.cls_conv[0], z, segs), segs, self.cls_conv[2])
+        r = T.groupnorm_rows(self.reg_conv[1], T.conv_rows(self.reg_conv[0], z, segs), segs, self.reg_conv[2])
+        cls = T.conv_rows(self.cls_logits, c, segs, pad_out=True)
+        rc = T.conv_rows(_RegCnt(self.reg_pred, self.cnt_logits), r, segs, pad_out=True)     # [:, :4] boxes, [:, 4] centre-ness
+        cls_l = T.pyramid_split(cls, segs)
+        cnt_l = T.pyramid_split(rc[:, 4:5], segs)
+        reg_l = [torch.exp(t * self.scale_exp[i].scale) for i, t in enumerate(T.pyramid_split(rc[:, :4], segs))]
+        return cls_l, cnt_l, reg_l
+
+    def _train_forward_stock(self, inputs):
         cls_l, cnt_l, reg_l = [], [], []
         for i, f in enumerate(inputs):
             h = F.silu(self.gn2(tconv(self.dw1, F.relu(self.gn1(tconv(self.pw1, f))))))
@@ -120,7 +153,7 @@ class HISFCOSHead(PlannedModule):
             c = self.cls_conv[2](self.cls_conv[1](tconv(self.cls_conv[0], z)))
             r = self.reg_conv[2](self.reg_conv[1](tconv(self.reg_conv[0], z)))
             cls_l.append(tconv(self.cls_logits, c))
-            cnt_l.append(self.cnt_logits(r))                 # Cout = 1: stock op
+            cnt_l.append(self.cnt_logits(r))
             reg_l.append(torch.exp(tconv(self.reg_pred, r) * self.scale_exp[i].scale))
         return cls_l, cnt_l, reg_l
 

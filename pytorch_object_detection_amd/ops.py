@@ -348,6 +348,23 @@ def groupnorm_act(x: Rows, gamma: torch.Tensor, beta: torch.Tensor, y: Rows, seg
                                            G, eps, act, C.byref(segs), ws.data_ptr(), _stream()), "fd_groupnorm_act_nhwc")
 
 
+def groupnorm_act_bwd(x: Rows, dy: Rows, gamma: torch.Tensor, beta: torch.Tensor, dx: Rows, segs: Segs, G: int, act: int,
+                      fwd_ws: torch.Tensor, eps: float = 1e-5):
+    """Backward of groupnorm_act (fwd_ws = the forward call's workspace, untouched since).  Returns (dgamma, dbeta)."""
+    dev = x.buf.device
+    n = _lib.lib().fd_groupnorm_bwd_workspace_bytes(C.byref(segs), x.C)
+    if n < 0:
+        raise FdError("fd_groupnorm_bwd_workspace_bytes: bad arguments")
+    ws = torch.empty(n // 8, dtype=torch.float64, device=dev)
+    dgamma = torch.empty(x.C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(x.C, dtype=torch.float32, device=dev)
+    check(_lib.lib().fd_groupnorm_act_bwd_nhwc(x.ptr, x.cs, x.co, dy.ptr, dy.cs, dy.co, gamma.data_ptr(), beta.data_ptr(),
+                                               dx.ptr, dx.cs, dx.co, dgamma.data_ptr(), dbeta.data_ptr(), x.C, G, eps, act,
+                                               C.byref(segs), fwd_ws.data_ptr(), ws.data_ptr(), _stream()),
+          "fd_groupnorm_act_bwd_nhwc")
+    return dgamma, dbeta
+
+
 def se_workspace(N: int, HW: int, C_: int, device) -> torch.Tensor:
     n = _lib.lib().fd_se_workspace_bytes(N, HW, C_)
     return torch.empty((n + 7) // 8, dtype=torch.float64, device=device)

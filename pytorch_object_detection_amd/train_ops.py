@@ -1,21 +1,26 @@
 """Autograd bindings of the HIP kernels for the training forward (reference train.py:175-181).
 
-`conv_bn_act(conv, bn, x, act, residual)` runs Conv2d -> frozen BatchNorm2d -> (+ residual) -> ReLU as ONE launch of
-fd_conv2d_nhwc_f32 (the BN is folded into the epilogue, as at inference) and differentiates it with
-  * the ReLU mask applied to the incoming gradient (one elementwise pass, from the saved output),
-  * the data gradient = the same conv kernel on dY with flipped / transposed weights (stride-1 layers),
-  * the weight gradient = fd_conv2d_bwd_weight_f32 (any stride),
-on channels-last tensors, which ARE the library's NHWC rows (zero-copy views).  Depthwise 3x3 layers use
-fd_dwconv3x3_nhwc (forward and data gradient) and fd_dwconv3x3_bwd_weight_nhwc.  What the kernels do not cover falls
-back to stock PyTorch-ROCm ops on the GPU: the data gradient of strided layers, dense layers with Cin % 32 != 0 or
-Cout % 4 != 0 (the 7x7 stem when it is trainable, the 1-channel centre-ness conv), BatchNorm in training mode or with
-trainable affine parameters, and SiLU (kept outside the fused epilogue because its derivative needs the pre-activation).
+Everything here works on the library's own layout: NHWC rows, i.e. 2-D tensors [rows, C] described by a segment table
+(`Segs`: one segment per pyramid level).  An NCHW-shaped channels-last tensor IS such a buffer (zero-copy view), and the
+five FCOS levels concatenated along the row axis are one buffer too, so a shared-weight head runs one launch per layer
+over the whole pyramid exactly as at inference.
+
+  conv_rows / conv_bn_act   Conv2d -> frozen BatchNorm2d -> (+ residual) -> ReLU as ONE launch of fd_conv2d_nhwc_f32
+                            (BN folded into the epilogue).  Backward: ReLU mask on the incoming gradient (one
+                            elementwise pass from the saved output), data gradient = the same conv kernel on dY with
+                            flipped / transposed weights (stride-1 layers), weight gradient = fd_conv2d_bwd_weight_f32.
+  dw_rows                   depthwise 3x3: fd_dwconv3x3_nhwc forward and data gradient, fd_dwconv3x3_bwd_weight_nhwc.
+  groupnorm_rows            GroupNorm + ReLU / SiLU: fd_groupnorm_act_nhwc / fd_groupnorm_act_bwd_nhwc.
+
+What the kernels do not cover falls back to stock PyTorch-ROCm ops on the GPU: the data gradient of strided layers,
+dense layers with Cin % 32 != 0 (the 7x7 stem when it is trainable), BatchNorm in training mode or with trainable
+affine parameters, and SiLU after a BatchNorm (its derivative needs the pre-activation, which the fused epilogue does
+not keep).  Narrow outputs (class / centre-ness / box logits) are padded to 32 channels by `conv_rows(pad_out=True)`.
 """
 from __future__ import annotations
 
-import ctypes as C
 import os
-from typing import Optional
+from typing import List, Optional, Sequence
 
 import torch
 import torch.nn as nn
@@ -23,23 +28,44 @@ import torch.nn.functional as F
 
 from . import _lib, ops
 from ._lib import FdError, Segs
-from .ops import ACT_NONE, ACT_RELU, Rows
+from .ops import ACT_NONE, ACT_RELU, ACT_SILU, Rows
 
-_STOCK = os.environ.get("FD_TRAIN_STOCK_CONV") == "1"   # diagnostic: route every conv to the stock op (timing comparisons)
+_STOCK = os.environ.get("FD_TRAIN_STOCK_CONV") == "1"   # diagnostic: route every layer to the stock ops (timing comparisons)
 STATS = {"cl_copies": 0}                                 # activation-sized layout copies made on entry (should stay 0)
 
 
-def _rows(t: torch.Tensor) -> Rows:
-    """NCHW-shaped channels-last tensor -> [B*H*W, C] rows view (no copy)."""
+# ----------------------------------------------------------------------------------------------- layout helpers
+def to_rows(t: torch.Tensor) -> torch.Tensor:
+    """NCHW-shaped tensor -> [B*H*W, C] rows (a view when `t` is channels-last; autograd-tracked either way)."""
+    if not t.is_contiguous(memory_format=torch.channels_last):
+        STATS["cl_copies"] += 1
+        t = t.contiguous(memory_format=torch.channels_last)
     B, Cc, H, W = t.shape
-    return Rows(t.permute(0, 2, 3, 1).reshape(B * H * W, Cc))
+    return t.permute(0, 2, 3, 1).reshape(B * H * W, Cc)
 
 
-def _cl(t: torch.Tensor) -> torch.Tensor:
-    if t.is_contiguous(memory_format=torch.channels_last):
-        return t
-    STATS["cl_copies"] += 1
-    return t.contiguous(memory_format=torch.channels_last)
+def from_rows(r: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    """[B*H*W, C] rows -> NCHW-shaped channels-last view."""
+    return r.view(B, H, W, r.shape[1]).permute(0, 3, 1, 2)
+
+
+def pyramid_rows(maps: Sequence[torch.Tensor]):
+    """Five NCHW maps -> one [sum B*H*W, C] rows buffer (level-major, the inference layout) + its segment table."""
+    B = maps[0].shape[0]
+    segs = Segs.make(B, [(t.shape[2], t.shape[3]) for t in maps])
+    return torch.cat([to_rows(t) for t in maps], 0), segs
+
+
+def pyramid_split(r: torch.Tensor, segs: Segs) -> List[torch.Tensor]:
+    """Rows buffer -> list of NCHW-shaped channels-last views, one per level."""
+    out = []
+    for i, (h, w) in enumerate(segs.level_hw()):
+        out.append(from_rows(r[segs.m_start[i]:segs.m_start[i + 1]], segs.batch, h, w))
+    return out
+
+
+def _r(t: torch.Tensor) -> Rows:
+    return Rows(t)
 
 
 def _pad_of(m: nn.Conv2d) -> int:
@@ -53,8 +79,8 @@ def _square(m: nn.Conv2d) -> bool:
             and (isinstance(m.padding, str) or m.padding[0] == m.padding[1]) and m.padding_mode == "zeros")
 
 
-def _dense_ok(m: nn.Conv2d, x: torch.Tensor) -> bool:
-    return (m.groups == 1 and m.in_channels % 32 == 0 and m.out_channels % 4 == 0 and _square(m)
+def _dense_ok(m: nn.Conv2d, x: torch.Tensor, pad_out: bool = False) -> bool:
+    return (m.groups == 1 and m.in_channels % 32 == 0 and (pad_out or m.out_channels % 4 == 0) and _square(m)
             and x.dtype == torch.float32 and m.weight.dtype == torch.float32)
 
 
@@ -62,7 +88,14 @@ def _dw_ok(m: nn.Conv2d, x: torch.Tensor) -> bool:
     c4 = m.in_channels // 4
     return (m.groups == m.in_channels == m.out_channels and m.in_channels % 4 == 0 and m.kernel_size == (3, 3)
             and m.stride == (1, 1) and m.dilation == (1, 1) and _pad_of(m) == 1 and m.padding_mode == "zeros"
-            and ((c4 < 256 and 256 % c4 == 0) or c4 % 256 == 0) and x.dtype == torch.float32)
+            and m.bias is None and ((c4 < 256 and 256 % c4 == 0) or c4 % 256 == 0) and x.dtype == torch.float32)
+
+
+def _gn_ok(gn: nn.Module, x: torch.Tensor) -> bool:
+    if not isinstance(gn, nn.GroupNorm) or not gn.affine or x.dtype != torch.float32:
+        return False
+    Cc = gn.num_channels
+    return Cc % 4 == 0 and Cc <= 1024 and 256 % (Cc // 4) == 0 and Cc % gn.num_groups == 0
 
 
 def bn_is_frozen(bn: Optional[nn.Module]) -> bool:
@@ -81,50 +114,59 @@ def _bn_fold(bn: nn.BatchNorm2d):
     return hit[1]
 
 
-def _conv_launch(x: torch.Tensor, w_oihw: torch.Tensor, y: torch.Tensor, *, k, stride, pad, dil, scale=None, shift=None,
-                 res: Optional[torch.Tensor] = None, act=ACT_NONE) -> None:
-    """y = act(conv(x, w) * scale + shift + res) on channels-last NCHW-shaped tensors."""
-    B, Cin, H, W = x.shape
-    Cout = w_oihw.shape[0]
-    segs = Segs.make(B, [(H, W)])
-    out_rows = B * y.shape[2] * y.shape[3]
+def _act_id(act) -> int:
+    if act is None or isinstance(act, nn.Identity):
+        return ACT_NONE
+    if isinstance(act, nn.ReLU):
+        return ACT_RELU
+    if isinstance(act, nn.SiLU):
+        return ACT_SILU
+    if isinstance(act, int):
+        return act
+    raise FdError(f"unsupported activation module {type(act).__name__}")
+
+
+# ------------------------------------------------------------------------------------------- dense convolution
+def _conv_launch(x: torch.Tensor, segs: Segs, w_oihw: torch.Tensor, y: torch.Tensor, *, k, stride, pad, dil, scale=None,
+                 shift=None, res: Optional[torch.Tensor] = None, act=ACT_NONE) -> None:
+    """y = act(conv(x, w) * scale + shift + res) on contiguous rows buffers."""
+    Cin, Cout = x.shape[1], w_oihw.shape[0]
+    out_rows = y.shape[0]
     code = ops.heuristic_conv(out_rows, Cout, (Cin // 32) * k * k, True)
     tile, ksplit = code & 0xFF, max(1, code >> 8)
     ws = None
     if ksplit > 1:
         nb = _lib.lib().fd_conv_workspace_bytes(out_rows, Cout, ksplit)
         ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=x.device)
-    ops.conv_call(_rows(x), segs, ops.pack_conv_weight(w_oihw), _rows(y), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad,
-                  dil=dil, scale=scale, shift=shift, res=_rows(res) if res is not None else None, act=act, tile=tile,
+    ops.conv_call(_r(x), segs, ops.pack_conv_weight(w_oihw), _r(y), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad,
+                  dil=dil, scale=scale, shift=shift, res=_r(res) if res is not None else None, act=act, tile=tile,
                   ksplit=ksplit, workspace=ws)()
 
 
-class _HipConv2d(torch.autograd.Function):
-    """y = act(conv(x, w) * scale + shift + residual); scale is a constant (frozen BN), shift may carry a gradient."""
+class _ConvRows(torch.autograd.Function):
+    """y = act(conv(x, w) * scale + shift + residual) on rows; scale is a constant (frozen BN), shift may need a gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, scale, shift, residual, stride, pad, dil, act):
-        xc = _cl(x)
-        B, Cin, H, W = xc.shape
+    def forward(ctx, x, weight, scale, shift, residual, segs, stride, pad, dil, act):
+        x = x.contiguous()
         Cout, _, k, _ = weight.shape
-        Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
-        Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
-        y = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        rc = _cl(residual) if residual is not None else None
-        _conv_launch(xc, weight.detach(), y, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
-                     shift=shift.detach().contiguous() if shift is not None else None, res=rc, act=act)
-        ctx.save_for_backward(xc, weight, scale, y if act == ACT_RELU else None)
-        ctx.geom = (stride, pad, dil, act)
+        so = ops.conv_out_segs(segs, k, stride, pad, dil)
+        y = torch.empty(so.rows, Cout, dtype=torch.float32, device=x.device)
+        _conv_launch(x, segs, weight.detach(), y, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
+                     shift=shift.detach().contiguous() if shift is not None else None,
+                     res=residual.contiguous() if residual is not None else None, act=act)
+        ctx.save_for_backward(x, weight, scale, y if act == ACT_RELU else None)
+        ctx.geom = (segs, so, stride, pad, dil, act)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xc, weight, scale, y = ctx.saved_tensors
-        stride, pad, dil, act = ctx.geom
-        g = _cl(gy)
+        x, weight, scale, y = ctx.saved_tensors
+        segs, so, stride, pad, dil, act = ctx.geom
+        g = gy.contiguous()
         if act == ACT_RELU:
             g = torch.ops.aten.threshold_backward(g, y, 0.0)
-        B, Cin, H, W = xc.shape
+        Cin = x.shape[1]
         Cout, _, k, _ = weight.shape
         gx = gw = gshift = gres = None
         if ctx.needs_input_grad[4]:
@@ -132,77 +174,139 @@ class _HipConv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             weff = weight.detach() if scale is None else weight.detach() * scale.view(-1, 1, 1, 1)
             if stride == 1 and Cout % 32 == 0:
-                gx = torch.empty_like(xc)
-                _conv_launch(g, weff.flip(2, 3).transpose(0, 1), gx, k=k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
-            else:  # strided layers / narrow outputs: stock op for the data gradient
-                gx = torch.ops.aten.convolution_backward(g, xc, weff, None, [stride, stride], [pad, pad], [dil, dil], False,
-                                                         [0, 0], 1, [True, False, False])[0]
+                gx = torch.empty_like(x)
+                _conv_launch(g, so, weff.flip(2, 3).transpose(0, 1), gx, k=k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
+            elif segs.nseg == 1:  # strided layers: stock op for the data gradient (single level only)
+                B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
+                gx4 = torch.ops.aten.convolution_backward(from_rows(g, B, Ho, Wo), from_rows(x, B, H, W), weff, None,
+                                                          [stride, stride], [pad, pad], [dil, dil], False, [0, 0], 1,
+                                                          [True, False, False])[0]
+                gx = to_rows(gx4)
+            else:
+                raise FdError("data gradient of a strided / narrow conv over a pyramid is not supported (pad Cout to 32)")
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(_rows(xc), _rows(g), Segs.make(B, [(H, W)]), Cin=Cin, Cout=Cout, k=k, stride=stride,
-                                pad=pad, dil=dil)
+            dw = ops.conv_wgrad(_r(x), _r(g), segs, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil)
             if scale is not None:
                 dw = dw * scale.view(-1, 1, 1, 1)
             gw = dw.permute(0, 3, 1, 2)                      # OHWI -> OIHW view
         if ctx.needs_input_grad[3]:
-            gshift = g.sum(dim=(0, 2, 3))
-        return gx, gw, None, gshift, gres, None, None, None, None
+            gshift = g.sum(dim=0)
+        return gx, gw, None, gshift, gres, None, None, None, None, None
 
 
-class _HipDwConv3x3(torch.autograd.Function):
+def conv_rows(m: nn.Conv2d, x: torch.Tensor, segs: Segs, bn: Optional[nn.Module] = None, act: int = ACT_NONE,
+              residual: Optional[torch.Tensor] = None, pad_out: bool = False) -> torch.Tensor:
+    """HIP conv layer on a rows buffer (must be covered: check with `covered(m, bn, x)`).  With pad_out the output
+    channels are zero-padded to a multiple of 32 inside (so the data gradient runs on the HIP kernel) and sliced back."""
+    scale = shift = None
+    if bn is not None:
+        scale, shift = _bn_fold(bn)
+    w, b = m.weight, m.bias
+    Cout = w.shape[0]
+    padn = (-Cout) % 32 if pad_out else 0
+    if padn:
+        w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, padn))
+        b = F.pad(b, (0, padn)) if b is not None else None
+        if scale is not None:
+            scale, shift = F.pad(scale, (0, padn), value=1.0), F.pad(shift, (0, padn))
+    if b is not None:
+        shift = b if scale is None else b * scale + shift
+    y = _ConvRows.apply(x, w, scale, shift, residual, segs, m.stride[0], _pad_of(m), m.dilation[0], act)
+    return y[:, :Cout] if padn else y
+
+
+# --------------------------------------------------------------------------------------------- depthwise 3x3
+class _DwRows(torch.autograd.Function):
     """Depthwise 3x3 (stride 1, pad 1, no bias): y = act(dw(x, w) * scale + shift), scale / shift constants."""
 
     @staticmethod
-    def forward(ctx, x, weight, scale, shift, act):
-        xc = _cl(x)
-        B, Cc, H, W = xc.shape
-        y = torch.empty_like(xc)
-        ops.dwconv3x3(_rows(xc), ops.pack_dw_weight(weight), _rows(y), Segs.make(B, [(H, W)]), scale, shift, act)
-        ctx.save_for_backward(xc, weight, scale, y if act == ACT_RELU else None)
-        ctx.act = act
+    def forward(ctx, x, weight, scale, shift, segs, act):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ops.dwconv3x3(_r(x), ops.pack_dw_weight(weight), _r(y), segs, scale, shift, act)
+        ctx.save_for_backward(x, weight, scale, y if act == ACT_RELU else None)
+        ctx.geom = (segs, act)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xc, weight, scale, y = ctx.saved_tensors
-        g = _cl(gy)
-        if ctx.act == ACT_RELU:
+        x, weight, scale, y = ctx.saved_tensors
+        segs, act = ctx.geom
+        g = gy.contiguous()
+        if act == ACT_RELU:
             g = torch.ops.aten.threshold_backward(g, y, 0.0)
-        B, Cc, H, W = xc.shape
-        segs = Segs.make(B, [(H, W)])
+        Cc = x.shape[1]
         gx = gw = None
         if ctx.needs_input_grad[0]:
             weff = weight.detach() if scale is None else weight.detach() * scale.view(-1, 1, 1, 1)
-            gx = torch.empty_like(xc)
-            ops.dwconv3x3(_rows(g), ops.pack_dw_weight(weff.flip(2, 3)), _rows(gx), segs)
+            gx = torch.empty_like(x)
+            ops.dwconv3x3(_r(g), ops.pack_dw_weight(weff.flip(2, 3)), _r(gx), segs)
         if ctx.needs_input_grad[1]:
-            dw = ops.dwconv3x3_wgrad(_rows(xc), _rows(g), segs)             # [9][C]
+            dw = ops.dwconv3x3_wgrad(_r(x), _r(g), segs)                # [9][C]
             if scale is not None:
                 dw = dw * scale
             gw = dw.t().reshape(Cc, 1, 3, 3)
-        return gx, gw, None, None, None
+        return gx, gw, None, None, None, None
 
 
+def dw_rows(m: nn.Conv2d, x: torch.Tensor, segs: Segs, bn: Optional[nn.Module] = None, act: int = ACT_NONE) -> torch.Tensor:
+    scale = shift = None
+    if bn is not None:
+        scale, shift = _bn_fold(bn)
+    return _DwRows.apply(x, m.weight, scale, shift, segs, act)
+
+
+# --------------------------------------------------------------------------------------- GroupNorm + activation
+class _GroupNormRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, segs, G, eps, act):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ws = ops.groupnorm_workspace(segs, G, x.device)
+        gm, bt = gamma.detach().contiguous(), beta.detach().contiguous()
+        ops.groupnorm_act(_r(x), gm, bt, _r(y), segs, G, act, ws, eps)
+        ctx.save_for_backward(x, gm, bt, ws)
+        ctx.geom = (segs, G, eps, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gm, bt, ws = ctx.saved_tensors
+        segs, G, eps, act = ctx.geom
+        g = gy.contiguous()
+        gx = torch.empty_like(x)
+        dgamma, dbeta = ops.groupnorm_act_bwd(_r(x), _r(g), gm, bt, _r(gx), segs, G, act, ws, eps)
+        return gx, dgamma, dbeta, None, None, None, None
+
+
+def groupnorm_rows(gn: nn.GroupNorm, x: torch.Tensor, segs: Segs, act=ACT_NONE) -> torch.Tensor:
+    """act(GroupNorm(x)) per (level, image) on a rows buffer: two HIP launches forward, three backward."""
+    return _GroupNormRows.apply(x, gn.weight, gn.bias, segs, gn.num_groups, gn.eps, _act_id(act))
+
+
+# ------------------------------------------------------------------------------------ NCHW-shaped conveniences
 def _need_cuda(x: torch.Tensor) -> None:
     if not x.is_cuda:
         raise FdError("pytorch_object_detection_amd runs on the GPU only; there is no CPU fallback (got a CPU tensor)")
 
 
+def covered(m: nn.Conv2d, bn: Optional[nn.Module], x: torch.Tensor, pad_out: bool = False) -> bool:
+    return not _STOCK and (bn is None or bn_is_frozen(bn)) and (_dense_ok(m, x, pad_out) or _dw_ok(m, x))
+
+
 def conv_bn_act(m: nn.Conv2d, bn: Optional[nn.Module], x: torch.Tensor, act: int = ACT_NONE,
                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(bn(m(x)) + residual), act in {ACT_NONE, ACT_RELU}; one HIP launch when the layer is covered (module docstring)."""
+    """act(bn(m(x)) + residual) on NCHW-shaped tensors, act in {ACT_NONE, ACT_RELU}; one HIP launch when covered."""
     _need_cuda(x)
-    fold = bn is None or bn_is_frozen(bn)
-    if not _STOCK and fold and (_dense_ok(m, x) or _dw_ok(m, x)):
-        scale = shift = None
-        if bn is not None:
-            scale, shift = _bn_fold(bn)
+    if covered(m, bn, x) and not (m.groups != 1 and residual is not None):
+        B, _, H, W = x.shape
+        segs = Segs.make(B, [(H, W)])
         if m.groups == 1:
-            if m.bias is not None:
-                shift = m.bias if scale is None else m.bias * scale + shift
-            return _HipConv2d.apply(x, m.weight, scale, shift, residual, m.stride[0], _pad_of(m), m.dilation[0], act)
-        if m.bias is None and residual is None:
-            return _HipDwConv3x3.apply(x, m.weight, scale, shift, act)
-    if not _STOCK and bn is not None and not fold and (_dense_ok(m, x) or _dw_ok(m, x)):
+            y = conv_rows(m, to_rows(x), segs, bn, act, to_rows(residual) if residual is not None else None)
+            k, s, p, d = m.kernel_size[0], m.stride[0], _pad_of(m), m.dilation[0]
+            return from_rows(y, B, (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1)
+        return from_rows(dw_rows(m, to_rows(x), segs, bn, act), B, H, W)
+    if not _STOCK and bn is not None and not bn_is_frozen(bn) and covered(m, None, x):
         y = bn(conv_bn_act(m, None, x))                     # BN in training mode: conv on HIP, statistics stock
     else:
         y = m(x) if bn is None else bn(m(x))
@@ -231,9 +335,9 @@ def stem_frozen(trunk: nn.Module, x: torch.Tensor) -> torch.Tensor:
         ops.conv_call(Rows(x4), s_in, ops.pack_stem_weight(trunk.conv1.weight), Rows(y1), Cin=4, Cout=64, k=7, stride=2,
                       pad=3, scale=sc, shift=sf, act=ACT_RELU, stem=True)()
         H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
-        y2 = torch.empty(B, 64, H2, W2, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-        ops.maxpool(Rows(y1), _rows(y2), B, H1, W1, 3, 2, 1)
-    return y2
+        y2 = torch.empty(B * H2 * W2, 64, dtype=torch.float32, device=dev)
+        ops.maxpool(Rows(y1), Rows(y2), B, H1, W1, 3, 2, 1)
+    return from_rows(y2, B, H2, W2)
 
 
 def stem_is_frozen(trunk: nn.Module, x: torch.Tensor) -> bool:
