@@ -13,6 +13,7 @@ from ..._lib import FdError, Segs
 import torch.nn.functional as F
 
 from ...ops import ACT_RELU
+from ... import train_ops as T
 from ...train_ops import conv2d as tconv, conv_bn_act as cba
 from ..backbone.resnet50 import ResNet50, trunk_train_forward
 from ..modules.modules import ScaleExp, init_conv_kaiming, init_conv_random_normal
@@ -82,14 +83,35 @@ class HeadFCOS(PlannedModule):
         self.scale_exp = nn.ModuleList([ScaleExp(1.0) for _ in range(5)])
 
     def train_forward(self, inputs):
+        """Training-time autograd forward: the five levels as one rows buffer, every tower layer (3x3 conv, GroupNorm +
+        ReLU) and the predictors one HIP launch over the whole pyramid, forward and backward (train_ops)."""
+        x0 = inputs[0]
+        gns = [self.cls_branch[3 * k + 1] for k in range(4)] + [self.reg_branch[3 * k + 1] for k in range(4)]
+        if not T.covered(self.cls_branch[0], None, x0) or not all(T._gn_ok(g, x0) for g in gns):
+            return self._train_forward_stock(inputs)
+        f, segs = T.pyramid_rows(inputs)
+        c, r = f, f
+        for k in range(4):
+            c = T.groupnorm_rows(self.cls_branch[3 * k + 1], T.conv_rows(self.cls_branch[3 * k], c, segs), segs,
+                                 self.cls_branch[3 * k + 2])
+            r = T.groupnorm_rows(self.reg_branch[3 * k + 1], T.conv_rows(self.reg_branch[3 * k], r, segs), segs,
+                                 self.reg_branch[3 * k + 2])
+        cls = T.conv_rows(self.cls_logits, c, segs, pad_out=True)
+        rc = T.conv_rows(T.MergedConv(self.reg_pred, self.cnt_logits), r, segs, pad_out=True)  # [:, :4] boxes, [:, 4] centre-ness
+        cls_l = T.pyramid_split(cls, segs)
+        cnt_l = T.pyramid_split(rc[:, 4:5], segs)
+        reg_l = [torch.exp(t * self.scale_exp[i].scale) for i, t in enumerate(T.pyramid_split(rc[:, :4], segs))]
+        return cls_l, cnt_l, reg_l
+
+    def _train_forward_stock(self, inputs):
         cls_l, cnt_l, reg_l = [], [], []
         for i, f in enumerate(inputs):
             c, r = f, f
-            for k in range(4):                               # 3x3 conv (HIP) -> GroupNorm -> ReLU, four times per branch
+            for k in range(4):
                 c = self.cls_branch[3 * k + 2](self.cls_branch[3 * k + 1](tconv(self.cls_branch[3 * k], c)))
                 r = self.reg_branch[3 * k + 2](self.reg_branch[3 * k + 1](tconv(self.reg_branch[3 * k], r)))
             cls_l.append(tconv(self.cls_logits, c))
-            cnt_l.append(self.cnt_logits(r))                 # Cout = 1: stock op
+            cnt_l.append(self.cnt_logits(r))
             reg_l.append(torch.exp(tconv(self.reg_pred, r) * self.scale_exp[i].scale))
         return cls_l, cnt_l, reg_l
 

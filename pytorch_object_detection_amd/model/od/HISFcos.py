@@ -95,15 +95,6 @@ class HalfInvertedStageFPN(PlannedModule):
         return pyramid_out(pyr, segs)
 
 
-class _RegCnt:
-    """reg_pred (4) and cnt_logits (1) as one 5-output conv for train_ops.conv_rows (same geometry, same input)."""
-
-    def __init__(self, reg: nn.Conv2d, cnt: nn.Conv2d):
-        self.weight = torch.cat((reg.weight, cnt.weight), 0)
-        self.bias = torch.cat((reg.bias, cnt.bias), 0)
-        self.stride, self.padding, self.dilation, self.kernel_size = reg.stride, reg.padding, reg.dilation, reg.kernel_size
-
-
 class HISFCOSHead(PlannedModule):
     def __init__(self, feature: int, num_class: int, prior: float = 0.01):
         super().__init__()
@@ -139,7 +130,7 @@ class HISFCOSHead(PlannedModule):
         c = T.groupnorm_rows(self.cls_conv[1], T.conv_rows(self.cls_conv[0], z, segs), segs, self.cls_conv[2])
         r = T.groupnorm_rows(self.reg_conv[1], T.conv_rows(self.reg_conv[0], z, segs), segs, self.reg_conv[2])
         cls = T.conv_rows(self.cls_logits, c, segs, pad_out=True)
-        rc = T.conv_rows(_RegCnt(self.reg_pred, self.cnt_logits), r, segs, pad_out=True)     # [:, :4] boxes, [:, 4] centre-ness
+        rc = T.conv_rows(T.MergedConv(self.reg_pred, self.cnt_logits), r, segs, pad_out=True)     # [:, :4] boxes, [:, 4] centre-ness
         cls_l = T.pyramid_split(cls, segs)
         cnt_l = T.pyramid_split(rc[:, 4:5], segs)
         reg_l = [torch.exp(t * self.scale_exp[i].scale) for i, t in enumerate(T.pyramid_split(rc[:, :4], segs))]

@@ -215,6 +215,15 @@ def conv_rows(m: nn.Conv2d, x: torch.Tensor, segs: Segs, bn: Optional[nn.Module]
     return y[:, :Cout] if padn else y
 
 
+class MergedConv:
+    """Two convs with the same geometry and input (reg_pred 4 + cnt_logits 1) presented to conv_rows as one layer."""
+
+    def __init__(self, a: nn.Conv2d, b: nn.Conv2d):
+        self.weight = torch.cat((a.weight, b.weight), 0)
+        self.bias = torch.cat((a.bias, b.bias), 0) if a.bias is not None else None
+        self.stride, self.padding, self.dilation, self.kernel_size = a.stride, a.padding, a.dilation, a.kernel_size
+
+
 # --------------------------------------------------------------------------------------------- depthwise 3x3
 class _DwRows(torch.autograd.Function):
     """Depthwise 3x3 (stride 1, pad 1, no bias): y = act(dw(x, w) * scale + shift), scale / shift constants."""
