@@ -309,11 +309,20 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_partial_kernel(const floa
 
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_final_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                      int n, int nchunk) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    // 16 outputs x 16 chunk lanes per workgroup: lane j adds chunks j, j+16, ... in order, lanes are combined in order
+    __shared__ double red[256];
+    const int o = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;
     double s = 0.0;
-    for (int k = 0; k < nchunk; ++k) s += (double)part[(long)k * n + i];
-    dw[i] = (float)s;
+    if (i < n)
+        for (int k = j; k < nchunk; k += 16) s += (double)part[(long)k * n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (j == 0 && i < n) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += red[q * 16 + o];
+        dw[i] = (float)t;
+    }
 }
 
 static inline int dw_wgrad_chunks(long rows) {
@@ -345,7 +354,7 @@ extern "C" int32_t fd_dwconv3x3_bwd_weight_nhwc(const float* x, int32_t x_cs, in
     hipLaunchKernelGGL(dwconv3x3_wgrad_partial_kernel, dim3(nchunk, C4 / QW), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co,
                        dy, dy_cs, dy_co, C, QW, chunk_rows, tab, (float*)workspace);
     FD_CHECK_LAUNCH("fd_dwconv3x3_bwd_weight_nhwc (partial)");
-    hipLaunchKernelGGL(dwconv3x3_wgrad_final_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(dwconv3x3_wgrad_final_kernel, dim3((9 * C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, dw, 9 * C, nchunk);
     FD_CHECK_LAUNCH("fd_dwconv3x3_bwd_weight_nhwc (final)");
     return FD_OK;
@@ -403,7 +412,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int x_cs, int x_co,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ y, int y_cs, int y_co, int C, int G, float eps,
-                                                        int act, SegTab tab, const double* __restrict__ part) {
+                                                        int act, SegTab tab, const double* __restrict__ part,
+                                                        double* __restrict__ gstat) {
     __shared__ float s_a[1024], s_b[1024];  // per-channel scale / bias
     const int img = blockIdx.y;
     const int s = img / tab.s.batch, n = img - s * tab.s.batch;
@@ -429,6 +439,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         const float sc = rstd * gamma[c];
         s_a[c] = sc;
         s_b[c] = beta[c] - (float)mean * sc;
+        if (blockIdx.x == 0 && c == g * cg) {          // kept for the backward pass (fd_groupnorm_act_bwd_nhwc)
+            gstat[((long)img * G + g) * 2] = mean;
+            gstat[((long)img * G + g) * 2 + 1] = (double)rstd;
+        }
     }
     __syncthreads();
     const int C4 = C >> 2;
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 
 extern "C" int64_t fd_groupnorm_workspace_bytes(const fd_segs* segs, int32_t G) {
     if (!fd_segs_ok(segs) || G < 1) return -1;
-    return (int64_t)segs->nseg * segs->batch * GN_MAXCHUNK * G * 2 * (int64_t)sizeof(double);
+    return (int64_t)segs->nseg * segs->batch * (GN_MAXCHUNK + 1) * G * 2 * (int64_t)sizeof(double);   // partials + (mean, rstd)
 }
 
 extern "C" int32_t fd_groupnorm_act_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* gamma,
@@ -472,7 +486,7 @@ extern "C" int32_t fd_groupnorm_act_nhwc(const float* x, int32_t x_cs, int32_t x
     FD_CHECK_LAUNCH("fd_groupnorm (partial)");
     const int ablk = max(1, min(64, (maxhw * (C / 4) + 2047) / 2048));
     hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, imgs), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, gamma, beta, y,
-                       y_cs, y_co, C, G, eps, act, tab, (const double*)workspace);
+                       y_cs, y_co, C, G, eps, act, tab, (const double*)workspace, (double*)workspace + (long)imgs * GN_MAXCHUNK * G * 2);
     FD_CHECK_LAUNCH("fd_groupnorm (apply)");
     return FD_OK;
 }
@@ -491,21 +505,12 @@ __device__ __forceinline__ float fd_act_grad(float z, int act) {
     }
 }
 
-__device__ __forceinline__ void gn_channel_stats(const double* __restrict__ fpart, int img, int nchunk, int G, int cg, int HW,
-                                                 float eps, int C, int tid, float* s_mean, float* s_rstd) {
+__device__ __forceinline__ void gn_channel_stats(const double* __restrict__ gstat, int img, int G, int cg, int C, int tid,
+                                                 float* s_mean, float* s_rstd) {
     for (int c = tid; c < C; c += 256) {
-        const int g = c / cg;
-        double a = 0, b = 0;
-        for (int k = 0; k < nchunk; ++k) {
-            const double* p = fpart + (((long)img * GN_MAXCHUNK + k) * G + g) * 2;
-            a += p[0]; b += p[1];
-        }
-        const double cnt = (double)HW * cg;
-        const double mean = a / cnt;
-        double var = b / cnt - mean * mean;
-        if (var < 0) var = 0;
-        s_mean[c] = (float)mean;
-        s_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        const double* p = gstat + ((long)img * G + c / cg) * 2;
+        s_mean[c] = (float)p[0];
+        s_rstd[c] = (float)p[1];
     }
 }
 
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
     const int chunk = blockIdx.x;
     if (chunk >= nchunk) return;
     const int tid = threadIdx.x, cg = C / G;
-    gn_channel_stats(fpart, img, nchunk, G, cg, HW, eps, C, tid, s_mean, s_rstd);
+    gn_channel_stats(fpart, img, G, cg, C, tid, s_mean, s_rstd);
     __syncthreads();
     const int rows_per = (HW + nchunk - 1) / nchunk;
     const int r_begin = chunk * rows_per, r_end = min(HW, r_begin + rows_per);
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ dx, int dx_cs, int dx_co, int C, int G, float eps,
                                                             int act, SegTab tab, const double* __restrict__ fpart,
-                                                            const double* __restrict__ part, double* __restrict__ img_sums) {
+                                                            const double* __restrict__ img_sums) {
     __shared__ float s_mean[1024], s_rstd[1024], s_k1[1024], s_p[1024], s_q[1024];
     __shared__ double s_ga[1024], s_gb[1024];
     const int img = blockIdx.y;
@@ -576,17 +581,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const int nblk = gridDim.x;
     const int rows_per = (HW + nblk - 1) / nblk;
     const int r_begin = blockIdx.x * rows_per, r_end = min(HW, r_begin + rows_per);
-    if (r_begin >= r_end && blockIdx.x != 0) return;
+    if (r_begin >= r_end) return;
     const int cg = C / G, tid = threadIdx.x;
-    gn_channel_stats(fpart, img, nchunk, G, cg, HW, eps, C, tid, s_mean, s_rstd);
+    gn_channel_stats(fpart, img, G, cg, C, tid, s_mean, s_rstd);
     for (int c = tid; c < C; c += 256) {
-        double a = 0, b = 0;
-        for (int k = 0; k < nchunk; ++k) {
-            const double* p = part + ((long)img * GN_MAXCHUNK + k) * 2 * C;
-            a += p[c]; b += p[C + c];
-        }
-        if (blockIdx.x == 0) { img_sums[(long)img * 2 * C + c] = a; img_sums[(long)img * 2 * C + C + c] = b; }
-        s_ga[c] = a * (double)gamma[c]; s_gb[c] = b * (double)gamma[c];
+        s_ga[c] = img_sums[(long)img * 2 * C + c] * (double)gamma[c];
+        s_gb[c] = img_sums[(long)img * 2 * C + C + c] * (double)gamma[c];
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -618,6 +618,19 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
             o[e] = s_k1[c] * dz + s_p[c] * v[e] + s_q[c];
         }
         *reinterpret_cast<float4*>(dx + m * dx_cs + dx_co + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const double* __restrict__ part, double* __restrict__ img_sums, int C,
+                                                             SegTab tab) {
+    const int img = blockIdx.x;
+    const int s = img / tab.s.batch;
+    const int HW = tab.s.H[s] * tab.s.W[s];
+    const int nchunk = min(GN_MAXCHUNK, (HW + 63) / 64);
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        double a = 0;
+        for (int k = 0; k < nchunk; ++k) a += part[((long)img * GN_MAXCHUNK + k) * 2 * C + c];
+        img_sums[(long)img * 2 * C + c] = a;
     }
 }
 
@@ -658,13 +671,16 @@ extern "C" int32_t fd_groupnorm_act_bwd_nhwc(const float* x, int32_t x_cs, int32
     const int nchunk = min(GN_MAXCHUNK, (maxhw + 63) / 64);
     double* part = (double*)workspace;
     double* img_sums = part + (long)imgs * GN_MAXCHUNK * 2 * C;
+    const double* gstat = (const double*)fwd_workspace + (long)imgs * GN_MAXCHUNK * G * 2;   // (mean, rstd) left by the forward
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, imgs), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, gamma, beta, C,
-                       G, eps, act, tab, (const double*)fwd_workspace, part);
+                       G, eps, act, tab, gstat, part);
     FD_CHECK_LAUNCH("fd_groupnorm_bwd (partial)");
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(imgs), dim3(256), 0, st, (const double*)part, img_sums, C, tab);
+    FD_CHECK_LAUNCH("fd_groupnorm_bwd (reduce)");
     const int ablk = max(1, min(64, (maxhw * (C / 4) + 2047) / 2048));
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ablk, imgs), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, gamma, beta, dx,
-                       dx_cs, dx_co, C, G, eps, act, tab, (const double*)fwd_workspace, (const double*)part, img_sums);
+                       dx_cs, dx_co, C, G, eps, act, tab, gstat, (const double*)img_sums);
     FD_CHECK_LAUNCH("fd_groupnorm_bwd (apply)");
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)img_sums, dgamma, dbeta, C,
                        imgs);
