@@ -186,6 +186,50 @@ def fast_mode(model, head, clip, x, args, ref_res):
         model.conv_precision = None
 
 
+def train_step(dev, batch: int = 16, size: int = 512, steps: int = 5):
+    """Diagnostic (SURVEY Cfg4): one HISFCOS-R50 training step (forward, FCOSGenTargets, FCOSLoss('giou'), backward, SGD)
+    at the reference's VOC shape, with the HIP training kernels and with every layer routed to stock PyTorch-ROCm ops."""
+    from pytorch_object_detection_amd import train_ops
+    from pytorch_object_detection_amd.model.loss import FCOSLoss
+    from pytorch_object_detection_amd.model.modules.head import FCOSGenTargets
+    from pytorch_object_detection_amd.model.od import HalfInvertedStageFCOS
+    torch.manual_seed(0)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).to(dev).train()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    x = torch.randn(batch, 3, size, size, device=dev)
+    c = torch.rand(batch, 8, 2, device=dev) * (size - 112) + 50
+    s = torch.rand(batch, 8, 2, device=dev) * 150 + 20
+    gt = torch.cat([c - s / 2, c + s / 2], -1).clamp(0, size - 1)
+    labels = torch.randint(1, 21, (batch, 8), device=dev)
+    gen = FCOSGenTargets([8, 16, 32, 64, 128], [[-1, 32], [32, 96], [96, 192], [192, 384], [384, 9999999]])
+    crit = FCOSLoss("giou")
+
+    def one():
+        opt.zero_grad(set_to_none=True)
+        out = model(x)
+        losses = crit([out, gen([out, gt, labels])])
+        losses[-1].backward()
+        opt.step()
+        return float(losses[-1].detach())
+
+    res = {"batch": batch, "size": size, "classes": 20, "gt_boxes_per_image": 8, "loss": "giou", "optimizer": "SGD"}
+    for name, stock in (("hip_ms", False), ("stock_ops_ms", True)):
+        train_ops._STOCK = stock
+        try:
+            for _ in range(2):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            torch.cuda.synchronize()
+            res[name] = round((time.perf_counter() - t0) / steps * 1e3, 2)
+        finally:
+            train_ops._STOCK = False
+    res["images_per_sec"] = round(batch / (res["hip_ms"] * 1e-3), 1)
+    return res
+
+
 def layer_times(plan, x, path, reps=5):
     """Diagnostic: HIP-event time of every plan step (median of `reps`), with conv TFLOP/s where applicable."""
     plan.image_ref[0] = x
@@ -225,6 +269,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra opt-in f16x3 measurement")
     ap.add_argument("--save-tuning", action="store_true", help="write the conv tile table measured in this run back to tuned/gfx950_tiles.json")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the Cfg4 training-step diagnostic")
     ap.add_argument("--layer-times", default="", help="diagnostic: write per-plan-step timings (TSV) to this file and exit")
     args = ap.parse_args()
 
@@ -328,6 +373,8 @@ def main():
             line["fast_mode"] = fast_mode(model, head, clip, x, args, res)
         if world == 1:
             line["nms_micro"] = nms_micro(dev, args.batch, with_cpu=sd_cpu is not None)
+        if world == 1 and not args.no_train_step:
+            line["train_step"] = train_step(dev)
         if sd_cpu is not None:
             line["cpu_baseline"] = cpu_baseline(sd_cpu, args.classes, args.size)
         print(json.dumps(line), flush=True)
