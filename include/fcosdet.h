@@ -141,12 +141,19 @@ typedef struct fd_conv_wgrad_params {
     void* workspace; /* fd_conv_wgrad_workspace_bytes(out_rows, Cin, Cout, KH, KW) bytes, 16-B aligned */
     int64_t workspace_bytes;
     int32_t nsplit;  /* 0 = library chooses; else the pixel-range split count (workspace >= nsplit * |dw| * 4 bytes) */
-    int32_t reserved;
+    int32_t layout;  /* dw layout: 0 = [Cout][KH][KW][Cin] (OHWI), 1 = [Cout][Cin][KH][KW] (OIHW, torch's parameter layout) */
+    const float* scale; /* optional [Cout]: dw[co] *= scale[co] (a frozen BatchNorm folded into the forward epilogue) */
     fd_segs in;      /* forward INPUT geometry */
 } fd_conv_wgrad_params;
 
 int64_t fd_conv_wgrad_workspace_bytes(int64_t out_rows, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
 int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_stream_t stream);
+/* OIHW fp32 weights -> the [N][K/32][KH][KW][32] layout fd_conv2d_nhwc_f32 reads, in one pass (the per-step weight
+ * preparation of the train step; plans pack once at build time).  mode 0: forward weights (N = Cout, K = Cin, Cin % 32
+ * == 0).  mode 1: weights of the stride-1 data-gradient conv (N = Cin, K = Cout, Cout % 32 == 0):
+ * w'[ci][co][r][q] = w[co][ci][KH-1-r][KW-1-q] * (scale ? scale[co] : 1). */
+int32_t fd_pack_conv_weight_f32(const float* w, const float* scale, float* out, int32_t Cout, int32_t Cin, int32_t KH,
+                                int32_t KW, int32_t mode, fd_stream_t stream);
 
 /* [N][3][H][W] fp32 (NCHW, the reference's input layout, dataset/voc.py:141-173) -> [N][H][W][4] (c=3 zero) */
 int32_t fd_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, fd_stream_t stream);
@@ -184,14 +191,15 @@ int32_t fd_dwconv3x3_nhwc(const float* x, int32_t x_cs, int32_t x_co, const floa
                           const fd_segs* segs, fd_stream_t stream);
 
 /* Weight gradient of the depthwise 3x3 conv above (stride 1, pad 1): dw[t][c] = sum_m x[pix(m, t)][c] * dy[m][c],
- * t = 3*r + q, same [9][C] layout as `w`.  Replaces the depthwise half of torch's convolution_backward in the
+ * t = 3*r + q, same [9][C] layout as `w` (layout 0) or torch's [C][1][3][3] (layout 1); optional scale[C] multiplies
+ * the result per channel (a frozen BatchNorm folded into the forward).  Replaces the depthwise half of torch's convolution_backward in the
  * reference's train step (train.py:175-181, modules.py:40-49).  The data gradient is fd_dwconv3x3_nhwc itself with the
  * taps reversed (w'[t] = w[8-t]).  Deterministic: fixed row partition, fixed-order fp64 final sum.
  * workspace: fd_dwconv3x3_wgrad_workspace_bytes(segs, C).  C/4 must divide 256 or be a multiple of 256. */
 int64_t fd_dwconv3x3_wgrad_workspace_bytes(const fd_segs* segs, int32_t C);
 int32_t fd_dwconv3x3_bwd_weight_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs,
-                                     int32_t dy_co, float* dw, int32_t C, const fd_segs* segs, void* workspace,
-                                     fd_stream_t stream);
+                                     int32_t dy_co, float* dw, int32_t C, const float* scale, int32_t layout,
+                                     const fd_segs* segs, void* workspace, fd_stream_t stream);
 
 /* GroupNorm(G, C) + activation (nn.GroupNorm in HISFCOSHead / HeadFCOS, HISFcos.py:190-204, Fcos.py:102-109).
  * Two launches: partial moments (fp64 accumulation, fixed order) then normalise+affine+act.

@@ -61,8 +61,8 @@ class WgradParams(C.Structure):
                 ("x_cs", C.c_int32), ("x_co", C.c_int32), ("dy_cs", C.c_int32), ("dy_co", C.c_int32),
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("dil", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("nsplit", C.c_int32), ("reserved", C.c_int32),
-                ("segs", Segs)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("nsplit", C.c_int32), ("layout", C.c_int32),
+                ("scale", C.c_void_p), ("segs", Segs)]
 
 
 _lib = None
@@ -74,6 +74,7 @@ _SIGS = {
     "fd_conv2d_nhwc_f32": (_I, [C.POINTER(ConvParams), _P]),
     "fd_conv_workspace_bytes": (_L, [_L, _I, _I]),
     "fd_conv_wgrad_workspace_bytes": (_L, [_L, _I, _I, _I, _I]),
+    "fd_pack_conv_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fd_conv2d_bwd_weight_f32": (_I, [C.POINTER(WgradParams), _P]),
     "fd_nchw3_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _P]),
     "fd_nhwc_to_nchw": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),
@@ -83,7 +84,7 @@ _SIGS = {
     "fd_upsample2x_add_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fd_dwconv3x3_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(Segs), _P]),
     "fd_dwconv3x3_wgrad_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
-    "fd_dwconv3x3_bwd_weight_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, C.POINTER(Segs), _P, _P]),
+    "fd_dwconv3x3_bwd_weight_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, C.POINTER(Segs), _P, _P]),
     "fd_groupnorm_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
     "fd_groupnorm_act_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _I, C.POINTER(Segs), _P, _P]),
     "fd_groupnorm_bwd_workspace_bytes": (_L, [C.POINTER(Segs), _I]),

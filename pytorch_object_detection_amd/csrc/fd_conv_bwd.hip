@@ -180,16 +180,71 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
 }
 
+// ordered sum of the split slabs (+ optional per-output-channel scale) written as OHWI (layout 0) or OIHW (layout 1)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4,
-                                                            int nsplit, long slab) {
+                                                            int nsplit, long slab, const float* __restrict__ scale, int layout,
+                                                            int Cin, int ntaps) {
+    const int Ktot = Cin * ntaps;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 v = reinterpret_cast<const float4*>(ws)[i];
         for (int s = 1; s < nsplit; ++s) {
             const float4 u = reinterpret_cast<const float4*>(ws + s * slab)[i];
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
-        reinterpret_cast<float4*>(dw)[i] = v;
+        const long e = 4 * i;                         // element index in [co][tap][ci]; Cin % 4 == 0 keeps a quad inside one tap
+        const int co = (int)(e / Ktot);
+        if (scale) { const float sc = scale[co]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+        if (layout == 0) {
+            reinterpret_cast<float4*>(dw)[i] = v;
+        } else {
+            const int r = (int)(e - (long)co * Ktot);
+            const int tap = r / Cin, ci = r - tap * Cin;
+            float* o = dw + ((long)co * Cin + ci) * ntaps + tap;
+            o[0] = v.x; o[ntaps] = v.y; o[2 * ntaps] = v.z; o[3 * ntaps] = v.w;
+        }
     }
+}
+
+// framework OIHW weights -> the conv kernel's [N][K/32][KH][KW][32] layout in one pass.
+// mode 0: forward weights (N = Cout, K = Cin).  mode 1: weights of the stride-1 data-gradient conv (N = Cin, K = Cout):
+// w'[ci][co][r][q] = w[co][ci][KH-1-r][KW-1-q] * scale[co].
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                           float* __restrict__ out, int Cout, int Cin, int KH, int KW, int mode,
+                                                           long total) {
+    const int taps = KH * KW;
+    const int N = mode ? Cin : Cout, K = mode ? Cout : Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c32 = (int)(i & 31);
+        long t = i >> 5;
+        const int tap = (int)(t % taps); t /= taps;
+        const int chunk = (int)(t % (K / 32));
+        const int n = (int)(t / (K / 32));
+        const int k = chunk * 32 + c32;
+        float v;
+        if (mode == 0) {
+            v = w[((long)n * Cin + k) * taps + tap];
+        } else {
+            v = w[((long)k * Cin + n) * taps + (taps - 1 - tap)];
+            if (scale) v *= scale[k];
+        }
+        out[i] = v;
+    }
+    (void)N;
+}
+
+extern "C" int32_t fd_pack_conv_weight_f32(const float* w, const float* scale, float* out, int32_t Cout, int32_t Cin,
+                                           int32_t KH, int32_t KW, int32_t mode, fd_stream_t stream) {
+    FD_REQUIRE(w && out && Cout >= 1 && Cin >= 1 && KH >= 1 && KW >= 1 && (mode == 0 || mode == 1), FD_E_INVAL,
+               "fd_pack_conv_weight: bad arguments");
+    FD_REQUIRE((mode == 0 ? Cin : Cout) % 32 == 0, FD_E_UNSUPPORTED,
+               "fd_pack_conv_weight: the reduction width (%d) must be a multiple of 32", mode == 0 ? Cin : Cout);
+    const long total = (long)Cout * Cin * KH * KW;
+    long g = (total + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, scale, out, Cout, Cin, KH, KW,
+                       mode, total);
+    FD_CHECK_LAUNCH("fd_pack_conv_weight_f32");
+    return FD_OK;
 }
 
 static void magic_div(int d, unsigned& m, int& sh) {
@@ -282,7 +337,9 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
     a.slab = (long)p->Cout * a.Ktot;
     FD_REQUIRE(p->workspace_bytes >= (int64_t)nsplit * a.slab * 4, FD_E_INVAL,
                "fd_conv2d_bwd_weight: workspace too small (need fd_conv_wgrad_workspace_bytes())");
-    a.out = (nsplit == 1) ? p->dw : (float*)p->workspace;
+    FD_REQUIRE(p->layout == 0 || p->layout == 1, FD_E_INVAL, "fd_conv2d_bwd_weight: layout must be 0 (OHWI) or 1 (OIHW)");
+    const bool need_reduce = nsplit > 1 || p->layout != 0 || p->scale != nullptr;
+    a.out = need_reduce ? (float*)p->workspace : p->dw;
     const dim3 grid(tiles, (unsigned)((mo + a.rows_per_split - 1) / a.rows_per_split));
     const bool one = p->in.nseg == 1;
     if (bn == 128 && one) hipLaunchKernelGGL((conv_wgrad_kernel<128, true>), grid, dim3(256), 0, stream, a);
@@ -290,12 +347,12 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
     else if (one) hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), grid, dim3(256), 0, stream, a);
     FD_CHECK_LAUNCH("fd_conv2d_bwd_weight");
-    if (nsplit > 1) {
+    if (need_reduce) {
         const long n4 = a.slab / 4;
         long g = (n4 + 255) / 256;
         if (g > 8192) g = 8192;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)p->workspace, p->dw, n4,
-                           (int)grid.y, a.slab);
+                           (int)grid.y, a.slab, p->scale, p->layout, p->Cin, a.ntaps);
         FD_CHECK_LAUNCH("fd_conv2d_bwd_weight (reduce)");
     }
     return FD_OK;

@@ -308,7 +308,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_partial_kernel(const floa
 }
 
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_final_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                     int n, int nchunk) {
+                                                                     int n, int nchunk, const float* __restrict__ scale,
+                                                                     int layout, int C) {
     // 16 outputs x 16 chunk lanes per workgroup: lane j adds chunks j, j+16, ... in order, lanes are combined in order
     __shared__ double red[256];
     const int o = threadIdx.x & 15, j = threadIdx.x >> 4;
@@ -321,7 +322,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_final_kernel(const float*
     if (j == 0 && i < n) {
         double t = 0.0;
         for (int q = 0; q < 16; ++q) t += red[q * 16 + o];
-        dw[i] = (float)t;
+        const int tap = i / C, c = i - tap * C;
+        float v = (float)t;
+        if (scale) v *= scale[c];
+        dw[layout ? c * 9 + tap : i] = v;
     }
 }
 
@@ -338,8 +342,8 @@ extern "C" int64_t fd_dwconv3x3_wgrad_workspace_bytes(const fd_segs* segs, int32
 }
 
 extern "C" int32_t fd_dwconv3x3_bwd_weight_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs,
-                                                int32_t dy_co, float* dw, int32_t C, const fd_segs* segs, void* workspace,
-                                                fd_stream_t stream) {
+                                                int32_t dy_co, float* dw, int32_t C, const float* scale, int32_t layout,
+                                                const fd_segs* segs, void* workspace, fd_stream_t stream) {
     FD_REQUIRE(fd_segs_ok(segs), FD_E_INVAL, "fd_dwconv3x3_bwd_weight: bad segment table");
     FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(dy, dy_cs, dy_co, C) && dw && workspace && ((uintptr_t)workspace & 15) == 0,
                FD_E_INVAL, "fd_dwconv3x3_bwd_weight: channel views must be 4-aligned (C=%d)", C);
@@ -355,7 +359,7 @@ extern "C" int32_t fd_dwconv3x3_bwd_weight_nhwc(const float* x, int32_t x_cs, in
                        dy, dy_cs, dy_co, C, QW, chunk_rows, tab, (float*)workspace);
     FD_CHECK_LAUNCH("fd_dwconv3x3_bwd_weight_nhwc (partial)");
     hipLaunchKernelGGL(dwconv3x3_wgrad_final_kernel, dim3((9 * C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)workspace, dw, 9 * C, nchunk);
+                       (const float*)workspace, dw, 9 * C, nchunk, scale, layout, C);
     FD_CHECK_LAUNCH("fd_dwconv3x3_bwd_weight_nhwc (final)");
     return FD_OK;
 }

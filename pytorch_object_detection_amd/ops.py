@@ -245,15 +245,18 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
 
 
 def conv_wgrad(x: Rows, dy: Rows, segs_in: Segs, *, Cin: int, Cout: int, k: int, stride: int = 1, pad: int = 0,
-               dil: int = 1, nsplit: int = 0) -> torch.Tensor:
-    """Weight gradient [Cout, k, k, Cin] (OHWI) of conv(x) w.r.t. its weights given dy (rows in output geometry)."""
+               dil: int = 1, nsplit: int = 0, scale: Optional[torch.Tensor] = None, oihw: bool = False) -> torch.Tensor:
+    """Weight gradient of conv(x) w.r.t. its weights given dy (rows in output geometry): [Cout, k, k, Cin] (OHWI), or
+    torch's [Cout, Cin, k, k] with oihw=True; `scale` [Cout] multiplies it per output channel (folded frozen BN)."""
     out_rows = conv_out_segs(segs_in, k, stride, pad, dil).rows
     dev = x.buf.device
-    dw = torch.empty(Cout, k, k, Cin, dtype=torch.float32, device=dev)
+    dw = torch.empty((Cout, Cin, k, k) if oihw else (Cout, k, k, Cin), dtype=torch.float32, device=dev)
     nb = _lib.lib().fd_conv_wgrad_workspace_bytes(out_rows, Cin, Cout, k, k) if nsplit <= 0 else nsplit * dw.numel() * 4
     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=dev)
     p = _lib.WgradParams()
     p.nsplit = max(nsplit, 0)
+    p.layout = 1 if oihw else 0
+    p.scale = scale.data_ptr() if scale is not None else None
     p.x, p.dy, p.dw = x.ptr, dy.ptr, dw.data_ptr()
     p.x_cs, p.x_co, p.dy_cs, p.dy_co = x.cs, x.co, dy.cs, dy.co
     p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, k, stride, pad, dil
@@ -261,6 +264,17 @@ def conv_wgrad(x: Rows, dy: Rows, segs_in: Segs, *, Cin: int, Cout: int, k: int,
     p.segs = segs_in
     check(_lib.lib().fd_conv2d_bwd_weight_f32(C.byref(p), _stream()), "fd_conv2d_bwd_weight_f32")
     return dw
+
+
+def pack_conv_weight_hip(w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False) -> torch.Tensor:
+    """pack_conv_weight (dgrad=False) or dgrad_weight with a per-output-channel scale (dgrad=True) as one HIP launch."""
+    w = w.detach().contiguous()
+    co, ci, kh, kw = w.shape
+    out = torch.empty((ci, co // 32, kh, kw, 32) if dgrad else (co, ci // 32, kh, kw, 32), dtype=torch.float32, device=w.device)
+    check(_lib.lib().fd_pack_conv_weight_f32(w.data_ptr(), scale.data_ptr() if (scale is not None and dgrad) else None,
+                                             out.data_ptr(), co, ci, kh, kw, 1 if dgrad else 0, _stream()),
+          "fd_pack_conv_weight_f32")
+    return out
 
 
 def dgrad_weight(w: torch.Tensor) -> torch.Tensor:
@@ -322,15 +336,16 @@ def dwconv3x3(x: Rows, w9c: torch.Tensor, y: Rows, segs: Segs, scale=None, shift
                                        C.byref(segs), _stream()), "fd_dwconv3x3_nhwc")
 
 
-def dwconv3x3_wgrad(x: Rows, dy: Rows, segs: Segs) -> torch.Tensor:
-    """Weight gradient [9][C] of the depthwise 3x3 conv (stride 1, pad 1) given dy."""
+def dwconv3x3_wgrad(x: Rows, dy: Rows, segs: Segs, scale: Optional[torch.Tensor] = None, torch_layout: bool = False) -> torch.Tensor:
+    """Weight gradient of the depthwise 3x3 conv (stride 1, pad 1) given dy: [9][C], or [C][1][3][3] with torch_layout."""
     dev = x.buf.device
     nb = _lib.lib().fd_dwconv3x3_wgrad_workspace_bytes(C.byref(segs), x.C)
     if nb < 0:
         raise FdError("fd_dwconv3x3_wgrad_workspace_bytes: bad arguments")
     ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
-    dw = torch.empty(9, x.C, dtype=torch.float32, device=dev)
+    dw = torch.empty((x.C, 1, 3, 3) if torch_layout else (9, x.C), dtype=torch.float32, device=dev)
     check(_lib.lib().fd_dwconv3x3_bwd_weight_nhwc(x.ptr, x.cs, x.co, dy.ptr, dy.cs, dy.co, dw.data_ptr(), x.C,
+                                                  scale.data_ptr() if scale is not None else None, 1 if torch_layout else 0,
                                                   C.byref(segs), ws.data_ptr(), _stream()), "fd_dwconv3x3_bwd_weight_nhwc")
     return dw
 

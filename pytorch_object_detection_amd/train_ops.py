@@ -30,6 +30,11 @@ from . import _lib, ops
 from ._lib import FdError, Segs
 from .ops import ACT_NONE, ACT_RELU, ACT_SILU, Rows
 
+# Under torch.autocast (the reference trains with AMP when cfg['model']['amp'] is set, train.py:175) the HIP nodes keep
+# computing in fp32: inputs are cast up on entry, autocast is off inside, gradients come back in fp32.
+_fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 _STOCK = os.environ.get("FD_TRAIN_STOCK_CONV") == "1"   # diagnostic: route every layer to the stock ops (timing comparisons)
 STATS = {"cl_copies": 0}                                 # activation-sized layout copies made on entry (should stay 0)
 
@@ -79,20 +84,25 @@ def _square(m: nn.Conv2d) -> bool:
             and (isinstance(m.padding, str) or m.padding[0] == m.padding[1]) and m.padding_mode == "zeros")
 
 
+def _f32(x: torch.Tensor) -> bool:
+    """fp32 data, or any float data while autocast is on (the nodes cast their inputs up to fp32 then)."""
+    return x.dtype == torch.float32 or (x.is_floating_point() and torch.is_autocast_enabled())
+
+
 def _dense_ok(m: nn.Conv2d, x: torch.Tensor, pad_out: bool = False) -> bool:
     return (m.groups == 1 and m.in_channels % 32 == 0 and (pad_out or m.out_channels % 4 == 0) and _square(m)
-            and x.dtype == torch.float32 and m.weight.dtype == torch.float32)
+            and _f32(x) and m.weight.dtype == torch.float32)
 
 
 def _dw_ok(m: nn.Conv2d, x: torch.Tensor) -> bool:
     c4 = m.in_channels // 4
     return (m.groups == m.in_channels == m.out_channels and m.in_channels % 4 == 0 and m.kernel_size == (3, 3)
             and m.stride == (1, 1) and m.dilation == (1, 1) and _pad_of(m) == 1 and m.padding_mode == "zeros"
-            and m.bias is None and ((c4 < 256 and 256 % c4 == 0) or c4 % 256 == 0) and x.dtype == torch.float32)
+            and m.bias is None and ((c4 < 256 and 256 % c4 == 0) or c4 % 256 == 0) and _f32(x))
 
 
 def _gn_ok(gn: nn.Module, x: torch.Tensor) -> bool:
-    if not isinstance(gn, nn.GroupNorm) or not gn.affine or x.dtype != torch.float32:
+    if not isinstance(gn, nn.GroupNorm) or not gn.affine or not _f32(x):
         return False
     Cc = gn.num_channels
     return Cc % 4 == 0 and Cc <= 1024 and 256 % (Cc // 4) == 0 and Cc % gn.num_groups == 0
@@ -127,10 +137,10 @@ def _act_id(act) -> int:
 
 
 # ------------------------------------------------------------------------------------------- dense convolution
-def _conv_launch(x: torch.Tensor, segs: Segs, w_oihw: torch.Tensor, y: torch.Tensor, *, k, stride, pad, dil, scale=None,
+def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.Tensor, *, k, stride, pad, dil, scale=None,
                  shift=None, res: Optional[torch.Tensor] = None, act=ACT_NONE) -> None:
-    """y = act(conv(x, w) * scale + shift + res) on contiguous rows buffers."""
-    Cin, Cout = x.shape[1], w_oihw.shape[0]
+    """y = act(conv(x, w) * scale + shift + res) on contiguous rows buffers; w_packed from ops.pack_conv_weight_hip."""
+    Cin, Cout = x.shape[1], w_packed.shape[0]
     out_rows = y.shape[0]
     code = ops.heuristic_conv(out_rows, Cout, (Cin // 32) * k * k, True)
     tile, ksplit = code & 0xFF, max(1, code >> 8)
@@ -138,7 +148,7 @@ def _conv_launch(x: torch.Tensor, segs: Segs, w_oihw: torch.Tensor, y: torch.Ten
     if ksplit > 1:
         nb = _lib.lib().fd_conv_workspace_bytes(out_rows, Cout, ksplit)
         ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=x.device)
-    ops.conv_call(_r(x), segs, ops.pack_conv_weight(w_oihw), _r(y), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad,
+    ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad,
                   dil=dil, scale=scale, shift=shift, res=_r(res) if res is not None else None, act=act, tile=tile,
                   ksplit=ksplit, workspace=ws)()
 
@@ -147,12 +157,13 @@ class _ConvRows(torch.autograd.Function):
     """y = act(conv(x, w) * scale + shift + residual) on rows; scale is a constant (frozen BN), shift may need a gradient."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, x, weight, scale, shift, residual, segs, stride, pad, dil, act):
         x = x.contiguous()
         Cout, _, k, _ = weight.shape
         so = ops.conv_out_segs(segs, k, stride, pad, dil)
         y = torch.empty(so.rows, Cout, dtype=torch.float32, device=x.device)
-        _conv_launch(x, segs, weight.detach(), y, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
+        _conv_launch(x, segs, ops.pack_conv_weight_hip(weight), y, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                      shift=shift.detach().contiguous() if shift is not None else None,
                      res=residual.contiguous() if residual is not None else None, act=act)
         ctx.save_for_backward(x, weight, scale, y if act == ACT_RELU else None)
@@ -160,6 +171,7 @@ class _ConvRows(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bwd
     def backward(ctx, gy):
         x, weight, scale, y = ctx.saved_tensors
         segs, so, stride, pad, dil, act = ctx.geom
@@ -172,11 +184,12 @@ class _ConvRows(torch.autograd.Function):
         if ctx.needs_input_grad[4]:
             gres = g
         if ctx.needs_input_grad[0]:
-            weff = weight.detach() if scale is None else weight.detach() * scale.view(-1, 1, 1, 1)
             if stride == 1 and Cout % 32 == 0:
                 gx = torch.empty_like(x)
-                _conv_launch(g, so, weff.flip(2, 3).transpose(0, 1), gx, k=k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
+                _conv_launch(g, so, ops.pack_conv_weight_hip(weight, scale, dgrad=True), gx, k=k, stride=1,
+                             pad=dil * (k - 1) - pad, dil=dil)
             elif segs.nseg == 1:  # strided layers: stock op for the data gradient (single level only)
+                weff = weight.detach() if scale is None else weight.detach() * scale.view(-1, 1, 1, 1)
                 B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
                 gx4 = torch.ops.aten.convolution_backward(from_rows(g, B, Ho, Wo), from_rows(x, B, H, W), weff, None,
                                                           [stride, stride], [pad, pad], [dil, dil], False, [0, 0], 1,
@@ -185,10 +198,8 @@ class _ConvRows(torch.autograd.Function):
             else:
                 raise FdError("data gradient of a strided / narrow conv over a pyramid is not supported (pad Cout to 32)")
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(_r(x), _r(g), segs, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil)
-            if scale is not None:
-                dw = dw * scale.view(-1, 1, 1, 1)
-            gw = dw.permute(0, 3, 1, 2)                      # OHWI -> OIHW view
+            gw = ops.conv_wgrad(_r(x), _r(g), segs, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
+                                oihw=True)
         if ctx.needs_input_grad[3]:
             gshift = g.sum(dim=0)
         return gx, gw, None, gshift, gres, None, None, None, None, None
@@ -229,6 +240,7 @@ class _DwRows(torch.autograd.Function):
     """Depthwise 3x3 (stride 1, pad 1, no bias): y = act(dw(x, w) * scale + shift), scale / shift constants."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, x, weight, scale, shift, segs, act):
         x = x.contiguous()
         y = torch.empty_like(x)
@@ -238,6 +250,7 @@ class _DwRows(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bwd
     def backward(ctx, gy):
         x, weight, scale, y = ctx.saved_tensors
         segs, act = ctx.geom
@@ -251,10 +264,7 @@ class _DwRows(torch.autograd.Function):
             gx = torch.empty_like(x)
             ops.dwconv3x3(_r(g), ops.pack_dw_weight(weff.flip(2, 3)), _r(gx), segs)
         if ctx.needs_input_grad[1]:
-            dw = ops.dwconv3x3_wgrad(_r(x), _r(g), segs)                # [9][C]
-            if scale is not None:
-                dw = dw * scale
-            gw = dw.t().reshape(Cc, 1, 3, 3)
+            gw = ops.dwconv3x3_wgrad(_r(x), _r(g), segs, scale, torch_layout=True)
         return gx, gw, None, None, None, None
 
 
@@ -268,6 +278,7 @@ def dw_rows(m: nn.Conv2d, x: torch.Tensor, segs: Segs, bn: Optional[nn.Module] =
 # --------------------------------------------------------------------------------------- GroupNorm + activation
 class _GroupNormRows(torch.autograd.Function):
     @staticmethod
+    @_fwd32
     def forward(ctx, x, gamma, beta, segs, G, eps, act):
         x = x.contiguous()
         y = torch.empty_like(x)
@@ -279,6 +290,7 @@ class _GroupNormRows(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bwd
     def backward(ctx, gy):
         x, gm, bt, ws = ctx.saved_tensors
         segs, G, eps, act = ctx.geom
@@ -335,7 +347,7 @@ def stem_frozen(trunk: nn.Module, x: torch.Tensor) -> torch.Tensor:
     dev = x.device
     with torch.no_grad():
         x4 = torch.empty(B * H * W, 4, dtype=torch.float32, device=dev)
-        ops.nchw3_to_nhwc4(x.contiguous(), x4)
+        ops.nchw3_to_nhwc4(x.float().contiguous(), x4)
         sc, sf = _bn_fold(trunk.bn1)
         s_in = Segs.make(B, [(H, W)])
         s1 = ops.conv_out_segs(s_in, 7, 2, 3, 1)
@@ -351,4 +363,4 @@ def stem_frozen(trunk: nn.Module, x: torch.Tensor) -> torch.Tensor:
 
 def stem_is_frozen(trunk: nn.Module, x: torch.Tensor) -> bool:
     return (not _STOCK and bn_is_frozen(trunk.bn1) and not trunk.conv1.weight.requires_grad and not x.requires_grad
-            and x.dtype == torch.float32 and tuple(trunk.conv1.weight.shape) == (64, 3, 7, 7))
+            and _f32(x) and tuple(trunk.conv1.weight.shape) == (64, 3, 7, 7))

@@ -429,3 +429,33 @@ def test_groupnorm_rows_autograd(C, G, act):
     for a, b in ((g2.weight.grad, gn.weight.grad), (g2.bias.grad, gn.bias.grad)):
         scale = float(b.abs().max())
         np.testing.assert_allclose(a.cpu().numpy() / scale, b.numpy() / scale, atol=5e-5)
+
+
+@pytest.mark.parametrize("shape", [(64, 96, 3), (256, 64, 1), (32, 160, 5)])
+def test_pack_conv_weight_kernel(shape):
+    """fd_pack_conv_weight_f32 == the torch packers, bit for bit (forward layout and flipped / transposed / scaled dgrad layout)."""
+    Cout, Cin, k = shape
+    gen = torch.Generator().manual_seed(Cout + Cin + k)
+    w = torch.randn(Cout, Cin, k, k, generator=gen).to(DEV)
+    sc = (torch.rand(Cout, generator=gen) + 0.5).to(DEV)
+    if Cin % 32 == 0:
+        assert torch.equal(ops.pack_conv_weight_hip(w), ops.pack_conv_weight(w))
+    if Cout % 32 == 0:
+        assert torch.equal(ops.pack_conv_weight_hip(w, dgrad=True), ops.dgrad_weight(w))
+        assert torch.equal(ops.pack_conv_weight_hip(w, sc, dgrad=True), ops.dgrad_weight(w * sc.view(-1, 1, 1, 1)))
+
+
+def test_conv_wgrad_oihw_scaled():
+    gen = torch.Generator().manual_seed(5)
+    B, Cin, Cout, H, W = 2, 64, 96, 9, 7
+    x = ops.Rows(torch.randn(B * H * W, Cin, generator=gen).to(DEV))
+    dy = ops.Rows(torch.randn(B * H * W, Cout, generator=gen).to(DEV))
+    sc = (torch.rand(Cout, generator=gen) + 0.5).to(DEV)
+    segs = Segs.make(B, [(H, W)])
+    ref = ops.conv_wgrad(x, dy, segs, Cin=Cin, Cout=Cout, k=3, pad=1)                       # OHWI
+    got = ops.conv_wgrad(x, dy, segs, Cin=Cin, Cout=Cout, k=3, pad=1, scale=sc, oihw=True)
+    assert got.shape == (Cout, Cin, 3, 3) and got.is_contiguous()
+    np.testing.assert_allclose(got.cpu().numpy(), (ref * sc.view(-1, 1, 1, 1)).permute(0, 3, 1, 2).cpu().numpy(), rtol=1e-6, atol=1e-6)
+    d0 = ops.dwconv3x3_wgrad(x, ops.Rows(dy.buf[:, :Cin].contiguous()), segs)
+    d1 = ops.dwconv3x3_wgrad(x, ops.Rows(dy.buf[:, :Cin].contiguous()), segs, sc[:Cin].contiguous(), torch_layout=True)
+    np.testing.assert_allclose(d1.cpu().numpy(), (d0 * sc[:Cin]).t().reshape(Cin, 1, 3, 3).cpu().numpy(), rtol=1e-6, atol=1e-6)

@@ -143,3 +143,43 @@ def test_pyramid_head_matches_per_level_head(which):
     for n in p1:
         s = float(p2[n].abs().max()) + 1e-12
         np.testing.assert_allclose(p1[n].cpu().numpy() / s, p2[n].cpu().numpy() / s, atol=3e-4, err_msg=n)
+
+
+def test_amp_and_ddp_train_step():
+    """The reference's loop shape (train.py:101-103,175-181): DistributedDataParallel(find_unused_parameters=True) around
+    the model, torch.autocast + GradScaler around the step.  World size 1 on RCCL: the DDP reducer hooks and the AMP
+    decorators of the HIP autograd nodes are exercised; the nodes keep computing in fp32."""
+    import os
+    import torch.distributed as dist
+    from pytorch_object_detection_amd.model.od import HalfInvertedStageFCOS
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).to(DEV)
+        ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
+        ddp.train()
+        opt = torch.optim.SGD([p for p in ddp.parameters() if p.requires_grad], lr=1e-3, momentum=0.9)
+        scaler = torch.amp.GradScaler("cuda", enabled=True)
+        x = torch.randn(2, 3, 128, 128, device=DEV)
+        gt = torch.tensor([[[10., 12., 60., 70.]], [[30., 20., 110., 100.]]], device=DEV)
+        labels = torch.tensor([[3], [7]], device=DEV)
+        gen = FCOSGenTargets([8, 16, 32, 64, 128], [[-1, 64], [64, 128], [128, 256], [256, 512], [512, 999999]])
+        crit = FCOSLoss("giou")
+        vals = []
+        for amp in (False, True):
+            opt.zero_grad()
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                out = ddp(x)
+                assert out[0][0].dtype == torch.float32          # HIP nodes stay fp32 under autocast
+                losses = crit([out, gen([out, gt, labels])])
+            scaler.scale(losses[-1].mean()).backward()
+            g = model.head.cls_conv[0].weight.grad
+            assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+            vals.append(float(losses[-1].detach()))
+            scaler.step(opt)
+            scaler.update()
+        assert all(np.isfinite(v) for v in vals)
+    finally:
+        dist.destroy_process_group()
