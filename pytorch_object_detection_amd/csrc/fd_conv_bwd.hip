@@ -38,10 +38,17 @@ __device__ __forceinline__ int fast_div(int n, unsigned m, int sh) {
     return m ? (int)(__umulhi((unsigned)n, m) >> sh) : n;
 }
 
-template <int BN, bool ONESEG>
+// BM = 128: 2 x 2 waves, wave tile 64 co x BN/2 ci.  BM = 32 (narrow predictors, Cout <= 32): 1 x 4 waves, wave tile
+// 32 co x BN/4 ci (BN = 128 only) -- a 128-wide tile would spend 3/4 of its MFMAs on padding.
+template <int BN, bool ONESEG, int BM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-    constexpr int BM = 128;                       // output channels per tile
-    constexpr int TN = BN / 64;                   // 32-wide ci sub-tiles per wave (wave tile 64 co x BN/2 ci)
+    constexpr int WAVES_N = BM == 128 ? 2 : 4;
+    constexpr int TM = BM == 128 ? 2 : 1;         // 32-wide co sub-tiles per wave
+    constexpr int TN = BN / (32 * WAVES_N);       // 32-wide ci sub-tiles per wave
+    static_assert(TN >= 1, "BM = 32 needs BN = 128");
+    constexpr int ATPR = BM / 4;                  // threads per A row (float4 each)
+    constexpr int ARPP = 256 / ATPR;              // A rows per pass
+    constexpr int AP = ARPP >= 32 ? 1 : 32 / ARPP;
     constexpr int BTPR = BN / 4;                  // threads per B row (float4 each)
     constexpr int BRPP = 256 / BTPR;              // B rows per pass
     constexpr int BP = 32 / BRPP;                 // passes for the 32 pixel rows
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float Bs[32 * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, lh = lane >> 5;
 
     int t = blockIdx.x;
@@ -65,18 +72,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, (short)0, (int)a.dy_bytes, 0x00020000);
 
-    // A rows (dY): 32 threads per pixel row of 128 channels, 8 rows per pass, 4 passes
-    const int arow = tid >> 5, ac4 = tid & 31;
-    const bool a_col_ok = co0 + ac4 * 4 < a.Cout;
+    // A rows (dY): ATPR threads per pixel row of BM channels
+    const int arow = tid / ATPR, ac4 = tid % ATPR;
+    const bool a_col_ok = co0 + ac4 * 4 < a.Cout && arow < 32;
     // B rows (X): BTPR threads per pixel row
     const int brow = tid / BTPR, bc4 = tid % BTPR;
     const bool b_col_ok = ci0 + bc4 * 4 < a.Cin;
 
-    float4 ra[4], rb[BP];
+    float4 ra[AP], rb[BP];
     auto load_tile = [&](int m0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + arow + 8 * i;
+        for (int i = 0; i < AP; ++i) {
+            const int m = m0 + arow + ARPP * i;
             const unsigned off = ((unsigned)m * (unsigned)a.dy_cs + (unsigned)(a.dy_co + co0 + ac4 * 4)) * 4u;
             ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(yrsrc, (int)((m < m_end && a_col_ok) ? off : OOB), 0, 0));
         }
@@ -115,14 +122,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(As + (arow + 8 * i) * BM + ac4 * 4) = ra[i];
+        for (int i = 0; i < AP; ++i)
+            if (ARPP <= 32 || arow < 32) *reinterpret_cast<float4*>(As + (arow + ARPP * i) * BM + ac4 * 4) = ra[i];
 #pragma unroll
         for (int i = 0; i < BP; ++i) *reinterpret_cast<float4*>(Bs + (brow + BRPP * i) * BN + bc4 * 4) = rb[i];
     };
 
-    f32x16 acc[2][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -135,12 +143,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             store_tile();
             __syncthreads();
             if (m0 + 32 < m_end) load_tile(m0 + 32);
-            const float* Ab = As + wm * 64 + l31;
-            const float* Bb = Bs + wn * (BN / 2) + l31;
+            const float* Ab = As + wm * (TM * 32) + l31;
+            const float* Bb = Bs + wn * (TN * 32) + l31;
             __builtin_amdgcn_s_setprio(1);
-            float fa[2][2], fb[2][TN];
+            float fa[2][TM], fb[2][TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[0][i] = Ab[lh * BM + i * 32];
+            for (int i = 0; i < TM; ++i) fa[0][i] = Ab[lh * BM + i * 32];
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[0][j] = Bb[lh * BN + j * 32];
 #pragma unroll
@@ -149,17 +157,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 if (p + 1 < 16) {                 // operands of the next k-step are in flight while this one multiplies
                     const int k = 2 * (p + 1) + lh;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) fa[nxt][i] = Ab[k * BM + i * 32];
+                    for (int i = 0; i < TM; ++i) fa[nxt][i] = Ab[k * BM + i * 32];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) fb[nxt][j] = Bb[k * BN + j * 32];
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // LDS reads of step p+1 ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);   // ... ahead of the MFMAs of step p
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);  // ... ahead of the MFMAs of step p
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -168,13 +176,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     // C[row = co][col = ci]: reg e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), col l&31 -> 128-byte runs along ci
     float* out = a.out + (size_t)blockIdx.y * a.slab;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int ci = ci0 + wn * (BN / 2) + j * 32 + l31;
+            const int ci = ci0 + wn * (TN * 32) + j * 32 + l31;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = co0 + wm * 64 + i * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+                const int co = co0 + wm * (TM * 32) + i * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
                 if (co < a.Cout && ci < a.Cin) out[(size_t)co * a.Ktot + tap * a.Cin + ci] = acc[i][j][e];
             }
         }
@@ -282,7 +290,8 @@ static int wgrad_splits(long M, int tiles, bool gemm) {
 extern "C" int64_t fd_conv_wgrad_workspace_bytes(int64_t out_rows, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW) {
     if (out_rows < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1) return -1;
     const int bn = (Cin % 128 == 0) ? 128 : 64;
-    const int tiles = ((Cout + 127) / 128) * KH * KW * ((Cin + bn - 1) / bn);
+    const int bm = (Cout <= 32 && bn == 128) ? 32 : 128;
+    const int tiles = ((Cout + bm - 1) / bm) * KH * KW * ((Cin + bn - 1) / bn);
     // upper bound over both split rules (the launcher knows stride / padding, this query does not)
     const int ns = std::max(wgrad_splits(out_rows, tiles, false), wgrad_splits(out_rows, tiles, true));
     return (int64_t)ns * Cout * KH * KW * Cin * 4;
@@ -328,7 +337,8 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     a.is_gemm = (p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0) ? 1 : 0;
     const int bn = (p->Cin % 128 == 0) ? 128 : 64;
-    a.co_tiles = (p->Cout + 127) / 128;
+    const int bm = (p->Cout <= 32 && bn == 128) ? 32 : 128;
+    a.co_tiles = (p->Cout + bm - 1) / bm;
     a.ci_tiles = (p->Cin + bn - 1) / bn;
     const int tiles = a.co_tiles * a.ntaps * a.ci_tiles;
     const int nsplit = p->nsplit > 0 ? p->nsplit : wgrad_splits(mo, tiles, a.is_gemm != 0);
@@ -342,10 +352,12 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
     a.out = need_reduce ? (float*)p->workspace : p->dw;
     const dim3 grid(tiles, (unsigned)((mo + a.rows_per_split - 1) / a.rows_per_split));
     const bool one = p->in.nseg == 1;
-    if (bn == 128 && one) hipLaunchKernelGGL((conv_wgrad_kernel<128, true>), grid, dim3(256), 0, stream, a);
-    else if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), grid, dim3(256), 0, stream, a);
-    else if (one) hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), grid, dim3(256), 0, stream, a);
+    if (bm == 32 && one) hipLaunchKernelGGL((conv_wgrad_kernel<128, true, 32>), grid, dim3(256), 0, stream, a);
+    else if (bm == 32) hipLaunchKernelGGL((conv_wgrad_kernel<128, false, 32>), grid, dim3(256), 0, stream, a);
+    else if (bn == 128 && one) hipLaunchKernelGGL((conv_wgrad_kernel<128, true, 128>), grid, dim3(256), 0, stream, a);
+    else if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, false, 128>), grid, dim3(256), 0, stream, a);
+    else if (one) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, 128>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, false, 128>), grid, dim3(256), 0, stream, a);
     FD_CHECK_LAUNCH("fd_conv2d_bwd_weight");
     if (need_reduce) {
         const long n4 = a.slab / 4;

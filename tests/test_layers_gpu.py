@@ -264,6 +264,9 @@ WGRAD_CASES = [
     (256, 128, 1, 2, 0, 1, 10, 10),
     (256, 80, 3, 1, 1, 1, 6, 6),
     (512, 256, 1, 1, 0, 1, 5, 5),
+    (256, 32, 3, 1, 1, 1, 11, 9),     # narrow predictors: 32-channel tile variant
+    (128, 20, 3, 1, 1, 1, 7, 12),
+    (128, 8, 1, 1, 0, 1, 9, 9),
 ]
 
 
