@@ -230,6 +230,89 @@ def train_step(dev, batch: int = 16, size: int = 512, steps: int = 5):
     return res
 
 
+def train_mode(args, rank, world, dev, use_dist):
+    """`--mode train` (SURVEY Cfg4): the reference's train.py step on N GPUs -- DistributedDataParallel around the model
+    (gradient all-reduce over RCCL, bucketed and overlapped with backward by DDP), HIP forward / backward / target /
+    loss kernels, SGD.  Weak scaling: --batch images of --size per GPU (defaults 16 x 512 x 512, 20 classes: voc.yaml)."""
+    from pytorch_object_detection_amd import ops
+    from pytorch_object_detection_amd._lib import Segs
+    from pytorch_object_detection_amd.model.loss import FCOSLoss
+    from pytorch_object_detection_amd.model.modules.head import FCOSGenTargets
+    from pytorch_object_detection_amd.model.od import HalfInvertedStageFCOS
+    size, batch, ncls = args.size, args.batch, args.classes
+    torch.manual_seed(0)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], ncls, 256).to(dev)
+    ddp_kw = {"find": dict(find_unused_parameters=True),                                   # train.py:101 as written
+              "static": dict(static_graph=True, gradient_as_bucket_view=True)}[os.environ.get("FD_BENCH_DDP", "static")]
+    net = torch.nn.parallel.DistributedDataParallel(model, **ddp_kw) if use_dist else model
+    net.train()
+    opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    gen = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(batch, 3, size, size, generator=gen).to(dev)
+    c = torch.rand(batch, 8, 2, generator=gen) * (size - 112) + 50
+    s = torch.rand(batch, 8, 2, generator=gen) * 150 + 20
+    gt = torch.cat([c - s / 2, c + s / 2], -1).clamp(0, size - 1).to(dev)
+    labels = torch.randint(1, ncls + 1, (batch, 8), generator=gen).to(dev)
+    gen_t = FCOSGenTargets([8, 16, 32, 64, 128], [[-1, 32], [32, 96], [96, 192], [192, 384], [384, 9999999]])
+    crit = FCOSLoss("giou")
+
+    def one():
+        opt.zero_grad(set_to_none=True)
+        out = net(x)
+        losses = crit([out, gen_t([out, gt, labels])])
+        losses[-1].backward()
+        opt.step()
+        return losses[-1]
+
+    for _ in range(args.warmup):
+        one()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank != 0:
+        return
+    # roofline of the dominant backward kernel: the weight gradient of the head tower 3x3 (256 -> 256, all five levels)
+    lv = [(size // st, size // st) for st in (8, 16, 32, 64, 128)]
+    segs = Segs.make(batch, lv)
+    xr, dy = ops.Rows(torch.randn(segs.rows, 256, device=dev)), ops.Rows(torch.randn(segs.rows, 256, device=dev))
+    f = lambda: ops.conv_wgrad(xr, dy, segs, Cin=256, Cout=256, k=3, pad=1, oihw=True)  # noqa: E731
+    for _ in range(3):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        f()
+    e1.record()
+    e1.synchronize()
+    wms = e0.elapsed_time(e1) / 10
+    wflops = 2 * segs.rows * 256 * 256 * 9
+    ach = wflops / (wms * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": f"images/sec HISFCOS-R50 {size}x{size} train step (GIoU loss, SGD)", "value": round(batch * world * args.steps / el, 2),
+        "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"HISFCOS-R50 train.py step, {batch} x {size}x{size} images/GPU, {ncls} classes, 8 GT boxes/image, "
+                               "HIP forward/backward/target/loss kernels" + (", DDP gradient all-reduce over RCCL" if use_dist else ""),
+                   "global_batch": batch * world, "parallelism": f"dp{world} (DistributedDataParallel)"},
+        "roofline": {"bound": "mfma", "kernel": "conv_wgrad_kernel (head tower 3x3 weight gradient, 5 levels) + ordered slab reduce",
+                     "instruction": "v_mfma_f32_32x32x2_f32", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "flops_per_launch": wflops, "avg_launch_ms": round(wms, 4)},
+        "final_loss": round(float(loss.detach()), 5)}), flush=True)
+
+
 def layer_times(plan, x, path, reps=5):
     """Diagnostic: HIP-event time of every plan step (median of `reps`), with conv TFLOP/s where applicable."""
     plan.image_ref[0] = x
@@ -266,6 +349,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--model", default="HISFCOS", choices=["HISFCOS", "FCOS"], help="FCOS = diagnostic run of the baseline detector")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = diagnostic: the Cfg4 training step (DDP over RCCL for N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra opt-in f16x3 measurement")
     ap.add_argument("--save-tuning", action="store_true", help="write the conv tile table measured in this run back to tuned/gfx950_tiles.json")
@@ -290,6 +374,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.mode == "train":
+        if args.size == 640 and args.classes == 80:      # untouched defaults -> the reference's VOC training shape
+            args.size, args.classes = 512, 20
+        train_mode(args, rank, world, dev, use_dist)
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     from pytorch_object_detection_amd import _lib
     from pytorch_object_detection_amd.dist import gather_detections
