@@ -108,6 +108,18 @@ def _dev(t: torch.Tensor, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ conv helpers
+def padded_input(plan: Plan, rows: int, C: int):
+    """Plan-owned staging buffer for a caller-supplied map of C channels: (Rows the convs read, Rows the copy-in writes).
+    C is rounded up to a multiple of 32 with zero channels that are never written (dedicated, not pooled)."""
+    Cp = (C + 31) // 32 * 32
+    if Cp == C:
+        r = plan.pool.get(rows, C)
+        return r, r
+    buf = torch.zeros(rows, Cp, dtype=torch.float32, device=plan.device)
+    plan.keep.append(buf)
+    return Rows(buf), Rows(buf, 0, C)
+
+
 def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, y: Rows, *, bn=None, act=ACT_NONE,
              res: Optional[Rows] = None, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
              Cout: Optional[int] = None, act_c0: int = 0, seg_param=None, tag: int = 0) -> Segs:
@@ -121,6 +133,11 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     else:
         pad = pad[0]
     Cin, co = w.shape[1], (w.shape[0] if Cout is None else Cout)
+    if Cin % 32 and x.co == 0 and x.C == x.cs and x.C % 32 == 0 and 0 < x.C - Cin < 32:
+        # input width that is not a multiple of 32 (EfficientNet-style backbones: 48, 136 channels): the caller staged
+        # the map into a zero-padded buffer (padded_input), the weights get matching zero input channels
+        w = torch.nn.functional.pad(_dev(w, dev).detach(), (0, 0, 0, 0, 0, x.C - Cin))
+        Cin = x.C
     split = plan.precision == "f16x3"
     wp = ops.pack_conv_weight_f16x3(_dev(w, dev)) if split else ops.pack_conv_weight(_dev(w, dev))
     scale = shift = None

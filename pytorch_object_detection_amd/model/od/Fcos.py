@@ -54,13 +54,14 @@ class FeaturePyramidNetwork(PlannedModule):
             ins = []
             for t in (c3, c4, c5):
                 B, C, H, W = t.shape
-                ins.append((plan.pool.get(B * H * W, C), Segs.make(B, [(H, W)])))
-            pyr, segs = engine.build_fcos_fpn(plan, self, ins)
+                full, view = engine.padded_input(plan, B * H * W, C)
+                ins.append((full, Segs.make(B, [(H, W)]), view))
+            pyr, segs = engine.build_fcos_fpn(plan, self, [(r, s) for r, s, _ in ins])
             return plan, ins, pyr, segs
 
         plan, ins, pyr, segs = self._get_plan(key, build)
-        for (r, s), t in zip(ins, (c3, c4, c5)):
-            copy_in_nchw(r, s, 0, t)
+        for (_, s, view), t in zip(ins, (c3, c4, c5)):
+            copy_in_nchw(view, s, 0, t)
         plan.run()
         return pyramid_out(pyr, segs)
 

@@ -238,3 +238,37 @@ def test_full_size_batch16_is_per_image_independent():
             return {(int(cl),) + tuple(np.round(bx.astype(np.float64), 2)) for cl, bx in zip(cls, box)}
         ra, rb = rows(ci[0, :k].cpu().numpy(), bi[0, :k].cpu().numpy()), rows(c[i, :k].cpu().numpy(), b[i, :k].cpu().numpy())
         assert len(ra & rb) >= 0.99 * k, (len(ra & rb), k)
+
+
+def test_fcos_fpn_head_on_efficientnet_b3_widths():
+    """Cfg5 data format: the FCOS FPN + head fed with EfficientNet-B3-shaped endpoints (reduction_3/4/5 = 48 / 136 / 384
+    channels, efficientnetv1.py:21-26; FCOS takes them as [C5, C4, C3] widths, Fcos.py:61-75) on a mixed-aspect
+    832x1344 canvas.  48 and 136 are not multiples of 32: the maps are staged into zero-padded buffers."""
+    from pytorch_object_detection_amd.model.od.Fcos import FeaturePyramidNetwork, HeadFCOS
+    torch.manual_seed(13)
+    fpn = FeaturePyramidNetwork([384, 136, 48], 64).eval()
+    head = HeadFCOS(64, 80, 0.01).eval()
+    randomize_norms(head, 3)
+    for p in list(fpn.parameters()) + [q for q in head.parameters() if q.dim() == 4]:
+        if p.dim() == 4:
+            torch.nn.init.normal_(p, std=(1.0 / (p.shape[1] * p.shape[2] * p.shape[3])) ** 0.5)
+    feats = [torch.randn(2, 48, 104, 168), torch.randn(2, 136, 52, 84), torch.randn(2, 384, 26, 42)]
+    sd = {"FPN." + k: v.clone() for k, v in fpn.state_dict().items()}
+    sd.update({"head." + k: v.clone() for k, v in head.state_dict().items()})
+    with torch.no_grad():
+        ps = R.fcos_fpn(sd, feats)
+        ref = R.fcos_head(sd, ps)
+    fpn.to(DEV); head.to(DEV)
+    pyr = fpn([f.to(DEV) for f in feats])
+    out = head(pyr)
+    for i in range(5):
+        np.testing.assert_allclose(pyr[i].cpu().numpy(), ps[i].numpy(), **TOL)
+        for o, r in zip(out, ref):
+            np.testing.assert_allclose(o[i].cpu().numpy(), r[i].numpy(), **TOL)
+    # a second call with new data must not see stale padding or stale inputs
+    feats2 = [f * 0.5 + 0.1 for f in feats]
+    with torch.no_grad():
+        ps2 = R.fcos_fpn(sd, feats2)
+    pyr2 = fpn([f.to(DEV) for f in feats2])
+    for i in range(5):
+        np.testing.assert_allclose(pyr2[i].cpu().numpy(), ps2[i].numpy(), **TOL)
