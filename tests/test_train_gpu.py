@@ -66,12 +66,22 @@ def test_train_step_matches_oracle_autograd():
         g_ref = sd[name].grad
         assert p.grad is not None and g_ref is not None, name
         scale = float(g_ref.abs().max()) + 1e-12
-        # deep in the trunk the backward passes through ~60 ReLU masks: a handful of near-zero activations flip between
-        # MIOpen's and oneDNN's fp32 summation orders, so those gradients get a looser (still relative-to-max) bar
+        # measured on MI355X: every gradient agrees with the CPU autograd to ~1e-6 of its max EXCEPT what sits behind one
+        # ReLU whose near-zero input lands on the other side of 0 under a different fp32 summation order (one element of
+        # head.reg_conv's channel 208 on this seed: 3 % on that filter, ~0.2 % on everything upstream of it); hence a
+        # relative-to-max bar that tolerates a flipped mask element, looser deep in the trunk (~60 ReLU masks)
         tol = 2e-2 if name.startswith("backbone.") else 2e-3
         np.testing.assert_allclose(p.grad.cpu().numpy() / scale, g_ref.numpy() / scale, atol=tol, err_msg=name)
         checked += 1
     assert checked == 8
+    # robust-to-a-flip view of the same comparison: for the parameters at or after the towers (nothing upstream of the
+    # flipped element) the MEDIAN deviation per parameter is at rounding level
+    for name, p in model.head.named_parameters():
+        g_ref = sd["head." + name].grad
+        if p.grad is None or g_ref is None or g_ref.numel() < 64 or not name.startswith(("cls_", "reg_", "cnt_")):
+            continue
+        scale = float(g_ref.abs().max()) + 1e-12
+        assert float((p.grad.cpu() - g_ref).abs().median()) / scale < 1e-5, name
     # layer1 and the stem are frozen (freeze_stages(1), HISFcos.py:67)
     assert model.backbone.extract_feature.layer1[0].conv1.weight.grad is None
     before = model.head.cls_logits.weight.detach().clone()
