@@ -124,4 +124,20 @@ def test_abi_argument_errors_without_gpu():
                             ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, None) < 0
     p = _lib.ConvParams()
     assert lib.fd_conv2d_nhwc_f32(ctypes.byref(p), None) == -1
-    assert lib.fd_groupnorm_workspace_bytes(ctypes.byref(_lib.Segs.make(2, [(8, 8), (4, 4)])), 32) == 2 * 2 * 64 * 32 * 16
+    assert lib.fd_groupnorm_workspace_bytes(ctypes.byref(_lib.Segs.make(2, [(8, 8), (4, 4)])), 32) == 2 * 2 * (64 + 1) * 32 * 16   # chunk partials + (mean, rstd)
+
+
+def test_backward_abi_argument_errors_without_gpu():
+    """The train-step entry points validate on the host too (no launch happens for bad arguments)."""
+    lib = _lib.lib()
+    p = _lib.WgradParams()
+    assert lib.fd_conv2d_bwd_weight_f32(ctypes.byref(p), None) < 0
+    assert lib.fd_conv_wgrad_workspace_bytes(4096, 256, 256, 3, 3) >= 256 * 256 * 9 * 4
+    assert lib.fd_conv_wgrad_workspace_bytes(0, 256, 256, 3, 3) == -1
+    assert lib.fd_pack_conv_weight_f32(None, None, None, 64, 64, 3, 3, 0, None) < 0
+    assert lib.fd_pack_conv_weight_f32(ctypes.c_void_p(16), None, ctypes.c_void_p(16), 64, 48, 3, 3, 0, None) < 0   # Cin % 32
+    segs = _lib.Segs.make(2, [(8, 8), (4, 4)])
+    assert lib.fd_groupnorm_bwd_workspace_bytes(ctypes.byref(segs), 64) == (4 * 64 + 4) * 2 * 64 * 8
+    assert lib.fd_dwconv3x3_wgrad_workspace_bytes(ctypes.byref(segs), 128) > 0
+    assert lib.fd_groupnorm_act_bwd_nhwc(None, 0, 0, None, 0, 0, None, None, None, 0, 0, None, None, 64, 32, 1e-5, 0,
+                                         ctypes.byref(segs), None, None, None) < 0
