@@ -137,20 +137,34 @@ def _act_id(act) -> int:
 
 
 # ------------------------------------------------------------------------------------------- dense convolution
+_TILE_CACHE: dict = {}
+
+
 def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.Tensor, *, k, stride, pad, dil, scale=None,
                  shift=None, res: Optional[torch.Tensor] = None, act=ACT_NONE) -> None:
-    """y = act(conv(x, w) * scale + shift + res) on contiguous rows buffers; w_packed from ops.pack_conv_weight_hip."""
+    """y = act(conv(x, w) * scale + shift + res) on contiguous rows buffers; w_packed from ops.pack_conv_weight_hip.
+    The block tile comes from the same table / heuristic / FD_AUTOTUNE timing as the inference plans (ops.autotune_conv),
+    remembered per shape for the process."""
     Cin, Cout = x.shape[1], w_packed.shape[0]
     out_rows = y.shape[0]
-    code = ops.heuristic_conv(out_rows, Cout, (Cin // 32) * k * k, True)
-    tile, ksplit = code & 0xFF, max(1, code >> 8)
+    KT = (Cin // 32) * k * k
+    hw = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
+    key = f"B{segs.batch}|{hw}|{Cin}>{Cout}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{Cin}|ycs{Cout}"
+    code = _TILE_CACHE.get(key)
     ws = None
-    if ksplit > 1:
-        nb = _lib.lib().fd_conv_workspace_bytes(out_rows, Cout, ksplit)
-        ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=x.device)
-    ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad,
-                  dil=dil, scale=scale, shift=shift, res=_r(res) if res is not None else None, act=act, tile=tile,
-                  ksplit=ksplit, workspace=ws)()
+    if code is None or (code >> 8) > 1:
+        nb = _lib.lib().fd_conv_workspace_bytes(out_rows, Cout, ops.KSPLIT_MAX)
+        if 0 < nb <= 256 * 1024 * 1024:
+            ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+    call = ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
+                         shift=shift, res=_r(res) if res is not None else None, act=act, workspace=ws)
+    if code is None:
+        code = _TILE_CACHE[key] = ops.autotune_conv(call, key, out_rows, Cout, KT)
+    p = call.params
+    p.tile, p.ksplit = code & 0xFF, max(1, code >> 8)
+    if p.ksplit > 1 and ws is None:
+        p.ksplit = 1
+    call()
 
 
 class _ConvRows(torch.autograd.Function):
