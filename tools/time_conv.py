@@ -35,4 +35,4 @@ for tile in (only or sorted(_lib.TILES)):
         run()
     e1.record(); e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print(f"tile {tile:2d} {_lib.TILES[tile]}: {ms*1e3:7.1f} us  {flops / ms / 1e9:6.1f} TFLOP/s  {byts / ms / 1e9:6.2f} TB/s")
+    print(f"tile {tile:2d} {_lib.TILES.get(tile, 'auto')}: {ms*1e3:7.1f} us  {flops / ms / 1e9:6.1f} TFLOP/s  {byts / ms / 1e9:6.2f} TB/s")
