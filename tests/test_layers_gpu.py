@@ -462,3 +462,53 @@ def test_conv_wgrad_oihw_scaled():
     d0 = ops.dwconv3x3_wgrad(x, ops.Rows(dy.buf[:, :Cin].contiguous()), segs)
     d1 = ops.dwconv3x3_wgrad(x, ops.Rows(dy.buf[:, :Cin].contiguous()), segs, sc[:Cin].contiguous(), torch_layout=True)
     np.testing.assert_allclose(d1.cpu().numpy(), (d0 * sc[:Cin]).t().reshape(Cin, 1, 3, 3).cpu().numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", [
+    # Cin, Cout, k, stride, dil, levels (the train step's real shapes: batch 16, 512x512 input)
+    (256, 256, 3, 1, 1, [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)]),     # head tower over the pyramid
+    (256, 256, 3, 1, 2, [(64, 64)]),                                          # HisBlock conv4 (dilated) at P3
+    (1024, 256, 1, 1, 1, [(32, 32)]),                                         # layer3 bottleneck 1x1
+    (128, 128, 3, 2, 1, [(128, 128)]),                                        # layer2 strided 3x3 (weight gradient only)
+])
+def test_conv_backward_adjoint_identity_full_size(case):
+    """Size-independent property at the bench sizes (no oracle needed): the conv is linear in x and in w, so
+    <conv(x, w), dy> == <w, wgrad(x, dy)> == <x, dgrad(dy, w)> up to fp32 rounding."""
+    Cin, Cout, k, stride, dil, hw = case
+    gen = torch.Generator(device=DEV).manual_seed(sum(case[:5]))
+    B, pad = 16, dil * (k - 1) // 2
+    segs = Segs.make(B, hw)
+    so = ops.conv_out_segs(segs, k, stride, pad, dil)
+    x = torch.randn(segs.rows, Cin, device=DEV, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, device=DEV, generator=gen) / np.sqrt(Cin * k * k)
+    dy = torch.randn(so.rows, Cout, device=DEV, generator=gen)
+    y = ops.new_rows(so.rows, Cout, DEV)
+    ops.conv_call(ops.Rows(x), segs, ops.pack_conv_weight_hip(w), y, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil)()
+    s_y = float((y.buf.double() * dy.double()).sum())
+    dw = ops.conv_wgrad(ops.Rows(x), ops.Rows(dy), segs, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, oihw=True)
+    s_w = float((dw.double() * w.double()).sum())
+    scale = float(y.buf.double().norm() * dy.double().norm())
+    assert abs(s_y - s_w) / scale < 2e-6, (s_y, s_w, scale)
+    if stride == 1:
+        dx = ops.new_rows(segs.rows, Cin, DEV)
+        ops.conv_call(ops.Rows(dy), so, ops.pack_conv_weight_hip(w, dgrad=True), dx, Cin=Cout, Cout=Cin, k=k, stride=1,
+                      pad=dil * (k - 1) - pad, dil=dil)()
+        s_x = float((dx.buf.double() * x.double()).sum())
+        assert abs(s_y - s_x) / scale < 2e-6, (s_y, s_x, scale)
+
+
+def test_dwconv_backward_adjoint_identity_full_size():
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    B, C = 16, 512
+    segs = Segs.make(B, [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)])
+    x = torch.randn(segs.rows, C, device=DEV, generator=gen)
+    w = torch.randn(C, 1, 3, 3, device=DEV, generator=gen) / 3
+    dy = torch.randn(segs.rows, C, device=DEV, generator=gen)
+    y, dx = ops.new_rows(segs.rows, C, DEV), ops.new_rows(segs.rows, C, DEV)
+    ops.dwconv3x3(ops.Rows(x), ops.pack_dw_weight(w), y, segs)
+    ops.dwconv3x3(ops.Rows(dy), ops.pack_dw_weight(w.flip(2, 3)), dx, segs)
+    dw = ops.dwconv3x3_wgrad(ops.Rows(x), ops.Rows(dy), segs, torch_layout=True)
+    s_y = float((y.buf.double() * dy.double()).sum())
+    scale = float(y.buf.double().norm() * dy.double().norm())
+    assert abs(s_y - float((dw.double() * w.double()).sum())) / scale < 2e-6
+    assert abs(s_y - float((dx.buf.double() * x.double()).sum())) / scale < 2e-6
