@@ -140,7 +140,8 @@ typedef struct fd_conv_wgrad_params {
     int32_t Cin, Cout, KH, KW, stride, pad, dil;
     void* workspace; /* fd_conv_wgrad_workspace_bytes(out_rows, Cin, Cout, KH, KW) bytes, 16-B aligned */
     int64_t workspace_bytes;
-    int32_t nsplit;  /* 0 = library chooses; else the pixel-range split count (workspace >= nsplit * |dw| * 4 bytes) */
+    int32_t nsplit;  /* 0 = library chooses; else the pixel-range split count (workspace >= (nsplit + 8) * |dw| * 4 bytes:
+                        ranges never cross a pyramid level, so every level adds at most one) */
     int32_t layout;  /* dw layout: 0 = [Cout][KH][KW][Cin] (OHWI), 1 = [Cout][Cin][KH][KW] (OIHW, torch's parameter layout) */
     const float* scale; /* optional [Cout]: dw[co] *= scale[co] (a frozen BatchNorm folded into the forward epilogue) */
     fd_segs in;      /* forward INPUT geometry */

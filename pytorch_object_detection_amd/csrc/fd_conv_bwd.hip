@@ -16,6 +16,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#define FD_WGRAD_MAX_RANGES 128
+
 struct WgradArgs {
     const float* x; const float* dy; float* out;
     int x_cs, x_co, dy_cs, dy_co;
@@ -27,7 +29,9 @@ struct WgradArgs {
     unsigned mg_hw[FD_MAX_SEG], mg_w[FD_MAX_SEG];   // division by Ho*Wo / Wo as mulhi + shift (0 = divisor 1)
     int sh_hw[FD_MAX_SEG], sh_w[FD_MAX_SEG];
     int co_tiles, ci_tiles;      // tiles of 128 output channels, tiles of BN input channels (per tap)
-    int rows_per_split;          // multiple of 32
+    int rows_per_split;          // 1x1 layers: uniform pixel ranges of this many rows (multiple of 32)
+    int r_begin[FD_WGRAD_MAX_RANGES], r_end[FD_WGRAD_MAX_RANGES];   // other layers: pixel range of workgroup row y ...
+    unsigned char r_seg[FD_WGRAD_MAX_RANGES];                         // ... and the one pyramid level it lies in
     long slab;                   // elements per split slab (= Cout * Ktot)
     unsigned x_bytes, dy_bytes;
     int is_gemm;
@@ -40,7 +44,7 @@ __device__ __forceinline__ int fast_div(int n, unsigned m, int sh) {
 
 // BM = 128: 2 x 2 waves, wave tile 64 co x BN/2 ci.  BM = 32 (narrow predictors, Cout <= 32): 1 x 4 waves, wave tile
 // 32 co x BN/4 ci (BN = 128 only) -- a 128-wide tile would spend 3/4 of its MFMAs on padding.
-template <int BN, bool ONESEG, int BM>
+template <int BN, int BM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int WAVES_N = BM == 128 ? 2 : 4;
     constexpr int TM = BM == 128 ? 2 : 1;         // 32-wide co sub-tiles per wave
@@ -65,8 +69,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int cot = t / a.ntaps;
     const int co0 = cot * BM, ci0 = cit * BN;
     const int fr = tap / a.KW, fq = tap - fr * a.KW;
-    const int m_begin = blockIdx.y * a.rows_per_split;
-    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    // pixel range of this workgroup: never crosses a pyramid level, so the level's geometry is wave-uniform
+    const int m_begin = a.is_gemm ? blockIdx.y * a.rows_per_split : a.r_begin[blockIdx.y];
+    const int m_end = a.is_gemm ? min(a.M, m_begin + a.rows_per_split) : a.r_end[blockIdx.y];
 
     constexpr unsigned OOB = 0xC0000000u;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
@@ -78,6 +83,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     // B rows (X): BTPR threads per pixel row
     const int brow = tid / BTPR, bc4 = tid % BTPR;
     const bool b_col_ok = ci0 + bc4 * 4 < a.Cin;
+
+    const int gs = a.is_gemm ? 0 : a.r_seg[blockIdx.y];
+    const int g_Wo = a.Wo[gs], g_hw = a.Ho[gs] * a.Wo[gs], g_H = a.H[gs], g_W = a.W[gs], g_mout = a.m_out[gs], g_min = a.m_in[gs];
+    const unsigned g_mgh = a.mg_hw[gs], g_mgw = a.mg_w[gs];
+    const int g_shh = a.sh_hw[gs], g_shw = a.sh_w[gs];
 
     float4 ra[AP], rb[BP];
     auto load_tile = [&](int m0) {
@@ -95,20 +105,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 if (a.is_gemm) {
                     off = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + bc4 * 4)) * 4u;
                 } else {
-                    int Wo, hw, H, W, local, m_in;
-                    unsigned mgh, mgw;
-                    int shh, shw;
-                    if (ONESEG) {
-                        Wo = a.Wo[0]; hw = a.Ho[0] * Wo; H = a.H[0]; W = a.W[0]; local = m; m_in = a.m_in[0];
-                        mgh = a.mg_hw[0]; shh = a.sh_hw[0]; mgw = a.mg_w[0]; shw = a.sh_w[0];
-                    } else {
-                        int s = 0;
-#pragma unroll
-                        for (int k = 1; k < FD_MAX_SEG; ++k)
-                            if (k < a.nseg && m >= a.m_out[k]) s = k;
-                        Wo = a.Wo[s]; hw = a.Ho[s] * Wo; H = a.H[s]; W = a.W[s]; local = m - a.m_out[s]; m_in = a.m_in[s];
-                        mgh = a.mg_hw[s]; shh = a.sh_hw[s]; mgw = a.mg_w[s]; shw = a.sh_w[s];
-                    }
+                    const int Wo = g_Wo, hw = g_hw, H = g_H, W = g_W, local = m - g_mout, m_in = g_min;
+                    const unsigned mgh = g_mgh, mgw = g_mgw;
+                    const int shh = g_shh, shw = g_shw;
                     const int n = fast_div(local, mgh, shh);
                     const int rem = local - n * hw;
                     const int ho = fast_div(rem, mgw, shw), wo = rem - ho * Wo;
@@ -294,7 +293,8 @@ extern "C" int64_t fd_conv_wgrad_workspace_bytes(int64_t out_rows, int32_t Cin, 
     const int tiles = ((Cout + bm - 1) / bm) * KH * KW * ((Cin + bn - 1) / bn);
     // upper bound over both split rules (the launcher knows stride / padding, this query does not)
     const int ns = std::max(wgrad_splits(out_rows, tiles, false), wgrad_splits(out_rows, tiles, true));
-    return (int64_t)ns * Cout * KH * KW * Cin * 4;
+    // + FD_MAX_SEG: level-aligned ranges give every pyramid level at least one slab of its own
+    return (int64_t)(ns + FD_MAX_SEG) * Cout * KH * KW * Cin * 4;
 }
 
 extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_stream_t stream_) {
@@ -341,23 +341,49 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
     a.co_tiles = (p->Cout + bm - 1) / bm;
     a.ci_tiles = (p->Cin + bn - 1) / bn;
     const int tiles = a.co_tiles * a.ntaps * a.ci_tiles;
-    const int nsplit = p->nsplit > 0 ? p->nsplit : wgrad_splits(mo, tiles, a.is_gemm != 0);
+    int nsplit = p->nsplit > 0 ? p->nsplit : wgrad_splits(mo, tiles, a.is_gemm != 0);
     FD_REQUIRE(nsplit <= 65535, FD_E_INVAL, "fd_conv2d_bwd_weight: nsplit too large");
     a.rows_per_split = (int)(((mo + nsplit - 1) / nsplit + 31) / 32 * 32);
+    unsigned ny = (unsigned)((mo + a.rows_per_split - 1) / a.rows_per_split);
+    if (!a.is_gemm) {
+        // level-aligned pixel ranges: every level gets its share of the splits (at least one), cut into equal parts
+        if (nsplit > FD_WGRAD_MAX_RANGES) nsplit = FD_WGRAD_MAX_RANGES;
+        int per[FD_MAX_SEG], tot = 0;
+        for (int s = 0; s < p->in.nseg; ++s) {
+            const long rows = (long)a.m_out[s + 1] - a.m_out[s];
+            per[s] = (int)((rows * nsplit + mo / 2) / mo);
+            if (per[s] < 1) per[s] = 1;
+            if (per[s] > rows / 32 + 1) per[s] = (int)(rows / 32 + 1);
+            tot += per[s];
+        }
+        while (tot > FD_WGRAD_MAX_RANGES) {            // only reachable with nsplit forced near the cap: trim the largest
+            int big = 0;
+            for (int s = 1; s < p->in.nseg; ++s) if (per[s] > per[big]) big = s;
+            --per[big]; --tot;
+        }
+        ny = 0;
+        for (int s = 0; s < p->in.nseg; ++s) {
+            const long rows = (long)a.m_out[s + 1] - a.m_out[s];
+            const long step = ((rows + per[s] - 1) / per[s] + 31) / 32 * 32;
+            for (long b = 0; b < rows; b += step) {
+                a.r_begin[ny] = a.m_out[s] + (int)b;
+                a.r_end[ny] = a.m_out[s] + (int)std::min(rows, b + step);
+                a.r_seg[ny] = (unsigned char)s;
+                ++ny;
+            }
+        }
+        nsplit = (int)ny;
+    }
     a.slab = (long)p->Cout * a.Ktot;
     FD_REQUIRE(p->workspace_bytes >= (int64_t)nsplit * a.slab * 4, FD_E_INVAL,
                "fd_conv2d_bwd_weight: workspace too small (need fd_conv_wgrad_workspace_bytes())");
     FD_REQUIRE(p->layout == 0 || p->layout == 1, FD_E_INVAL, "fd_conv2d_bwd_weight: layout must be 0 (OHWI) or 1 (OIHW)");
     const bool need_reduce = nsplit > 1 || p->layout != 0 || p->scale != nullptr;
     a.out = need_reduce ? (float*)p->workspace : p->dw;
-    const dim3 grid(tiles, (unsigned)((mo + a.rows_per_split - 1) / a.rows_per_split));
-    const bool one = p->in.nseg == 1;
-    if (bm == 32 && one) hipLaunchKernelGGL((conv_wgrad_kernel<128, true, 32>), grid, dim3(256), 0, stream, a);
-    else if (bm == 32) hipLaunchKernelGGL((conv_wgrad_kernel<128, false, 32>), grid, dim3(256), 0, stream, a);
-    else if (bn == 128 && one) hipLaunchKernelGGL((conv_wgrad_kernel<128, true, 128>), grid, dim3(256), 0, stream, a);
-    else if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, false, 128>), grid, dim3(256), 0, stream, a);
-    else if (one) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, 128>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<64, false, 128>), grid, dim3(256), 0, stream, a);
+    const dim3 grid(tiles, ny);
+    if (bm == 32) hipLaunchKernelGGL((conv_wgrad_kernel<128, 32>), grid, dim3(256), 0, stream, a);
+    else if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, stream, a);
     FD_CHECK_LAUNCH("fd_conv2d_bwd_weight");
     if (need_reduce) {
         const long n4 = a.slab / 4;

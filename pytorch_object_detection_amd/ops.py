@@ -251,7 +251,7 @@ def conv_wgrad(x: Rows, dy: Rows, segs_in: Segs, *, Cin: int, Cout: int, k: int,
     out_rows = conv_out_segs(segs_in, k, stride, pad, dil).rows
     dev = x.buf.device
     dw = torch.empty((Cout, Cin, k, k) if oihw else (Cout, k, k, Cin), dtype=torch.float32, device=dev)
-    nb = _lib.lib().fd_conv_wgrad_workspace_bytes(out_rows, Cin, Cout, k, k) if nsplit <= 0 else nsplit * dw.numel() * 4
+    nb = _lib.lib().fd_conv_wgrad_workspace_bytes(out_rows, Cin, Cout, k, k) if nsplit <= 0 else (nsplit + 8) * dw.numel() * 4
     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=dev)
     p = _lib.WgradParams()
     p.nsplit = max(nsplit, 0)

@@ -17,7 +17,9 @@ SHAPES = [
     (512, 512, 3, 1, 1, 16, 16), (2048, 512, 1, 1, 1, 16, 16), (512, 2048, 1, 1, 1, 16, 16),
     (256, 512, 1, 1, 1, 64, 64), (512, 256, 1, 1, 1, 64, 64),
 ]
-if os.environ.get('SHAPES'):
+if os.environ.get('CUSTOM'):
+    SHAPES = [tuple(int(v) for v in t.split(',')) for t in os.environ['CUSTOM'].split(';')]
+elif os.environ.get('SHAPES'):
     SHAPES = [SHAPES[int(i)] for i in os.environ['SHAPES'].split(',')]
 tot = {s: 0.0 for s in splits}
 for Cin, Cout, k, stride, dil, H, W in SHAPES:
