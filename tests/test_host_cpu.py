@@ -36,14 +36,20 @@ def test_struct_layout_matches_c():
     int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(fd_segs), sizeof(fd_conv_params),
         offsetof(fd_conv_params, x_cs), offsetof(fd_conv_params, seg_param), offsetof(fd_conv_params, in),
         offsetof(fd_conv_params, tile), offsetof(fd_conv_params, ksplit), offsetof(fd_conv_params, workspace),
-        offsetof(fd_conv_params, workspace_bytes), offsetof(fd_conv_params, precision)); return 0; }'''
+        offsetof(fd_conv_params, workspace_bytes), offsetof(fd_conv_params, precision));
+      printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(fd_conv_wgrad_params), offsetof(fd_conv_wgrad_params, dw),
+        offsetof(fd_conv_wgrad_params, workspace), offsetof(fd_conv_wgrad_params, nsplit), offsetof(fd_conv_wgrad_params, layout),
+        offsetof(fd_conv_wgrad_params, scale), offsetof(fd_conv_wgrad_params, in)); return 0; }'''
     exe = os.path.join(ROOT, "oracle", "_build", "abi_probe")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
     vals = [int(v) for v in subprocess.check_output([exe]).split()]
     P = _lib.ConvParams
+    Q = _lib.WgradParams
     assert vals == [ctypes.sizeof(_lib.Segs), ctypes.sizeof(P), P.x_cs.offset, P.seg_param.offset, P.segs.offset,
-                    P.tile.offset, P.ksplit.offset, P.workspace.offset, P.workspace_bytes.offset, P.precision.offset]
+                    P.tile.offset, P.ksplit.offset, P.workspace.offset, P.workspace_bytes.offset, P.precision.offset,
+                    ctypes.sizeof(Q), Q.dw.offset, Q.workspace.offset, Q.nsplit.offset, Q.layout.offset, Q.scale.offset,
+                    Q.segs.offset]
 
 
 def test_segs_table():
