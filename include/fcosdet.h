@@ -93,7 +93,8 @@ const char* fd_last_error(void);
 #define FD_TILE_64x128_SB 9
 #define FD_TILE_256x128 10   /* 8 waves (512 threads), 4 x 2 wave tiles of 64 x 64 */
 #define FD_TILE_256x128_SB 11
-#define FD_TILE_COUNT 11
+#define FD_TILE_128x96_SB 12
+#define FD_TILE_COUNT 12
 
 typedef struct fd_conv_params {
     const float* x;

@@ -10,7 +10,8 @@ CONV_GENERIC, CONV_STEM = 0, 1
 PREC_F32, PREC_F16X3 = 0, 1
 TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (128, 32), 6: (128, 96),
          7: (128, 128), 8: (128, 64), 9: (64, 128),   # 7-9: single-LDS-buffer variants
-         10: (256, 128), 11: (256, 128)}             # 8-wave tile (11: single LDS buffer)
+         10: (256, 128), 11: (256, 128),             # 8-wave tile (11: single LDS buffer)
+         12: (128, 96)}                              # 128x96, single LDS buffer
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcosdet_hip.so")

@@ -532,6 +532,7 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
             case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true, 0, true>(a, stream);
             case FD_TILE_128x32: return launch_conv<4, 1, 1, 1, false, false, 0, true>(a, stream);
             case FD_TILE_128x96: return launch_conv<4, 1, 1, 3, false, false, 0, true>(a, stream);
+            case FD_TILE_128x96_SB: return launch_conv<4, 1, 1, 3, false, true, 0, true>(a, stream);
             case FD_TILE_256x128:
                 return tg ? launch_conv<4, 2, 2, 2, false, false, 1, true>(a, stream) : launch_conv<4, 2, 2, 2, false, false, 0, true>(a, stream);
             case FD_TILE_256x128_SB:
@@ -557,6 +558,7 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
         case FD_TILE_64x64: return launch_conv<2, 2, 1, 1, false>(a, stream);
         case FD_TILE_128x32: return launch_conv<4, 1, 1, 1, false>(a, stream);
         case FD_TILE_128x96: return launch_conv<4, 1, 1, 3, false>(a, stream);
+        case FD_TILE_128x96_SB: return launch_conv<4, 1, 1, 3, false, true>(a, stream);
         case FD_TILE_128x128_SB: return launch_conv<2, 2, 2, 2, false, true>(a, stream);
         case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true>(a, stream);
         case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true>(a, stream);

@@ -180,7 +180,7 @@ def heuristic_conv(M: int, Cout: int, KT: int, have_ws: bool) -> int:
     if Cout <= 64:
         tiles, bm, bn = 4, 64, 64
     elif Cout <= 96:
-        return 6
+        return 12
     else:
         def nblk(bm_, bn_):
             return -(-M // bm_) * -(-Cout // bn_)
