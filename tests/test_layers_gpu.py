@@ -11,6 +11,7 @@ from pytorch_object_detection_amd import ops
 from pytorch_object_detection_amd._lib import ACT_EXP, ACT_NONE, ACT_RELU, ACT_SILU, Segs
 
 pytestmark = pytest.mark.gpu
+from pytorch_object_detection_amd._lib import TILES as _TILE_IDS  # noqa: E402
 DEV = "cuda:0"
 ATOL, RTOL = 1e-4, 1e-5
 
@@ -65,7 +66,7 @@ def test_conv_single_level(case, prec):
     y = ops.new_rows(B * Ho * Wo, Cout, DEV)
     rr = to_rows(res) if use_res else None
     wp = ops.pack_conv_weight_f16x3(w.to(DEV)) if prec == "f16x3" else ops.pack_conv_weight(w.to(DEV))
-    for tile in ([0, 10, 11] if prec == "f32" else [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]):
+    for tile in ([0] if prec == "f32" else []) + sorted(_TILE_IDS):
         y.buf.fill_(float("nan"))
         ops.conv_call(xr, segs, wp, y, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil,
                       scale=scale.to(DEV) if use_bn else None, shift=shift.to(DEV), res=rr, act=act, tile=tile,
