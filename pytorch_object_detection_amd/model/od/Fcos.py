@@ -184,6 +184,9 @@ class FCOS(PlannedModule):
         if self.training:
             self._check_train_input(x)
             return self.head.train_forward(self.FPN.train_forward(trunk_train_forward(self.backbone.trunk, x)))
+        chunk = self.plan_batch_limit(x)
+        if x.shape[0] > chunk:
+            return self._forward_chunked(x, chunk)
         plan = self.plan_for(x)
         plan.image_ref[0] = x.contiguous()
         plan.run(events)

@@ -219,10 +219,13 @@ class HalfInvertedStageFCOS(PlannedModule):
         (strides 8..128; reference HISFcos.py:70-74).  The tensors are views of plan-owned buffers and are
         overwritten by the next forward of the same shape."""
         if self.training:
-            # training: autograd forward on stock PyTorch-ROCm ops (conv backward is MIOpen's); the losses, their
-            # gradients and the target assignment are the HIP kernels of model.loss / model.modules.head
+            # training: an autograd graph whose nodes are the HIP kernels (train_ops.py: fused conv + frozen BN + ReLU, data /
+            # weight gradients, depthwise, GroupNorm); the losses and the target assignment are HIP kernels too
             self._check_train_input(x)
             return self.head.train_forward(self.fpn.train_forward(trunk_train_forward(self.backbone.trunk, x)))
+        chunk = self.plan_batch_limit(x)
+        if x.shape[0] > chunk:
+            return self._forward_chunked(x, chunk)
         plan = self.plan_for(x)
         plan.image_ref[0] = x.contiguous()
         plan.run(events)

@@ -55,6 +55,26 @@ class PlannedModule(nn.Module):
     def invalidate_plans(self) -> None:
         self._plans.clear()
 
+    max_plan_batch = None    # optional cap on the images one plan handles (larger batches run as consecutive sub-batches)
+
+    def plan_batch_limit(self, x: torch.Tensor) -> int:
+        """Images per plan: the conv kernels address each activation buffer through a 32-bit buffer descriptor
+        (< 3 GiB); the largest map is the stem / layer1 output, H/2 * W/2 * 64 floats per image."""
+        H, W = (x.shape[1], x.shape[2]) if x.dtype == torch.uint8 else (x.shape[2], x.shape[3])
+        per_image = (H // 2) * (W // 2) * 64 * 4
+        lim = max(1, int((3 * 2 ** 30 - 2 ** 24) // per_image))
+        return min(lim, self.max_plan_batch) if self.max_plan_batch else lim
+
+    def _forward_chunked(self, x: torch.Tensor, chunk: int):
+        """Batches beyond plan_batch_limit: consecutive sub-batches through the (cached) plans, outputs copied out of the
+        plan-owned buffers and concatenated per level (images are independent end to end)."""
+        parts = []
+        for i in range(0, x.shape[0], chunk):
+            out = self.forward(x[i:i + chunk])
+            parts.append([[t.clone() for t in grp] for grp in out])
+        return tuple([torch.cat([p[g][lv] for p in parts], 0) for lv in range(5)] for g in range(3))
+
+
     @staticmethod
     def _check_image(x: torch.Tensor) -> None:
         if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3:

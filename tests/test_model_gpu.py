@@ -272,3 +272,22 @@ def test_fcos_fpn_head_on_efficientnet_b3_widths():
     pyr2 = fpn([f.to(DEV) for f in feats2])
     for i in range(5):
         np.testing.assert_allclose(pyr2[i].cpu().numpy(), ps2[i].numpy(), **TOL)
+
+
+def test_batches_beyond_the_plan_limit_run_as_sub_batches():
+    """A batch larger than one plan can address (3 GiB per activation buffer: ~120 images at 640^2) runs as consecutive
+    sub-batches with identical results; exercised at small scale through the max_plan_batch knob."""
+    torch.manual_seed(17)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).eval().to(DEV)
+    x = torch.randn(5, 3, 128, 160, device=DEV)
+    assert 100 <= model.plan_batch_limit(torch.empty(1, 3, 640, 640)) <= 122
+    whole = [[t.clone() for t in grp] for grp in model(x)]
+    model.max_plan_batch = 2
+    parts = model(x)
+    for ga, gb in zip(whole, parts):
+        for a, b in zip(ga, gb):      # not bit-equal: small maps pick split-K by batch size (another fp32 summation order)
+            assert a.shape == b.shape
+            np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=2e-5)
+    fh = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
+    sb = fh.detect_padded(parts)          # plain lists of NCHW tensors are accepted like the plan-owned pyramid
+    assert sb[0].shape[0] == 5 and int(sb[3].min()) >= 0
