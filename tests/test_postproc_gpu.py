@@ -222,3 +222,18 @@ def test_edge_shapes_and_errors():
         FCOSHead(0.05, 0.6, 1500, [8])(big)
     with pytest.raises(FdError):
         ops.fcos_topk(_t(np.zeros((1, 10), np.float32)), _t(np.zeros((1, 10), np.int32)), _t(np.zeros((1, 10, 4), np.float32)), 11)
+
+
+def test_c_abi_from_a_torch_free_host():
+    """tests/abi/abi_host_check.cpp: a plain C++ / HIP-runtime program (no Python, no torch) drives fd_batched_nms,
+    fd_clip_boxes and fd_pairwise_iou on its own hipMalloc'ed buffers and checks them bit for bit against the oracle's C
+    restatement -- the C-ABI is usable exactly as INTEGRATION.md's non-Python bindings would use it."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_build", "abi_host_check")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "abi_host_check"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi_host_check ok" in out.stdout
