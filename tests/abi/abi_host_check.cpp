@@ -7,7 +7,7 @@
 //
 // Checks: fd_version, error path (null pointer -> negative code + fd_last_error text), fd_batched_nms kept indices
 // bit-identical to ref_post_process on 4 images x 1000 candidates (crowded boxes, 80 classes), fd_clip_boxes,
-// fd_pairwise_iou vs ref_pairwise_iou bit for bit.
+// fd_pairwise_iou vs ref_pairwise_iou bit for bit, one fused fd_conv2d_nhwc_f32 launch vs a naive fp64 loop.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -111,6 +111,58 @@ int main() {
     ref_pairwise_iou(boxes.data(), &boxes[(size_t)K * 4], Na, Nb, 0, r_iou.data());
     CHECK(std::memcmp(h_iou.data(), r_iou.data(), h_iou.size() * 4) == 0, "pairwise IoU differs from the oracle");
 
-    std::printf("abi_host_check ok: %d images x %d candidates, %ld boxes kept, indices / clipped boxes / IoU identical to the oracle\n", N, K, kept_total);
+    // one fused conv launch: 3x3, 64 -> 96 channels, folded-BN scale / shift, residual, ReLU on a 2 x 9 x 7 map, against a
+    // naive double-precision loop (tolerance 1e-4: north_star's conv bar); weights packed as the header documents
+    {
+        const int B = 2, H = 9, W = 7, Cin = 64, Cout = 96, KH = 3;
+        const int M = B * H * W;
+        std::vector<float> x((size_t)M * Cin), wt((size_t)Cout * Cin * 9), wp(wt.size()), sc(Cout), sf(Cout), res((size_t)M * Cout);
+        for (auto& v : x) v = urand() * 2.f - 1.f;
+        for (auto& v : wt) v = (urand() * 2.f - 1.f) / 24.f;          // [co][ci][r][q]
+        for (auto& v : sc) v = 0.5f + urand();
+        for (auto& v : sf) v = urand() - 0.5f;
+        for (auto& v : res) v = urand() - 0.5f;
+        for (int co = 0; co < Cout; ++co)                              // -> [Cout][Cin/32][KH][KW][32]
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int t = 0; t < 9; ++t)
+                    wp[(((size_t)co * (Cin / 32) + ci / 32) * 9 + t) * 32 + ci % 32] = wt[((size_t)co * Cin + ci) * 9 + t];
+        float *dx = dev_copy(x), *dw = dev_copy(wp), *dsc = dev_copy(sc), *dsf = dev_copy(sf), *dres = dev_copy(res), *dy;
+        HIPOK(hipMalloc((void**)&dy, (size_t)M * Cout * 4));
+        fd_conv_params p;
+        std::memset(&p, 0, sizeof p);
+        p.x = dx; p.w = dw; p.scale = dsc; p.shift = dsf; p.res = dres; p.y = dy;
+        p.x_cs = Cin; p.res_cs = Cout; p.y_cs = Cout;
+        p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = KH; p.stride = 1; p.pad = 1; p.dil = 1;
+        p.act = FD_ACT_RELU; p.mode = FD_CONV_GENERIC; p.precision = FD_PREC_F32;
+        p.in.nseg = 1; p.in.batch = B; p.in.H[0] = H; p.in.W[0] = W; p.in.m_start[0] = 0;
+        for (int s = 1; s <= FD_MAX_SEG; ++s) p.in.m_start[s] = M;
+        CHECK(fd_conv2d_nhwc_f32(&p, st) == FD_OK, "fd_conv2d_nhwc_f32: %s", fd_last_error());
+        std::vector<float> y((size_t)M * Cout);
+        HIPOK(hipStreamSynchronize(st));
+        HIPOK(hipMemcpy(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int n = 0; n < B; ++n)
+            for (int h = 0; h < H; ++h)
+                for (int w = 0; w < W; ++w)
+                    for (int co = 0; co < Cout; ++co) {
+                        double a = 0;
+                        for (int r = 0; r < 3; ++r)
+                            for (int q = 0; q < 3; ++q) {
+                                const int hi = h + r - 1, wi = w + q - 1;
+                                if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
+                                const float* px = &x[((size_t)(n * H + hi) * W + wi) * Cin];
+                                for (int ci = 0; ci < Cin; ++ci) a += (double)px[ci] * wt[((size_t)co * Cin + ci) * 9 + r * 3 + q];
+                            }
+                        const size_t m = (size_t)(n * H + h) * W + w;
+                        double v = a * sc[co] + sf[co] + res[m * Cout + co];
+                        if (v < 0) v = 0;
+                        const double d = v - y[m * Cout + co];
+                        if (d > worst) worst = d;
+                        if (-d > worst) worst = -d;
+                    }
+        CHECK(worst < 1e-4, "conv differs from the naive loop by %g", worst);
+    }
+
+    std::printf("abi_host_check ok: fused conv within 1e-4 of a naive fp64 loop; %d images x %d candidates, %ld boxes kept, indices / clipped boxes / IoU identical to the oracle\n", N, K, kept_total);
     return 0;
 }
