@@ -1,43 +1,55 @@
-"""Builder(cfg).model_build() / .opt_build(model) — the reference's bulider.py:10-43 factory (same spelling),
-with its defects fixed rather than copied: HISFCOS resolves (the reference points at a non-existent
-`od.proposed`), unknown names raise NotImplementedError, and Adam-family optimizers receive weight_decay by name."""
+"""Builder(cfg).model_build() / .opt_build(model): the factory the reference's scripts go through (bulider.py:10-43,
+module name spelled as there), written table-driven.  Behaviour differs from the reference where the reference is
+broken: 'HISFCOS' resolves (the reference looks up a module `od.proposed` that does not exist), an unknown model or
+optimizer raises NotImplementedError (the reference raises the NotImplemented *constant*), and the Adam family gets
+weight_decay as weight_decay (the reference passes it positionally into `betas`).  Only trainable parameters are handed
+to the optimizer (frozen BatchNorm / stage-1 weights carry requires_grad=False, HISFcos.py:57-68)."""
 from __future__ import annotations
+
+from typing import Callable, Dict
 
 import torch
 import torch.nn as nn
 
-from .model import od
-from .utill.utills import load_config  # noqa: F401
+from .utill.utills import load_config  # noqa: F401  (re-exported: `from bulider import Builder, load_config`)
+
+
+def _detectors() -> Dict[str, Callable[..., nn.Module]]:
+    from .model import od
+    return {"FCOS": od.Fcos.FCOS, "HISFCOS": od.HISFcos.HalfInvertedStageFCOS}
+
+
+_OPTIMIZERS: Dict[str, Callable[..., torch.optim.Optimizer]] = {
+    "SGD": lambda params, o: torch.optim.SGD(params, lr=o["lr"], momentum=o["momentum"], weight_decay=o["weight_decay"]),
+    "Adam": lambda params, o: torch.optim.Adam(params, lr=o["lr"], weight_decay=o["weight_decay"]),
+    "AdamW": lambda params, o: torch.optim.AdamW(params, lr=o["lr"], weight_decay=o["weight_decay"]),
+    "RAdam": lambda params, o: torch.optim.RAdam(params, lr=o["lr"], weight_decay=o["weight_decay"]),
+}
 
 
 class Builder:
+    """cfg: the dict load_config() returns (keys 'model', 'dataset_setting', and one block per detector name)."""
+
     def __init__(self, cfg: dict):
         self.config = cfg
-        self.model = cfg['model']['name']
+        self.model = cfg["model"]["name"]
+
+    def _block(self) -> dict:
+        try:
+            return self.config[self.model]
+        except KeyError:
+            raise NotImplementedError(f"no '{self.model}' block in the dataset config") from None
 
     def model_build(self) -> nn.Module:
-        if self.model not in self.config:
-            raise NotImplementedError(f"no '{self.model}' block in the dataset config")
-        cfg_model = self.config[self.model]
-        cob = cfg_model['CannelofBackbone']
-        noc = self.config['dataset_setting']['class_num']
-        channel = cfg_model['channel']
-        if self.model == 'FCOS':
-            return od.Fcos.FCOS(cob, noc, channel)
-        if self.model == 'HISFCOS':
-            return od.HISFcos.HalfInvertedStageFCOS(cob, noc, channel)
-        raise NotImplementedError(f"model '{self.model}' is outside the MI355X hot path (FCOS, HISFCOS)")
+        block = self._block()
+        ctor = _detectors().get(self.model)
+        if ctor is None:
+            raise NotImplementedError(f"model '{self.model}' is outside the MI355X hot path (FCOS, HISFCOS)")
+        return ctor(block["CannelofBackbone"], self.config["dataset_setting"]["class_num"], block["channel"])
 
     def opt_build(self, model: nn.Module) -> torch.optim.Optimizer:
-        cfg = self.config[self.model]['optimizer']
-        params = [p for p in model.parameters() if p.requires_grad]
-        name = cfg['name']
-        if name == 'SGD':
-            return torch.optim.SGD(params, cfg['lr'], cfg['momentum'], weight_decay=cfg['weight_decay'])
-        if name == 'Adam':
-            return torch.optim.Adam(params, cfg['lr'], weight_decay=cfg['weight_decay'])
-        if name == 'AdamW':
-            return torch.optim.AdamW(params, cfg['lr'], weight_decay=cfg['weight_decay'])
-        if name == 'RAdam':
-            return torch.optim.RAdam(params, cfg['lr'], weight_decay=cfg['weight_decay'])
-        raise NotImplementedError(f"optimizer '{name}'")
+        opt = self._block()["optimizer"]
+        make = _OPTIMIZERS.get(opt["name"])
+        if make is None:
+            raise NotImplementedError(f"optimizer '{opt['name']}'")
+        return make([p for p in model.parameters() if p.requires_grad], opt)
