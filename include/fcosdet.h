@@ -118,6 +118,9 @@ typedef struct fd_conv_params {
     void* workspace;           /* split-K scratch, fd_conv_workspace_bytes(out_rows, Cout, ksplit) bytes, 16-B aligned */
     int64_t workspace_bytes;
     int32_t precision; /* FD_PREC_F32 (exact fp32 MFMA) | FD_PREC_F16X3 (opt-in split-f16 products, see below) */
+    int32_t res_mode;  /* what `res` does: 0 = added (residual connection); 1 = ReLU mask: y = res > 0 ? v : 0 -- the data
+                          gradient of a layer whose input came out of a ReLU is masked in the epilogue that produces it
+                          (train step: removes the separate threshold pass) */
     float seg_param[FD_MAX_SEG]; /* per-level scalar for FD_ACT_EXP */
     fd_segs in;     /* input geometry */
 } fd_conv_params;

@@ -53,7 +53,7 @@ class ConvParams(C.Structure):
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("dil", C.c_int32),
                 ("act", C.c_int32), ("act_c0", C.c_int32), ("mode", C.c_int32), ("tile", C.c_int32), ("tag", C.c_int32), ("ksplit", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("precision", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("precision", C.c_int32), ("res_mode", C.c_int32),
                 ("seg_param", C.c_float * FD_MAX_SEG), ("segs", Segs)]
 
 

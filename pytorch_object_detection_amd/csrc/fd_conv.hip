@@ -36,6 +36,7 @@ struct ConvArgs {
     int kt_per;    // K-tiles per split-K slice (blockIdx.y = slice); KT when split-K is off
     long slice_stride;  // elements between consecutive split-K slabs in the workspace
     unsigned x_bytes, w_bytes;   // extents of the input / packed-weight buffers (raw buffer descriptors: OOB reads return 0)
+    int res_mask;  // 1: `res` is a ReLU mask (y = res > 0 ? v : 0) instead of an addend
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -313,7 +314,12 @@ void conv_igemm_kernel(ConvArgs a) {
                             float4 r;
                             if constexpr (SPLIT) r = *reinterpret_cast<const float4*>(a.res + (size_t)m * a.res_cs + a.res_co + nn);
                             else r = rres[i][j][p];
-                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                            if (a.res_mask) {
+                                v.x = r.x > 0.f ? v.x : 0.f; v.y = r.y > 0.f ? v.y : 0.f;
+                                v.z = r.z > 0.f ? v.z : 0.f; v.w = r.w > 0.f ? v.w : 0.f;
+                            } else {
+                                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                            }
                         }
                         if (a.act != FD_ACT_NONE) {
                             float prm = 0.f;
@@ -340,7 +346,10 @@ void conv_igemm_kernel(ConvArgs a) {
                     const int m = mb + 4 * lh + (e & 3) + 8 * (e >> 2);
                     if (n_ok && m < a.M) {
                         float v = acc[i][j][e] * sc + sf;
-                        if (a.res) v += a.res[(size_t)m * a.res_cs + a.res_co + n];
+                        if (a.res) {
+                            const float r = a.res[(size_t)m * a.res_cs + a.res_co + n];
+                            v = a.res_mask ? (r > 0.f ? v : 0.f) : v + r;
+                        }
                         float prm = 0.f;
                         if (act == FD_ACT_EXP) {
                             int s = 0;
@@ -385,7 +394,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, const fl
             const int n = nn + e;
             if (n >= a.Cout) continue;
             float r = o[e] * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
-            if (a.res) r += a.res[(size_t)m * a.res_cs + a.res_co + n];
+            if (a.res) {
+                const float rv = a.res[(size_t)m * a.res_cs + a.res_co + n];
+                r = a.res_mask ? (rv > 0.f ? r : 0.f) : r + rv;
+            }
             a.y[(size_t)m * a.y_cs + a.y_co + n] = fd_act(r, n >= a.act_c0 ? a.act : FD_ACT_NONE, prm);
         }
     }
@@ -447,6 +459,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     a.x_cs = p->x_cs; a.x_co = p->x_co; a.res_cs = p->res_cs; a.res_co = p->res_co; a.y_cs = p->y_cs; a.y_co = p->y_co;
     a.Cin = p->Cin; a.Cout = p->Cout; a.KW = p->KW; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;
     a.act = p->act; a.act_c0 = p->act_c0;
+    a.res_mask = (p->res && p->res_mode == 1) ? 1 : 0;
     a.nseg = p->in.nseg;
     long mo = 0;
     for (int s = 0; s < FD_MAX_SEG; ++s) {

@@ -61,8 +61,7 @@ def trunk_train_forward(trunk: nn.Module, x: torch.Tensor):
     gradient kernels; a frozen stem (freeze_stages(1)) runs on the inference kernels.  Returns (C3, C4, C5)."""
     import torch.nn.functional as F
 
-    from ...ops import ACT_NONE, ACT_RELU
-    from ...train_ops import conv_bn_act, stem_frozen, stem_is_frozen
+    from ...train_ops import bottleneck, stem_frozen, stem_is_frozen
     if stem_is_frozen(trunk, x):
         x = stem_frozen(trunk, x)
     else:                                                     # trainable 7x7 stem (Cin = 3): stock ops
@@ -70,10 +69,7 @@ def trunk_train_forward(trunk: nn.Module, x: torch.Tensor):
     feats = []
     for li in (1, 2, 3, 4):
         for blk in getattr(trunk, f"layer{li}"):
-            idt = x if blk.downsample is None else conv_bn_act(blk.downsample[0], blk.downsample[1], x, ACT_NONE)
-            y = conv_bn_act(blk.conv1, blk.bn1, x, ACT_RELU)
-            y = conv_bn_act(blk.conv2, blk.bn2, y, ACT_RELU)
-            x = conv_bn_act(blk.conv3, blk.bn3, y, ACT_RELU, residual=idt)
+            x = bottleneck(blk, x)          # one autograd node per block (train_ops._BottleneckRows)
         feats.append(x)
     return feats[1], feats[2], feats[3]
 

@@ -110,7 +110,7 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
               res: Optional[Rows] = None, act: int = ACT_NONE, act_c0: int = 0,
               seg_param: Optional[Sequence[float]] = None, stem: bool = False, tile: int = 0,
               tag: int = 0, precision: int = 0, ksplit: int = 1,
-              workspace: Optional[torch.Tensor] = None) -> Callable[[], None]:
+              workspace: Optional[torch.Tensor] = None, res_mask: bool = False) -> Callable[[], None]:
     """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream."""
     _need_gpu(w_packed, scale, shift)
     p = ConvParams()
@@ -124,6 +124,7 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, k, stride, pad, dil
     p.act, p.act_c0, p.mode = act, act_c0, (_lib.CONV_STEM if stem else _lib.CONV_GENERIC)
     p.tile, p.tag, p.precision, p.ksplit = tile, tag, precision, ksplit
+    p.res_mode = 1 if (res_mask and res is not None) else 0
     if workspace is not None:
         _need_gpu(workspace)
         p.workspace, p.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()

@@ -141,7 +141,7 @@ _TILE_CACHE: dict = {}
 
 
 def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.Tensor, *, k, stride, pad, dil, scale=None,
-                 shift=None, res: Optional[torch.Tensor] = None, act=ACT_NONE) -> None:
+                 shift=None, res: Optional[torch.Tensor] = None, act=ACT_NONE, res_mask: bool = False) -> None:
     """y = act(conv(x, w) * scale + shift + res) on contiguous rows buffers; w_packed from ops.pack_conv_weight_hip.
     The block tile comes from the same table / heuristic / FD_AUTOTUNE timing as the inference plans (ops.autotune_conv),
     remembered per shape for the process."""
@@ -149,7 +149,7 @@ def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.T
     out_rows = y.shape[0]
     KT = (Cin // 32) * k * k
     hw = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
-    key = f"B{segs.batch}|{hw}|{Cin}>{Cout}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{Cin}|ycs{Cout}"
+    key = f"B{segs.batch}|{hw}|{Cin}>{Cout}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{Cin}|ycs{Cout}"   # (mask / add: same cost)
     code = _TILE_CACHE.get(key)
     ws = None
     if code is None or (code >> 8) > 1:
@@ -157,7 +157,7 @@ def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.T
         if 0 < nb <= 256 * 1024 * 1024:
             ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
     call = ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
-                         shift=shift, res=_r(res) if res is not None else None, act=act, workspace=ws)
+                         shift=shift, res=_r(res) if res is not None else None, act=act, workspace=ws, res_mask=res_mask)
     if code is None:
         code = _TILE_CACHE[key] = ops.autotune_conv(call, key, out_rows, Cout, KT)
     p = call.params
@@ -247,6 +247,108 @@ class MergedConv:
         self.weight = torch.cat((a.weight, b.weight), 0)
         self.bias = torch.cat((a.bias, b.bias), 0) if a.bias is not None else None
         self.stride, self.padding, self.dilation, self.kernel_size = a.stride, a.padding, a.dilation, a.kernel_size
+
+
+class _BottleneckRows(torch.autograd.Function):
+    """A whole ResNet bottleneck with frozen BatchNorm as one autograd node (torchvision Bottleneck.forward):
+         y1 = relu(bn1(conv1 x));  y2 = relu(bn2(conv2 y1));  out = relu(bn3(conv3 y2) + (downsample(x) | x))
+    Forward: the same 3-4 fused conv launches as separate nodes would issue.  Backward, written out by hand so that the
+    elementwise work rides in the conv epilogues: one mask pass for the block output, then every data gradient is masked
+    by the ReLU of the layer it flows into INSIDE the conv that produces it (res_mode 1) and the identity gradient is added
+    in conv1's data-gradient epilogue (res_mode 0): per block 1 elementwise pass instead of 3 masks + 1 add."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, w1, w2, w3, wd, c1, c2, c3, cd, segs, stride):
+        x = x.contiguous()
+        dev = x.device
+        so = ops.conv_out_segs(segs, 3, stride, 1, 1)
+        P, C4 = w1.shape[0], w3.shape[0]
+        y1 = torch.empty(segs.rows, P, dtype=torch.float32, device=dev)
+        y2 = torch.empty(so.rows, P, dtype=torch.float32, device=dev)
+        out = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
+        _conv_launch(x, segs, ops.pack_conv_weight_hip(w1), y1, k=1, stride=1, pad=0, dil=1, scale=c1[0], shift=c1[1], act=ACT_RELU)
+        _conv_launch(y1, segs, ops.pack_conv_weight_hip(w2), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0], shift=c2[1],
+                     act=ACT_RELU)
+        if wd is not None:
+            idt = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
+            _conv_launch(x, segs, ops.pack_conv_weight_hip(wd), idt, k=1, stride=stride, pad=0, dil=1, scale=cd[0], shift=cd[1])
+        else:
+            idt = x
+        _conv_launch(y2, so, ops.pack_conv_weight_hip(w3), out, k=1, stride=1, pad=0, dil=1, scale=c3[0], shift=c3[1], res=idt,
+                     act=ACT_RELU)
+        ctx.save_for_backward(x, y1, y2, out, w1, w2, w3, wd, c1[0], c2[0], c3[0], cd[0] if wd is not None else None)
+        ctx.geom = (segs, so, stride)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, gout):
+        x, y1, y2, out, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors
+        segs, so, stride = ctx.geom
+        need_x = ctx.needs_input_grad[0]
+        P, Cin, C4 = w1.shape[0], w1.shape[1], w3.shape[0]
+        g = torch.ops.aten.threshold_backward(gout.contiguous(), out, 0.0)          # the one elementwise pass of the block
+        gw1 = gw2 = gw3 = gwd = gx = None
+        wg = lambda xx, gg, sg, Ci, Co, k, st, pad, sc: ops.conv_wgrad(_r(xx), _r(gg), sg, Cin=Ci, Cout=Co, k=k, stride=st,  # noqa: E731
+                                                                     pad=pad, dil=1, scale=sc, oihw=True)
+        if ctx.needs_input_grad[3]:
+            gw3 = wg(y2, g, so, P, C4, 1, 1, 0, s3)
+        g2 = torch.empty_like(y2)                                                    # d/d(conv2 output), ReLU-masked in the epilogue
+        _conv_launch(g, so, ops.pack_conv_weight_hip(w3, s3, dgrad=True), g2, k=1, stride=1, pad=0, dil=1, res=y2, res_mask=True)
+        if ctx.needs_input_grad[2]:
+            gw2 = wg(y1, g2, segs, P, P, 3, stride, 1, s2)
+        if stride == 1:
+            g1 = torch.empty_like(y1)
+            _conv_launch(g2, so, ops.pack_conv_weight_hip(w2, s2, dgrad=True), g1, k=3, stride=1, pad=1, dil=1, res=y1, res_mask=True)
+        else:   # strided 3x3: stock data gradient, masked separately
+            B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
+            g1 = torch.ops.aten.convolution_backward(from_rows(g2, B, Ho, Wo), from_rows(y1, B, H, W), w2.detach() * s2.view(-1, 1, 1, 1),
+                                                     None, [stride, stride], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            g1 = torch.ops.aten.threshold_backward(to_rows(g1), y1, 0.0)
+        if ctx.needs_input_grad[1]:
+            gw1 = wg(x, g1, segs, Cin, P, 1, 1, 0, s1)
+        if wd is not None and ctx.needs_input_grad[4]:
+            gwd = wg(x, g, segs, Cin, C4, 1, stride, 0, sd)
+        if need_x:
+            if wd is None:
+                gid = g                                                             # identity path
+            elif stride == 1:
+                gid = torch.empty_like(x)
+                _conv_launch(g, so, ops.pack_conv_weight_hip(wd, sd, dgrad=True), gid, k=1, stride=1, pad=0, dil=1)
+            else:
+                B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
+                gid = to_rows(torch.ops.aten.convolution_backward(from_rows(g, B, Ho, Wo), from_rows(x, B, H, W),
+                                                                   wd.detach() * sd.view(-1, 1, 1, 1), None, [stride, stride], [0, 0],
+                                                                   [1, 1], False, [0, 0], 1, [True, False, False])[0])
+            gx = torch.empty_like(x)                                                # conv1's data gradient + the identity gradient
+            _conv_launch(g1, segs, ops.pack_conv_weight_hip(w1, s1, dgrad=True), gx, k=1, stride=1, pad=0, dil=1, res=gid)
+        return gx, gw1, gw2, gw3, gwd, None, None, None, None, None, None
+
+
+def bottleneck(blk: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """torchvision-style Bottleneck (conv1/bn1, conv2/bn2, conv3/bn3, optional downsample) on an NCHW-shaped tensor: one
+    fused autograd node when every BatchNorm is frozen and the shapes are covered, else layer by layer (conv_bn_act)."""
+    _need_cuda(x)
+    ds = blk.downsample
+    bns = [blk.bn1, blk.bn2, blk.bn3] + ([ds[1]] if ds is not None else [])
+    convs = [blk.conv1, blk.conv2, blk.conv3] + ([ds[0]] if ds is not None else [])
+    ok = (not _STOCK and all(bn_is_frozen(b) for b in bns) and all(c.bias is None and _dense_ok(c, x) and c.out_channels % 32 == 0
+                                                                   for c in convs)
+          and blk.conv1.kernel_size == (1, 1) and blk.conv3.kernel_size == (1, 1) and blk.conv2.kernel_size == (3, 3)
+          and blk.conv2.padding == (1, 1) and blk.conv2.dilation == (1, 1) and blk.conv1.stride == (1, 1) and blk.conv3.stride == (1, 1)
+          and (ds is None or (ds[0].kernel_size == (1, 1) and ds[0].stride == blk.conv2.stride)))
+    if not ok:
+        idt = x if ds is None else conv_bn_act(ds[0], ds[1], x, ACT_NONE)
+        y = conv_bn_act(blk.conv1, blk.bn1, x, ACT_RELU)
+        y = conv_bn_act(blk.conv2, blk.bn2, y, ACT_RELU)
+        return conv_bn_act(blk.conv3, blk.bn3, y, ACT_RELU, residual=idt)
+    B, _, H, W = x.shape
+    s = blk.conv2.stride[0]
+    out = _BottleneckRows.apply(to_rows(x), blk.conv1.weight, blk.conv2.weight, blk.conv3.weight, ds[0].weight if ds is not None else None,
+                                _bn_fold(blk.bn1), _bn_fold(blk.bn2), _bn_fold(blk.bn3), _bn_fold(ds[1]) if ds is not None else (None, None),
+                                Segs.make(B, [(H, W)]), s)
+    return from_rows(out, B, (H - 1) // s + 1, (W - 1) // s + 1)
 
 
 # --------------------------------------------------------------------------------------------- depthwise 3x3

@@ -513,3 +513,60 @@ def test_dwconv_backward_adjoint_identity_full_size():
     scale = float(y.buf.double().norm() * dy.double().norm())
     assert abs(s_y - float((dw.double() * w.double()).sum())) / scale < 2e-6
     assert abs(s_y - float((dx.buf.double() * x.double()).sum())) / scale < 2e-6
+
+
+@pytest.mark.parametrize("stride,down", [(1, False), (1, True), (2, True)])
+def test_fused_bottleneck_autograd(stride, down):
+    """train_ops.bottleneck (one autograd node; masks and the identity add ride in the conv epilogues) vs the stock module
+    chain on the CPU: output, input gradient and all four weight gradients."""
+    from pytorch_object_detection_amd import train_ops
+    gen = torch.Generator().manual_seed(10 * stride + int(down))
+    Cin, P = (128, 32) if not down else (64, 32)
+    C4 = 4 * P
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(Cin, P, 1, bias=False)
+            self.conv2 = torch.nn.Conv2d(P, P, 3, stride, 1, bias=False)
+            self.conv3 = torch.nn.Conv2d(P, C4, 1, bias=False)
+            self.bn1, self.bn2, self.bn3 = _frozen_bn(P, gen), _frozen_bn(P, gen), _frozen_bn(C4, gen)
+            self.downsample = torch.nn.Sequential(torch.nn.Conv2d(Cin, C4, 1, stride, bias=False), _frozen_bn(C4, gen)) if down else None
+
+        def forward(self, x):
+            idt = x if self.downsample is None else self.downsample(x)
+            y = F.relu(self.bn1(self.conv1(x)))
+            y = F.relu(self.bn2(self.conv2(y)))
+            return F.relu(self.bn3(self.conv3(y)) + idt)
+
+    blk = Blk()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            with torch.no_grad():
+                m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * (2.0 / (m.weight.shape[1] * m.weight.shape[2] ** 2)) ** 0.5)
+    blk.eval()
+    x = torch.randn(2, Cin, 10, 12, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    ref = blk(xr)
+    dy = torch.randn(ref.shape, generator=gen)
+    ref.backward(dy)
+    b2 = copy.deepcopy(blk).to(DEV)
+    for p in b2.parameters():
+        p.grad = None
+    xd = x.clone().to(DEV).requires_grad_(True)
+    out = train_ops.bottleneck(b2, xd)
+    seen, stack = set(), [out.grad_fn]
+    while stack:
+        fn = stack.pop()
+        if fn is not None and fn not in seen:
+            seen.add(fn)
+            stack.extend(f for f, _ in fn.next_functions)
+    assert any(type(f).__name__ == "_BottleneckRowsBackward" for f in seen)
+    out.backward(dy.to(DEV))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    pairs = [(xd.grad, xr.grad)] + [(getattr(b2, n).weight.grad, getattr(blk, n).weight.grad) for n in ("conv1", "conv2", "conv3")]
+    if down:
+        pairs.append((b2.downsample[0].weight.grad, blk.downsample[0].weight.grad))
+    for a, b in pairs:
+        s = float(b.abs().max())
+        np.testing.assert_allclose(a.cpu().numpy() / s, b.numpy() / s, atol=3e-5)
