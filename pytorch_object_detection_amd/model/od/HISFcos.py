@@ -37,11 +37,25 @@ class HisBlock(nn.Module):
 
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
         """Training-time autograd forward (dense convs on the HIP kernels via train_ops); inference runs engine._his_block."""
-        x1 = F.silu(cba(self.conv1, self.bn1, x))              # conv + frozen BN fused; SiLU stock (needs pre-activation)
+        if T.covered(self.conv1, self.bn1, x) and T.covered(self.conv2, None, x) and self.conv1.bias is not None:
+            # conv1 (+ frozen bn1) and conv2 read the same map: one 2*half-wide launch forward, one data gradient (no gradient
+            # add for x) and one weight gradient backward; the halves are channel views of its output
+            B, _, H, W = x.shape
+            sc, sf = T._bn_fold(self.bn1)
+            half = self.conv1.out_channels
+            both = T._ConvRows.apply(T.to_rows(x), torch.cat((self.conv1.weight, self.conv2.weight), 0),
+                                     torch.cat((sc, torch.ones_like(sc))),
+                                     torch.cat((self.conv1.bias * sc + sf, self.conv2.bias)), None, Segs.make(B, [(H, W)]), 1, 0, 1,
+                                     ACT_NONE)
+            x1 = F.silu(T.from_rows(both[:, :half], B, H, W))    # SiLU stock (its derivative needs the pre-activation)
+            x2 = T.from_rows(both[:, half:], B, H, W)
+        else:
+            x1 = F.silu(cba(self.conv1, self.bn1, x))
+            x2 = tconv(self.conv2, x)
         se = self.conv1_2.excitation
         gate = se(x1.mean((2, 3), keepdim=True))
         left = torch.cat((cba(self.conv1_1, self.bn2, x1, ACT_RELU), x1 * gate), 1)
-        mid = torch.cat((cba(self.conv3, self.bn3, left, ACT_RELU), tconv(self.conv2, x)), 1)
+        mid = torch.cat((cba(self.conv3, self.bn3, left, ACT_RELU), x2), 1)
         return F.silu(cba(self.conv4, self.bn4, mid))
 
 
