@@ -122,8 +122,9 @@ def padded_input(plan: Plan, rows: int, C: int):
 
 def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, y: Rows, *, bn=None, act=ACT_NONE,
              res: Optional[Rows] = None, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
-             Cout: Optional[int] = None, act_c0: int = 0, seg_param=None, tag: int = 0) -> Segs:
-    """conv (+folded BN / bias) (+res) (+act).  `weight`/`bias` override conv's own (fused multi-conv launches)."""
+             Cout: Optional[int] = None, act_c0: int = 0, seg_param=None, tag: int = 0, fold=None) -> Segs:
+    """conv (+folded BN / bias) (+res) (+act).  `weight`/`bias` override conv's own (fused multi-conv launches);
+    `fold` = (scale, shift) overrides the epilogue constants altogether (convs with different BN / bias merged by hand)."""
     dev = plan.device
     w = conv.weight if weight is None else weight
     b = (conv.bias if bias is None else bias)
@@ -141,7 +142,9 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     split = plan.precision == "f16x3"
     wp = ops.pack_conv_weight_f16x3(_dev(w, dev)) if split else ops.pack_conv_weight(_dev(w, dev))
     scale = shift = None
-    if bn is not None:
+    if fold is not None:
+        scale, shift = fold
+    elif bn is not None:
         scale, shift = ops.fold_bn(_dev(bn.weight, dev), _dev(bn.bias, dev), _dev(bn.running_mean, dev),
                                    _dev(bn.running_var, dev), bn.eps, _dev(b, dev) if b is not None else None)
     elif b is not None:
@@ -235,11 +238,18 @@ def _his_block(plan: Plan, name: str, blk, x: Rows, segs: Segs, out: Rows) -> No
     M = segs.rows
     half = blk.conv1.weight.shape[0]
     N, HW = segs.batch, segs.H[0] * segs.W[0]
-    x1 = pool.get(M, half)
     cat1 = pool.get(M, 2 * half)
     cat2 = pool.get(M, 2 * half)
-    add_conv(plan, name + ".conv1", x, segs, blk.conv1, x1, bn=blk.bn1, act=ACT_SILU)
-    add_conv(plan, name + ".conv2", x, segs, blk.conv2, cat2.slice(half, half))
+    # conv1 (+bn1, SiLU) and conv2 (bias only) read the same map: ONE 2*half-wide launch writing [x2 | x1] into cat2
+    # (the activation applies to channels >= half).  x1 lives in cat2's upper half until conv3 overwrites it with y, so
+    # conv4 sees [x2 | y] and gets its input channels swapped to match (the reference order is [y | x2], HISFcos.py:111).
+    s1, t1 = ops.fold_bn(_dev(blk.bn1.weight, dev), _dev(blk.bn1.bias, dev), _dev(blk.bn1.running_mean, dev),
+                         _dev(blk.bn1.running_var, dev), blk.bn1.eps, _dev(blk.conv1.bias, dev) if blk.conv1.bias is not None else None)
+    bias2 = _dev(blk.conv2.bias, dev) if blk.conv2.bias is not None else torch.zeros(half, device=dev)
+    w12 = torch.cat([blk.conv2.weight.detach(), blk.conv1.weight.detach()], 0)
+    fold = (torch.cat([torch.ones(half, device=dev), s1]).contiguous(), torch.cat([bias2, t1]).contiguous())
+    add_conv(plan, name + ".conv1+2", x, segs, blk.conv1, cat2, weight=w12, Cout=2 * half, act=ACT_SILU, act_c0=half, fold=fold)
+    x1 = cat2.slice(half, half)
     wd = ops.pack_dw_weight(_dev(blk.conv1_1.weight, dev))
     sc, sf = ops.fold_bn(_dev(blk.bn2.weight, dev), _dev(blk.bn2.bias, dev), _dev(blk.bn2.running_mean, dev),
                          _dev(blk.bn2.running_var, dev), blk.bn2.eps)
@@ -255,9 +265,11 @@ def _his_block(plan: Plan, name: str, blk, x: Rows, segs: Segs, out: Rows) -> No
     cr = w1.shape[0]
     plan.add(name + ".conv1_2", lambda: ops.se_scale(x1, w1, b1, w2, b2, v, N, HW, cr, ws))
     plan.keep += [wd, sc, sf, w1, b1, w2, b2, ws]
-    add_conv(plan, name + ".conv3", cat1, segs, blk.conv3, cat2.slice(0, half), bn=blk.bn3, act=ACT_RELU)
-    add_conv(plan, name + ".conv4", cat2, segs, blk.conv4, out, bn=blk.bn4, act=ACT_SILU)
-    pool.put(x1); pool.put(cat1); pool.put(cat2)
+    add_conv(plan, name + ".conv3", cat1, segs, blk.conv3, cat2.slice(half, half), bn=blk.bn3, act=ACT_RELU)
+    w4 = blk.conv4.weight.detach()
+    add_conv(plan, name + ".conv4", cat2, segs, blk.conv4, out, bn=blk.bn4, act=ACT_SILU,
+             weight=torch.cat([w4[:, half:], w4[:, :half]], 1))
+    pool.put(cat1); pool.put(cat2)
 
 
 def build_his_fpn(plan: Plan, fpn, feats):
