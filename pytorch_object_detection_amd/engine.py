@@ -3,6 +3,7 @@ launches over pre-allocated NHWC buffers.
 
  * frozen BatchNorm (HISFcos.py:57-68) is folded into the conv epilogue (scale, shift);
  * torch.cat (HISFcos.py:107,111) disappears: producers write channel slices of the consumer's input buffer;
+ * a HisBlock's conv1 (+bn1, SiLU) and conv2 (same input) run as one 2*half-wide conv (activation on the upper half only);
  * the 5 pyramid levels live in ONE rows buffer, so the shared-weight head (HISFcos.py:215-229) is one grouped
    launch per layer instead of five;
  * cls_conv / reg_conv (same input) run as one 512-wide conv, their GroupNorm(32,256) pair as GroupNorm(64,512);
