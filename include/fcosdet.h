@@ -160,6 +160,17 @@ int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_stream_t stre
 int32_t fd_pack_conv_weight_f32(const float* w, const float* scale, float* out, int32_t Cout, int32_t Cin, int32_t KH,
                                 int32_t KW, int32_t mode, fd_stream_t stream);
 
+/* The same for many weight tensors in ONE launch (a train step re-packs every layer after the optimizer update).
+ * `jobs_dev` is a DEVICE array of n_jobs descriptors (pointers are device pointers; the caller checks the divisibility
+ * rules of fd_pack_conv_weight_f32); max_elems = the largest Cout*Cin*KH*KW among them (sizes the grid). */
+typedef struct fd_pack_job {
+    const float* w;      /* [Cout][Cin][KH][KW] */
+    const float* scale;  /* [Cout] or NULL (mode 1 only) */
+    float* out;
+    int32_t Cout, Cin, KH, KW, mode, reserved;
+} fd_pack_job;
+int32_t fd_pack_conv_weights_batch_f32(const fd_pack_job* jobs_dev, int32_t n_jobs, int64_t max_elems, fd_stream_t stream);
+
 /* [N][3][H][W] fp32 (NCHW, the reference's input layout, dataset/voc.py:141-173) -> [N][H][W][4] (c=3 zero) */
 int32_t fd_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, fd_stream_t stream);
 /* Input pipeline tail on the device: uint8 [N][H][W][3] images, already resized and zero padded on

@@ -57,6 +57,11 @@ class ConvParams(C.Structure):
                 ("seg_param", C.c_float * FD_MAX_SEG), ("segs", Segs)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("scale", C.c_void_p), ("out", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("KH", C.c_int32), ("KW", C.c_int32), ("mode", C.c_int32), ("reserved", C.c_int32)]
+
+
 class WgradParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p),
                 ("x_cs", C.c_int32), ("x_co", C.c_int32), ("dy_cs", C.c_int32), ("dy_co", C.c_int32),
@@ -76,6 +81,7 @@ _SIGS = {
     "fd_conv_workspace_bytes": (_L, [_L, _I, _I]),
     "fd_conv_wgrad_workspace_bytes": (_L, [_L, _I, _I, _I, _I]),
     "fd_pack_conv_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "fd_pack_conv_weights_batch_f32": (_I, [_P, _I, _L, _P]),
     "fd_conv2d_bwd_weight_f32": (_I, [C.POINTER(WgradParams), _P]),
     "fd_nchw3_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _P]),
     "fd_nhwc_to_nchw": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),

@@ -254,6 +254,44 @@ extern "C" int32_t fd_pack_conv_weight_f32(const float* w, const float* scale, f
     return FD_OK;
 }
 
+// Many weight tensors in one launch (the train step re-packs ~150 of them after every optimizer update): a job table in
+// device memory, one workgroup range per job (blockIdx.y = job, grid-stride over its elements).
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const fd_pack_job* __restrict__ jobs) {
+    const fd_pack_job j = jobs[blockIdx.y];
+    const int taps = j.KH * j.KW;
+    const int K = j.mode ? j.Cout : j.Cin;
+    const long total = (long)j.Cout * j.Cin * taps;
+    const float* __restrict__ w = j.w;
+    const float* __restrict__ scale = j.scale;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c32 = (int)(i & 31);
+        long t = i >> 5;
+        const int tap = (int)(t % taps); t /= taps;
+        const int chunk = (int)(t % (K / 32));
+        const int n = (int)(t / (K / 32));
+        const int k = chunk * 32 + c32;
+        float v;
+        if (j.mode == 0) {
+            v = w[((long)n * j.Cin + k) * taps + tap];
+        } else {
+            v = w[((long)k * j.Cin + n) * taps + (taps - 1 - tap)];
+            if (scale) v *= scale[k];
+        }
+        j.out[i] = v;
+    }
+}
+
+extern "C" int32_t fd_pack_conv_weights_batch_f32(const fd_pack_job* jobs_dev, int32_t n_jobs, int64_t max_elems,
+                                                  fd_stream_t stream) {
+    FD_REQUIRE(jobs_dev && n_jobs >= 1 && n_jobs <= 65535 && max_elems >= 1, FD_E_INVAL, "fd_pack_conv_weights_batch: bad arguments");
+    long gx = (max_elems + 256L * 8 - 1) / (256L * 8);       // ~8 elements per thread for the largest job
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(pack_weight_batch_kernel, dim3((unsigned)gx, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    FD_CHECK_LAUNCH("fd_pack_conv_weights_batch_f32");
+    return FD_OK;
+}
+
 static void magic_div(int d, unsigned& m, int& sh) {
     if (d <= 1) { m = 0; sh = 0; return; }
     int l = 0;

@@ -183,6 +183,7 @@ class FCOS(PlannedModule):
     def forward(self, x: torch.Tensor, events=None):
         if self.training:
             self._check_train_input(x)
+            T.PACKS.refresh()        # every parameter's packed conv weights for this step, one launch
             return self.head.train_forward(self.FPN.train_forward(trunk_train_forward(self.backbone.trunk, x)))
         chunk = self.plan_batch_limit(x)
         if x.shape[0] > chunk:

@@ -236,6 +236,7 @@ class HalfInvertedStageFCOS(PlannedModule):
             # training: an autograd graph whose nodes are the HIP kernels (train_ops.py: fused conv + frozen BN + ReLU, data /
             # weight gradients, depthwise, GroupNorm); the losses and the target assignment are HIP kernels too
             self._check_train_input(x)
+            T.PACKS.refresh()        # every parameter's packed conv weights for this step, one launch
             return self.head.train_forward(self.fpn.train_forward(trunk_train_forward(self.backbone.trunk, x)))
         chunk = self.plan_batch_limit(x)
         if x.shape[0] > chunk:

@@ -137,6 +137,82 @@ def _act_id(act) -> int:
 
 
 # ------------------------------------------------------------------------------------------- dense convolution
+class _PackCache:
+    """Packed conv weights of the model's PARAMETERS, kept across steps and refreshed by ONE launch per step.
+
+    A train step needs every weight in the conv kernel's layout twice (forward, and flipped / transposed / BN-scaled for the
+    data gradient) and the optimizer changes them all every step: ~150 small packing launches.  Entries are keyed by the
+    parameter's storage (data_ptr, shape) and guarded by its version counter, so a stale entry is never used: a miss or a
+    version mismatch packs on the spot (always correct), `refresh()` -- called at the top of every training forward --
+    re-packs every known entry with fd_pack_conv_weights_batch_f32 (unconditionally: updates made through `.data` do not
+    move the version counter) and records the versions it packed.  Code that calls the layer functions of this module
+    directly AND updates weights through `.data` must call PACKS.refresh() itself before the next forward."""
+
+    def __init__(self):
+        self.entries: dict = {}     # key -> [weakref(param), scale, dgrad, out, version]
+        self.params: dict = {}      # data_ptr -> weakref(param)
+        self.table = None           # (signature, device tensor of fd_pack_job, max_elems)
+
+    @staticmethod
+    def _key(w, scale, dgrad):
+        return (w.data_ptr(), tuple(w.shape), bool(dgrad), scale.data_ptr() if (scale is not None and dgrad) else 0)
+
+    def get(self, w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False) -> torch.Tensor:
+        import weakref
+        if isinstance(w, nn.Parameter) and w.is_contiguous():
+            self.params[w.data_ptr()] = weakref.ref(w)
+        ref = self.params.get(w.data_ptr())
+        owner = ref() if ref is not None else None
+        if owner is None or owner.data_ptr() != w.data_ptr() or owner.shape != w.shape or not w.is_contiguous():
+            return ops.pack_conv_weight_hip(w, scale, dgrad)             # a temporary (merged / padded weights): pack now
+        key = self._key(w, scale, dgrad)
+        e = self.entries.get(key)
+        if e is not None and e[0]() is not owner:       # the address was recycled by another parameter: drop the old entry
+            e = None
+        if e is None:
+            out = ops.pack_conv_weight_hip(w, scale, dgrad)
+            self.entries[key] = [ref, scale, dgrad, out, w._version]
+            self.table = None
+            return out
+        if e[4] != w._version:                                            # changed since the last refresh: re-pack in place
+            co, ci, kh, kw = w.shape
+            ops.check(_lib.lib().fd_pack_conv_weight_f32(w.data_ptr(), scale.data_ptr() if (scale is not None and dgrad) else None,
+                                                         e[3].data_ptr(), co, ci, kh, kw, 1 if dgrad else 0, ops._stream()),
+                      "fd_pack_conv_weight_f32")
+            e[4] = w._version
+        return e[3]
+
+    def refresh(self) -> None:
+        import ctypes as C
+        live = {}
+        for key, e in self.entries.items():
+            p = e[0]()
+            if p is not None and p.data_ptr() == key[0] and tuple(p.shape) == key[1]:
+                live[key] = e
+        if len(live) != len(self.entries):
+            self.entries, self.table = live, None
+        if not live:
+            return
+        # unconditional: an update made through `.data` does not move the version counter, a re-pack is one short launch
+        if self.table is None:
+            jobs = (_lib.PackJob * len(live))()
+            mx = 0
+            for j, (key, e) in zip(jobs, live.items()):
+                co, ci, kh, kw = key[1]
+                j.w, j.scale, j.out = key[0], (e[1].data_ptr() if (e[1] is not None and e[2]) else None), e[3].data_ptr()
+                j.Cout, j.Cin, j.KH, j.KW, j.mode = co, ci, kh, kw, 1 if e[2] else 0
+                mx = max(mx, co * ci * kh * kw)
+            raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).clone()
+            dev = next(iter(live.values()))[3].device
+            self.table = (raw.to(dev), len(live), mx)
+        tab, n, mx = self.table
+        ops.check(_lib.lib().fd_pack_conv_weights_batch_f32(tab.data_ptr(), n, mx, ops._stream()), "fd_pack_conv_weights_batch_f32")
+        for e in live.values():
+            e[4] = e[0]()._version
+
+
+PACKS = _PackCache()
+
 _TILE_CACHE: dict = {}
 
 
@@ -177,7 +253,7 @@ class _ConvRows(torch.autograd.Function):
         Cout, _, k, _ = weight.shape
         so = ops.conv_out_segs(segs, k, stride, pad, dil)
         y = torch.empty(so.rows, Cout, dtype=torch.float32, device=x.device)
-        _conv_launch(x, segs, ops.pack_conv_weight_hip(weight), y, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
+        _conv_launch(x, segs, PACKS.get(weight), y, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                      shift=shift.detach().contiguous() if shift is not None else None,
                      res=residual.contiguous() if residual is not None else None, act=act)
         ctx.save_for_backward(x, weight, scale, y if act == ACT_RELU else None)
@@ -200,7 +276,7 @@ class _ConvRows(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if stride == 1 and Cout % 32 == 0:
                 gx = torch.empty_like(x)
-                _conv_launch(g, so, ops.pack_conv_weight_hip(weight, scale, dgrad=True), gx, k=k, stride=1,
+                _conv_launch(g, so, PACKS.get(weight, scale, dgrad=True), gx, k=k, stride=1,
                              pad=dil * (k - 1) - pad, dil=dil)
             elif segs.nseg == 1:  # strided layers: stock op for the data gradient (single level only)
                 weff = weight.detach() if scale is None else weight.detach() * scale.view(-1, 1, 1, 1)
@@ -267,15 +343,15 @@ class _BottleneckRows(torch.autograd.Function):
         y1 = torch.empty(segs.rows, P, dtype=torch.float32, device=dev)
         y2 = torch.empty(so.rows, P, dtype=torch.float32, device=dev)
         out = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
-        _conv_launch(x, segs, ops.pack_conv_weight_hip(w1), y1, k=1, stride=1, pad=0, dil=1, scale=c1[0], shift=c1[1], act=ACT_RELU)
-        _conv_launch(y1, segs, ops.pack_conv_weight_hip(w2), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0], shift=c2[1],
+        _conv_launch(x, segs, PACKS.get(w1), y1, k=1, stride=1, pad=0, dil=1, scale=c1[0], shift=c1[1], act=ACT_RELU)
+        _conv_launch(y1, segs, PACKS.get(w2), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0], shift=c2[1],
                      act=ACT_RELU)
         if wd is not None:
             idt = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
-            _conv_launch(x, segs, ops.pack_conv_weight_hip(wd), idt, k=1, stride=stride, pad=0, dil=1, scale=cd[0], shift=cd[1])
+            _conv_launch(x, segs, PACKS.get(wd), idt, k=1, stride=stride, pad=0, dil=1, scale=cd[0], shift=cd[1])
         else:
             idt = x
-        _conv_launch(y2, so, ops.pack_conv_weight_hip(w3), out, k=1, stride=1, pad=0, dil=1, scale=c3[0], shift=c3[1], res=idt,
+        _conv_launch(y2, so, PACKS.get(w3), out, k=1, stride=1, pad=0, dil=1, scale=c3[0], shift=c3[1], res=idt,
                      act=ACT_RELU)
         ctx.save_for_backward(x, y1, y2, out, w1, w2, w3, wd, c1[0], c2[0], c3[0], cd[0] if wd is not None else None)
         ctx.geom = (segs, so, stride)
@@ -295,12 +371,12 @@ class _BottleneckRows(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             gw3 = wg(y2, g, so, P, C4, 1, 1, 0, s3)
         g2 = torch.empty_like(y2)                                                    # d/d(conv2 output), ReLU-masked in the epilogue
-        _conv_launch(g, so, ops.pack_conv_weight_hip(w3, s3, dgrad=True), g2, k=1, stride=1, pad=0, dil=1, res=y2, res_mask=True)
+        _conv_launch(g, so, PACKS.get(w3, s3, dgrad=True), g2, k=1, stride=1, pad=0, dil=1, res=y2, res_mask=True)
         if ctx.needs_input_grad[2]:
             gw2 = wg(y1, g2, segs, P, P, 3, stride, 1, s2)
         if stride == 1:
             g1 = torch.empty_like(y1)
-            _conv_launch(g2, so, ops.pack_conv_weight_hip(w2, s2, dgrad=True), g1, k=3, stride=1, pad=1, dil=1, res=y1, res_mask=True)
+            _conv_launch(g2, so, PACKS.get(w2, s2, dgrad=True), g1, k=3, stride=1, pad=1, dil=1, res=y1, res_mask=True)
         else:   # strided 3x3: stock data gradient, masked separately
             B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
             g1 = torch.ops.aten.convolution_backward(from_rows(g2, B, Ho, Wo), from_rows(y1, B, H, W), w2.detach() * s2.view(-1, 1, 1, 1),
@@ -315,14 +391,14 @@ class _BottleneckRows(torch.autograd.Function):
                 gid = g                                                             # identity path
             elif stride == 1:
                 gid = torch.empty_like(x)
-                _conv_launch(g, so, ops.pack_conv_weight_hip(wd, sd, dgrad=True), gid, k=1, stride=1, pad=0, dil=1)
+                _conv_launch(g, so, PACKS.get(wd, sd, dgrad=True), gid, k=1, stride=1, pad=0, dil=1)
             else:
                 B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
                 gid = to_rows(torch.ops.aten.convolution_backward(from_rows(g, B, Ho, Wo), from_rows(x, B, H, W),
                                                                    wd.detach() * sd.view(-1, 1, 1, 1), None, [stride, stride], [0, 0],
                                                                    [1, 1], False, [0, 0], 1, [True, False, False])[0])
             gx = torch.empty_like(x)                                                # conv1's data gradient + the identity gradient
-            _conv_launch(g1, segs, ops.pack_conv_weight_hip(w1, s1, dgrad=True), gx, k=1, stride=1, pad=0, dil=1, res=gid)
+            _conv_launch(g1, segs, PACKS.get(w1, s1, dgrad=True), gx, k=1, stride=1, pad=0, dil=1, res=gid)
         return gx, gw1, gw2, gw3, gwd, None, None, None, None, None, None
 
 

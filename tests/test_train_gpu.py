@@ -233,3 +233,39 @@ def test_unfrozen_batchnorm_trains_with_hip_convs():
     for n in ("head.cls_logits.weight", "head.pw1.weight", "fpn.tf1.weight", "backbone.extract_feature.layer3.0.conv2.weight",
               "backbone.conv1.weight"):
         assert med(g1[n], g2[n]) <= 3 * med(g3[n], g2[n]) + 1e-4, (n, med(g1[n], g2[n]), med(g3[n], g2[n]))
+
+
+def test_packed_weight_cache_follows_every_kind_of_update():
+    """train_ops.PACKS keeps packed conv weights across steps: after optimizer.step(), after an update through `.data`
+    (no version bump) and after load_state_dict the training forward must see the new weights."""
+    from pytorch_object_detection_amd import train_ops
+    torch.manual_seed(21)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).to(DEV).train()
+    x = torch.randn(1, 3, 128, 128, device=DEV)
+
+    def fwd():
+        return [t.detach().clone() for grp in model(x) for t in grp]
+
+    def stock():
+        train_ops._STOCK = True
+        try:
+            return [t.detach().clone() for grp in model(x) for t in grp]
+        finally:
+            train_ops._STOCK = False
+
+    def same(a, b):
+        for u, v in zip(a, b):
+            np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), atol=2e-4, rtol=2e-4)
+
+    same(fwd(), stock())
+    assert len(train_ops.PACKS.entries) > 40
+    w = model.backbone.extract_feature.layer3[1].conv2.weight
+    with torch.no_grad():
+        w.mul_(1.5)                                   # version bump, like an optimizer step
+    same(fwd(), stock())
+    w.data.mul_(0.5)                                  # no version bump
+    same(fwd(), stock())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["fpn.tf1.weight"] = sd["fpn.tf1.weight"] * 0.25
+    model.load_state_dict(sd)
+    same(fwd(), stock())
