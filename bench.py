@@ -33,6 +33,15 @@ def build_model(num_classes: int, seed: int, name: str = "HISFCOS"):
     torch.manual_seed(seed)
     if name == "FCOS":   # the baseline detector behind the same API; diagnostic, not the headline
         model = FCOS([2048, 1024, 512], num_classes, 256).eval()
+    elif name == "FCOS-B3":   # BASELINE configs[4]: EfficientNet-B3 trunk; diagnostic, not the headline
+        model = FCOS([384, 136, 48], num_classes, 256, efficientnet=True, backbone_number=3).eval()
+        gen = torch.Generator().manual_seed(seed + 2)
+        for n, m in model.backbone.named_modules():   # variance-preserving init: torch's default drives 26 MBConv blocks to 1e-11
+            if isinstance(m, torch.nn.Conv2d):
+                fan = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                gain = 1.0 if "_se_" in n else (0.6 if "_project" in n else 3.2)
+                with torch.no_grad():
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * (gain / fan) ** 0.5)
     else:
         model = HalfInvertedStageFCOS([512, 1024, 2048], num_classes, 256).eval()
     gen = torch.Generator().manual_seed(seed + 1)
@@ -346,9 +355,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
-    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--size", default="640", help="input size: S (square) or HxW, multiples of 32 (Cfg5: 832x1344)")
     ap.add_argument("--classes", type=int, default=80)
-    ap.add_argument("--model", default="HISFCOS", choices=["HISFCOS", "FCOS"], help="FCOS = diagnostic run of the baseline detector")
+    ap.add_argument("--model", default="HISFCOS", choices=["HISFCOS", "FCOS", "FCOS-B3"],
+                    help="FCOS / FCOS-B3 = diagnostic runs of the baseline detector on ResNet-50 / EfficientNet-B3 (Cfg5)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = diagnostic: the Cfg4 training step (DDP over RCCL for N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra opt-in f16x3 measurement")
@@ -356,6 +366,9 @@ def main():
     ap.add_argument("--no-train-step", action="store_true", help="skip the Cfg4 training-step diagnostic")
     ap.add_argument("--layer-times", default="", help="diagnostic: write per-plan-step timings (TSV) to this file and exit")
     args = ap.parse_args()
+    hw = [int(v) for v in str(args.size).lower().split("x")]
+    args.height, args.width = (hw[0], hw[0]) if len(hw) == 1 else (hw[0], hw[1])
+    args.size = args.height if args.height == args.width else f"{args.height}x{args.width}"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -396,7 +409,7 @@ def main():
     head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
     clip = ClipBoxes()
     gen = torch.Generator().manual_seed(1000 + rank)
-    x = torch.randn(args.batch, 3, args.size, args.size, generator=gen).to(dev)
+    x = torch.randn(args.batch, 3, args.height, args.width, generator=gen).to(dev)
 
     plan = model.plan_for(x)
     if args.save_tuning and rank == 0:
@@ -445,11 +458,11 @@ def main():
         achieved = tower_flops / (tower_ms * 1e-3) / 1e12
         ms_step = el / args.steps * 1e3
         line = {
-            "metric": f"images/sec {args.model}-R50 {args.size}x{args.size} inference",
+            "metric": f"images/sec {args.model if '-' in args.model else args.model + '-R50'} {args.height}x{args.width} inference",
             "value": round(images / el, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model}-R50 {args.size}x{args.size} batch={args.batch}/GPU inference on MI355X, "
+            "config": {"workload": f"{args.model if '-' in args.model else args.model + '-R50'} {args.height}x{args.width} batch={args.batch}/GPU inference on MI355X, "
                                    f"fused conv head + HIP NMS ({args.classes} classes, score>=0.05, IoU 0.6, top-1000)"
                                    + (", RCCL detection all-gather" if world > 1 else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (image-sharded)"},
@@ -468,7 +481,7 @@ def main():
         if world == 1 and not args.no_train_step:
             line["train_step"] = train_step(dev)
         if sd_cpu is not None:
-            line["cpu_baseline"] = cpu_baseline(sd_cpu, args.classes, args.size)
+            line["cpu_baseline"] = cpu_baseline(sd_cpu, args.classes, args.height)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

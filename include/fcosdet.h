@@ -62,8 +62,9 @@ const char* fd_last_error(void);
  *   torchvision resnet50 bottlenecks (reference model/backbone/resnet50.py:68-80),
  *   HalfInvertedStageFPN / HisBlock (model/od/HISFcos.py:77-179), HISFCOSHead (HISFcos.py:182-229),
  *   FeaturePyramidNetwork / HeadFCOS (model/od/Fcos.py:61-133).
- * w is packed [Cout][Cin/32][KH][KW][32] (K contiguous, 32-channel chunk major, then filter tap).
- * Cin % 32 == 0, x_cs % 4 == 0, x_co % 4 == 0.
+ * w is packed [Cout][ceil(Cin/32)][KH][KW][32] (K contiguous, 32-channel chunk major, then filter tap; input
+ * channels beyond Cin are zero).  Cin % 4 == 0 (a last partial chunk is read as zeros: EfficientNet widths such
+ * as 24, 40, 48, 136, 144, 232, 816, 1392), x_cs % 4 == 0, x_co % 4 == 0.
  * in.nseg > 1 requires stride 1 and "same" padding (pad == dil*(K-1)/2).
  * mode FD_CONV_STEM: x is [N][H][W][4] (3 channels + zero pad), 7x7 stride 2 pad 3,
  *   w packed [Cout][7][8][4] (zeros at kw=7 and c=3).
@@ -217,6 +218,34 @@ int32_t fd_dwconv3x3_bwd_weight_nhwc(const float* x, int32_t x_cs, int32_t x_co,
                                      int32_t dy_co, float* dw, int32_t C, const float* scale, int32_t layout,
                                      const fd_segs* segs, void* workspace, fd_stream_t stream);
 
+/* Depthwise k x k convolution with stride and asymmetric zero padding, y = act(dw(x)*scale + shift): the depthwise
+ * stage of an EfficientNet MBConv block (efficientnet_pytorch 0.7.1 MBConvBlock._depthwise_conv + _bn1 + swish, wrapped by
+ * the reference's model/backbone/efficientnetv1.py:11-26; Conv2dStaticSamePadding pads (pad//2, pad - pad//2), i.e. more at
+ * the bottom / right).  k in {3, 5, 7}, stride in {1, 2}; the caller states the top / left padding and the output size,
+ * every tap outside the H x W input reads as zero.  w packed [K*K][C] (tap major).  Single level (no pyramid). */
+int32_t fd_dwconv2d_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w, const float* scale,
+                         const float* shift, float* y, int32_t y_cs, int32_t y_co, int32_t N, int32_t H, int32_t W,
+                         int32_t C, int32_t K, int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo,
+                         int32_t act, fd_stream_t stream);
+
+/* 3-channel stem convolution (EfficientNet._conv_stem 3x3 stride 2 + _bn0 + swish) on the [N][H][W][4] image layout
+ * fd_nchw3_to_nhwc4 / fd_preprocess_u8_nhwc4 / fd_collate_u8_nhwc4 produce: y = act(conv(x)*scale + shift).
+ * w packed [K*K][4][Cout] (tap, input channel, output channel; input channel 3 is ignored).  K = 3, stride in {1, 2},
+ * Cout % 4 == 0; padding as for fd_dwconv2d_nhwc. */
+int32_t fd_stem_conv_nhwc4(const float* x4, const float* w, const float* scale, const float* shift, float* y,
+                           int32_t y_cs, int32_t y_co, int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t K,
+                           int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo, int32_t act,
+                           fd_stream_t stream);
+
+/* Mixed-aspect batch assembly on the device (dataset/voc.py:128-132 pad-to-32, :141-156 collate_fn):
+ * N resized uint8 images of different sizes -> ONE normalised fp32 [N][H][W][4] batch (the stem's input layout).
+ * images_dev: DEVICE array of N device pointers to [h_n][w_n][3] uint8; hw_dev: DEVICE int32 [N][2] = (h_n, w_n);
+ * H, W >= every (h_n, w_n): the batch canvas (the host picks max over n of h_n + 32 - h_n % 32, as the reference does).
+ * Pixels outside an image are uint8 zeros BEFORE normalisation, i.e. (0 - mean) / std, exactly what the reference's
+ * zero-pad-then-Normalize produces.  cv2.resize stays on the host.  mean3 / std3 are HOST pointers to 3 floats. */
+int32_t fd_collate_u8_nhwc4(const uint8_t* const* images_dev, const int32_t* hw_dev, float* y, int32_t N, int32_t H,
+                            int32_t W, const float* mean3, const float* std3, fd_stream_t stream);
+
 /* GroupNorm(G, C) + activation (nn.GroupNorm in HISFCOSHead / HeadFCOS, HISFcos.py:190-204, Fcos.py:102-109).
  * Two launches: partial moments (fp64 accumulation, fixed order) then normalise+affine+act.
  * workspace: fd_groupnorm_workspace_bytes(segs, G). x and y may alias. */
@@ -237,8 +266,9 @@ int32_t fd_groupnorm_act_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, co
                                   int32_t act, const fd_segs* segs, const void* fwd_workspace, void* workspace,
                                   fd_stream_t stream);
 
-/* Squeeze-excitation (SEBlock, modules.py:107-121): y = x * sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2).
- * w1 [Cr][C], w2 [C][Cr].  workspace: fd_se_workspace_bytes(N, HW, C). */
+/* Squeeze-excitation (SEBlock, modules.py:107-121; also the SE stage of an EfficientNet MBConv block, whose middle
+ * activation is the same swish): y = x * sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2).
+ * w1 [Cr][C], w2 [C][Cr]; C % 4 == 0, C <= 4096, Cr <= 1024.  workspace: fd_se_workspace_bytes(N, HW, C).  x and y may alias. */
 int64_t fd_se_workspace_bytes(int32_t N, int32_t HW, int32_t C);
 int32_t fd_se_scale_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w1, const float* b1,
                          const float* w2, const float* b2, float* y, int32_t y_cs, int32_t y_co, int32_t N,
@@ -290,6 +320,15 @@ int32_t fd_pairwise_iou(const float* a, const float* b, int32_t Na, int32_t Nb, 
 
 /* ClipBoxes (head.py:152-162): clamp(min 0), x <= W-1, y <= H-1, in place on [n_boxes][4] */
 int32_t fd_clip_boxes(float* boxes, int64_t n_boxes, int32_t img_h, int32_t img_w, fd_stream_t stream);
+
+/* Detection records for the ONE collective of image-sharded multi-GPU inference: the padded
+ * outputs of fd_batched_nms of B images as one fp32 message records[B][K+1][6]:
+ *   records[b][0] = (counts[b], 0, 0, 0, 0, 0);  records[b][1+r] = (x1, y1, x2, y2, score, class), r < K.
+ * Counts and class ids are < 2^24, exact in fp32.  fd_unpack_detections is the inverse (on the gathered [W*B] images). */
+int32_t fd_pack_detections(const float* scores, const int64_t* classes, const float* boxes, const int32_t* counts,
+                           int32_t B, int32_t K, float* records, fd_stream_t stream);
+int32_t fd_unpack_detections(const float* records, int32_t B, int32_t K, float* scores, int64_t* classes, float* boxes,
+                             int32_t* counts, fd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------- */
 /* LTRB IoU / GIoU regression loss (reference model/loss.py:116-177), fused masked forward + backward.

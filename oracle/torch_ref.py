@@ -26,10 +26,16 @@ _EPS = 1e-5
 # ----------------------------------------------------------------------------------------------
 # building blocks
 # ----------------------------------------------------------------------------------------------
+BN_TRAIN_PREFIXES: Tuple[str, ...] = ()   # BatchNorm2d layers whose name starts with one of these run in TRAINING mode
+
+
 def _bn(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
-    """frozen nn.BatchNorm2d (eval): HISFcos.py:57-68 freeze_bn."""
+    """nn.BatchNorm2d.  Default: eval (frozen, HISFcos.py:57-68 freeze_bn).  Layers named in BN_TRAIN_PREFIXES use batch
+    statistics and update their running statistics in `sd` (momentum 0.1), which is what the reference's model.train()
+    (train.py:151) does to every BatchNorm the constructor had put in eval mode."""
+    training = any(p.startswith(q) for q in BN_TRAIN_PREFIXES)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
-                        False, 0.0, _EPS)
+                        training, 0.1 if training else 0.0, _EPS)
 
 
 def _conv(sd: SD, p: str, x: torch.Tensor, stride: int = 1, pad: int = 0, dil: int = 1, groups: int = 1) -> torch.Tensor:

@@ -90,6 +90,9 @@ _SIGS = {
     "fd_maxpool_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fd_upsample2x_add_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fd_dwconv3x3_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(Segs), _P]),
+    "fd_dwconv2d_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fd_stem_conv_nhwc4": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fd_collate_u8_nhwc4": (_I, [_P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
     "fd_dwconv3x3_wgrad_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
     "fd_dwconv3x3_bwd_weight_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, C.POINTER(Segs), _P, _P]),
     "fd_groupnorm_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
@@ -107,6 +110,8 @@ _SIGS = {
     "fd_box_nms_plus1": (_I, [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P]),
     "fd_pairwise_iou": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "fd_clip_boxes": (_I, [_P, _L, _I, _I, _P]),
+    "fd_pack_detections": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
+    "fd_unpack_detections": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
     "fd_ltrb_iou_loss_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "fd_ltrb_iou_loss_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "fd_focal_workspace_bytes": (_L, [_I]),

@@ -122,17 +122,20 @@ void conv_igemm_kernel(ConvArgs a) {
     auto load_tile = [&](int kt) {
         int dr, dq;          // tap displacement in input rows / columns
         unsigned dbytes;     // uniform byte displacement: column shift + channel chunk
+        bool c_ok = true;    // Cin % 32 != 0 (EfficientNet widths: 24, 40, 48, 136, 144, 232 ...): the last chunk's missing
+                             // channels read as zero (their packed weights are zero too, but 0 * garbage could be NaN)
         if (STEM) { dr = kt; dq = 0; dbytes = 0; }
         else {
             dr = ld_r * a.dil;
             dq = ld_q * a.dil;
             dbytes = (unsigned)(dq * a.x_cs + ld_cc * 32) * 4u;
+            c_ok = ld_cc * 32 + chunk * 4 < a.Cin;
             if (++ld_q == a.KW) { ld_q = 0; if (++ld_r * a.KW == a.ntaps) { ld_r = 0; ++ld_cc; } }
         }
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int hi = a_hi0[i] + dr, wi = a_wi0[i] + dq + (STEM ? chunk : 0);
-            bool ok = (unsigned)hi < (unsigned)a_H[i] && (unsigned)wi < (unsigned)a_W[i];
+            bool ok = (unsigned)hi < (unsigned)a_H[i] && (unsigned)wi < (unsigned)a_W[i] && c_ok;
             if (STEM) ok = ok && (chunk < 7);
             const unsigned off = a_off[i] + (unsigned)__mul24(dr, a_wcs[i]) + dbytes;
             ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : OOB), 0, 0));
@@ -443,7 +446,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
                        p->x_cs == 4 && p->x_co == 0,
                    FD_E_INVAL, "fd_conv2d: stem mode needs 7x7 s2 p3 on an [N][H][W][4] input");
     } else {
-        FD_REQUIRE(p->Cin >= 32 && p->Cin % 32 == 0, FD_E_UNSUPPORTED, "fd_conv2d: Cin=%d must be a multiple of 32", p->Cin);
+        FD_REQUIRE(p->Cin >= 4 && p->Cin % 4 == 0, FD_E_UNSUPPORTED, "fd_conv2d: Cin=%d must be a multiple of 4", p->Cin);
         FD_REQUIRE(p->x_cs % 4 == 0 && p->x_co % 4 == 0 && p->x_cs >= p->x_co + p->Cin, FD_E_INVAL,
                    "fd_conv2d: input channel view (cs=%d co=%d Cin=%d) must be 4-aligned and in range", p->x_cs, p->x_co, p->Cin);
     }
@@ -482,7 +485,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     FD_REQUIRE((long)p->in.m_start[p->in.nseg] * p->x_cs < (1L << 31) && mo * p->y_cs < (1L << 31), FD_E_UNSUPPORTED,
                "fd_conv2d: tensor exceeds 2^31 elements");
     if (stem) { a.KT = 7; a.ntaps = 7; a.Kpacked = 7 * 32; }
-    else { a.ntaps = p->KH * p->KW; a.KT = a.ntaps * (p->Cin / 32); a.Kpacked = p->KH * p->KW * p->Cin; }
+    else { const int cch = (p->Cin + 31) / 32; a.ntaps = p->KH * p->KW; a.KT = a.ntaps * cch; a.Kpacked = a.ntaps * cch * 32; }
     a.mtiles = a.ntiles = 0;
 
     a.vec_epi = (p->Cout % 4 == 0 && p->y_cs % 4 == 0 && p->y_co % 4 == 0 && ((uintptr_t)p->y & 15) == 0 &&

@@ -741,56 +741,69 @@ extern "C" int32_t fd_groupnorm_act_bwd_nhwc(const float* x, int32_t x_cs, int32
 }
 
 // ------------------------------------------------------------------------------ squeeze-excitation
+// Any C % 4 == 0 up to SE_MAXC (HisBlock: 128 -> 32; EfficientNet MBConv: expanded width up to 3840 -> block_in / 4).
 #define SE_MAXCHUNK 64
+#define SE_MAXC 4096
+#define SE_MAXCR 1024
 
+// partial channel sums: grid (row chunk, image, channel tile of QW quads); 256 threads = QW quads x (256 / QW) row lanes
 __global__ __launch_bounds__(256) void se_gap_kernel(const float* __restrict__ x, int x_cs, int x_co, int HW, int C,
-                                                      int nchunk, double* __restrict__ part) {
+                                                      int nchunk, int QW, double* __restrict__ part) {
     __shared__ double s_sum[256 * 4];
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int rows_per = (HW + nchunk - 1) / nchunk;
     const int r_begin = chunk * rows_per, r_end = min(HW, r_begin + rows_per);
-    const int C4 = C >> 2, RT = 256 / C4;
-    const int tid = threadIdx.x, q = tid % C4, rt = tid / C4;
+    const int C4 = C >> 2, RT = 256 / QW, CW = 4 * QW;
+    const int tid = threadIdx.x, ql = tid % QW, rt = tid / QW;
+    const int q = blockIdx.z * QW + ql;
     double su[4] = {0, 0, 0, 0};
-    if (rt < RT) {
+    if (q < C4) {
         const float* base = x + (long)n * HW * x_cs + x_co + 4 * q;
         for (int r = r_begin + rt; r < r_end; r += RT) {
             const float4 v = *reinterpret_cast<const float4*>(base + (long)r * x_cs);
             su[0] += v.x; su[1] += v.y; su[2] += v.z; su[3] += v.w;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s_sum[rt * C + 4 * q + e] = su[e];
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_sum[rt * CW + 4 * ql + e] = su[e];
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int cl = tid; cl < CW; cl += 256) {
+        const int c = blockIdx.z * CW + cl;
+        if (c >= C) continue;
         double a = 0;
-        for (int r = 0; r < RT; ++r) a += s_sum[r * C + c];
+        for (int r = 0; r < RT; ++r) a += s_sum[r * CW + cl];
         part[((long)n * SE_MAXCHUNK + chunk) * C + c] = a;
     }
 }
 
+// gate = sigmoid(W2 silu(W1 mean + b1) + b2), one workgroup per image.  The squeeze dot products (length C) are spread
+// over a wave's lanes and combined with a fixed shuffle tree; the excite ones (length Cr) run one output per thread.
 __global__ __launch_bounds__(256) void se_fc_kernel(const double* __restrict__ part, int nchunk, int HW, int C, int Cr,
                                                      const float* __restrict__ w1, const float* __restrict__ b1,
                                                      const float* __restrict__ w2, const float* __restrict__ b2,
                                                      float* __restrict__ gate) {
-    __shared__ float s_mean[1024];
-    __shared__ float s_h[256];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    __shared__ float s_mean[SE_MAXC];
+    __shared__ float s_h[SE_MAXCR];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int c = tid; c < C; c += 256) {
         double a = 0;
         for (int k = 0; k < nchunk; ++k) a += part[((long)n * SE_MAXCHUNK + k) * C + c];
         s_mean[c] = (float)(a / (double)HW);
     }
     __syncthreads();
-    for (int j = tid; j < Cr; j += 256) {
-        float a = b1 ? b1[j] : 0.f;
-        for (int c = 0; c < C; ++c) a = fmaf(w1[j * C + c], s_mean[c], a);
-        s_h[j] = fd_act(a, FD_ACT_SILU, 0.f);
+    for (int j = wv; j < Cr; j += 4) {
+        float a = 0.f;
+        const float* wr = w1 + (long)j * C;
+        for (int c = lane; c < C; c += 64) a = fmaf(wr[c], s_mean[c], a);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) s_h[j] = fd_act(a + (b1 ? b1[j] : 0.f), FD_ACT_SILU, 0.f);
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float a = b2 ? b2[c] : 0.f;
-        for (int j = 0; j < Cr; ++j) a = fmaf(w2[c * Cr + j], s_h[j], a);
+        const float* wr = w2 + (long)c * Cr;
+        for (int j = 0; j < Cr; ++j) a = fmaf(wr[j], s_h[j], a);
         gate[(long)n * C + c] = fd_sigmoid(a);
     }
 }
@@ -818,13 +831,16 @@ extern "C" int32_t fd_se_scale_nhwc(const float* x, int32_t x_cs, int32_t x_co, 
                                     int32_t HW, int32_t C, int32_t Cr, void* workspace, fd_stream_t stream) {
     FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C) && w1 && w2 && workspace, FD_E_INVAL,
                "fd_se_scale: bad pointer / channel view (C=%d)", C);
-    FD_REQUIRE(N >= 1 && N <= 65535 && HW >= 1 && Cr >= 1 && Cr <= 256 && C <= 1024 && 256 % (C / 4) == 0,
-               FD_E_UNSUPPORTED, "fd_se_scale: C=%d Cr=%d unsupported", C, Cr);
+    FD_REQUIRE(N >= 1 && N <= 65535 && HW >= 1 && Cr >= 1 && Cr <= SE_MAXCR && C <= SE_MAXC, FD_E_UNSUPPORTED,
+               "fd_se_scale: C=%d Cr=%d unsupported (C <= %d, Cr <= %d)", C, Cr, SE_MAXC, SE_MAXCR);
     FD_REQUIRE(((uintptr_t)workspace & 15) == 0, FD_E_INVAL, "fd_se_scale: workspace not 16-byte aligned");
     double* part = (double*)workspace;
     float* gate = (float*)((char*)workspace + (size_t)N * SE_MAXCHUNK * C * sizeof(double));
     const int nchunk = min(SE_MAXCHUNK, (HW + 63) / 64);
-    hipLaunchKernelGGL(se_gap_kernel, dim3(nchunk, N), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, HW, C, nchunk, part);
+    int QW = 1;                                      // quads per channel tile: a power of two, at most 64
+    while (QW < 64 && QW < C / 4) QW <<= 1;
+    hipLaunchKernelGGL(se_gap_kernel, dim3(nchunk, N, (C / 4 + QW - 1) / QW), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, HW, C,
+                       nchunk, QW, part);
     FD_CHECK_LAUNCH("fd_se_scale (gap)");
     hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const double*)part, nchunk, HW, C, Cr, w1,
                        b1, w2, b2, gate);

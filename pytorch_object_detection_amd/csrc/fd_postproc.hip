@@ -597,3 +597,65 @@ extern "C" int32_t fd_clip_boxes(float* boxes, int64_t n_boxes, int32_t img_h, i
     FD_CHECK_LAUNCH("fd_clip_boxes");
     return FD_OK;
 }
+
+// --------------------------------------------------------------------------------------------
+// detection records for the multi-GPU all-gather: ONE fixed-size fp32 message per rank
+//   rec[b][0]     = (count_b, 0, 0, 0, 0, 0)
+//   rec[b][1 + r] = (x1, y1, x2, y2, score, class)      r < K   (class ids and counts are < 2^24: exact in fp32)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_det_kernel(const float* __restrict__ scores, const long long* __restrict__ classes,
+                                                        const float4* __restrict__ boxes, const int* __restrict__ counts, int K,
+                                                        float* __restrict__ rec, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / (K + 1);
+    const int r = (int)(i - b * (K + 1));
+    float* o = rec + i * 6;
+    if (r == 0) {
+        o[0] = (float)counts[b]; o[1] = o[2] = o[3] = o[4] = o[5] = 0.f;
+    } else {
+        const long src = b * K + (r - 1);
+        const float4 bx = boxes[src];
+        o[0] = bx.x; o[1] = bx.y; o[2] = bx.z; o[3] = bx.w; o[4] = scores[src]; o[5] = (float)classes[src];
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_det_kernel(const float* __restrict__ rec, int K, float* __restrict__ scores,
+                                                          long long* __restrict__ classes, float4* __restrict__ boxes,
+                                                          int* __restrict__ counts, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / (K + 1);
+    const int r = (int)(i - b * (K + 1));
+    const float* o = rec + i * 6;
+    if (r == 0) {
+        counts[b] = (int)o[0];
+    } else {
+        const long dst = b * K + (r - 1);
+        boxes[dst] = make_float4(o[0], o[1], o[2], o[3]);
+        scores[dst] = o[4];
+        classes[dst] = (long long)o[5];
+    }
+}
+
+extern "C" int32_t fd_pack_detections(const float* scores, const int64_t* classes, const float* boxes, const int32_t* counts,
+                                      int32_t B, int32_t K, float* records, fd_stream_t stream) {
+    FD_REQUIRE(scores && classes && boxes && counts && records && B >= 1 && K >= 1, FD_E_INVAL, "fd_pack_detections: bad argument");
+    FD_REQUIRE(((uintptr_t)boxes & 15) == 0, FD_E_INVAL, "fd_pack_detections: boxes not 16-byte aligned");
+    const long total = (long)B * (K + 1);
+    hipLaunchKernelGGL(pack_det_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores,
+                       (const long long*)classes, (const float4*)boxes, counts, K, records, total);
+    FD_CHECK_LAUNCH("fd_pack_detections");
+    return FD_OK;
+}
+
+extern "C" int32_t fd_unpack_detections(const float* records, int32_t B, int32_t K, float* scores, int64_t* classes, float* boxes,
+                                        int32_t* counts, fd_stream_t stream) {
+    FD_REQUIRE(scores && classes && boxes && counts && records && B >= 1 && K >= 1, FD_E_INVAL, "fd_unpack_detections: bad argument");
+    FD_REQUIRE(((uintptr_t)boxes & 15) == 0, FD_E_INVAL, "fd_unpack_detections: boxes not 16-byte aligned");
+    const long total = (long)B * (K + 1);
+    hipLaunchKernelGGL(unpack_det_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, records, K, scores,
+                       (long long*)classes, (float4*)boxes, counts, total);
+    FD_CHECK_LAUNCH("fd_unpack_detections");
+    return FD_OK;
+}

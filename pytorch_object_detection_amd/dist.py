@@ -16,26 +16,38 @@ def shard_batch(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_detections(scores: torch.Tensor, classes: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
-    """[B,K] f32, [B,K] i64, [B,K,4] f32 -> [B,K,6] f32 rows (x1, y1, x2, y2, score, class); class ids are < 2^24."""
-    return torch.cat([boxes, scores.unsqueeze(-1), classes.to(torch.float32).unsqueeze(-1)], dim=-1).contiguous()
+def pack_detections(scores: torch.Tensor, classes: torch.Tensor, boxes: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+    """[B,K] f32, [B,K] i64, [B,K,4] f32, [B] i32 -> ONE message [B, K+1, 6] f32: row 0 of an image carries its count, rows
+    1..K are (x1, y1, x2, y2, score, class); class ids and counts are < 2^24, exact in fp32.  One HIP launch on CUDA
+    tensors (fd_pack_detections); CPU tensors (the gloo rehearsal of the protocol in tests/test_dist_cpu.py) take the
+    equivalent torch ops."""
+    if scores.is_cuda:
+        from . import ops
+        return ops.pack_detections(scores, classes, boxes, counts)
+    B, K = scores.shape
+    rec = torch.zeros(B, K + 1, 6, dtype=torch.float32)
+    rec[:, 0, 0] = counts.to(torch.float32)
+    rec[:, 1:, :4], rec[:, 1:, 4], rec[:, 1:, 5] = boxes, scores, classes.to(torch.float32)
+    return rec
 
 
-def unpack_detections(packed: torch.Tensor):
-    return packed[..., 4].contiguous(), packed[..., 5].to(torch.int64), packed[..., :4].contiguous()
+def unpack_detections(rec: torch.Tensor):
+    """Inverse of pack_detections: -> (scores [B,K], classes [B,K] int64, boxes [B,K,4], counts [B] int32)."""
+    if rec.is_cuda:
+        from . import ops
+        return ops.unpack_detections(rec)
+    return (rec[:, 1:, 4].contiguous(), rec[:, 1:, 5].to(torch.int64), rec[:, 1:, :4].contiguous(), rec[:, 0, 0].to(torch.int32))
 
 
 def gather_detections(scores, classes, boxes, counts, group=None, force: bool = False):
     """All-gather padded detections from every rank: returns (scores [W*B,K], classes, boxes [W*B,K,4], counts [W*B]).
-    Every rank must hold the same local batch B and K (pad the last shard).  Two fixed-size messages per rank:
-    B*K*6 floats (384 KB at B=16, K=1000) and B int32 counts."""
+    Every rank must hold the same local batch B and K (pad the last shard).  ONE collective: a single
+    all_gather_into_tensor of the [B, K+1, 6] fp32 records (385 KB at B=16, K=1000; latency-bound on xGMI), one pack
+    launch before it and one unpack launch after it."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return scores, classes, boxes, counts
     world = dist.get_world_size(group)
-    packed = pack_detections(scores, classes, boxes)
-    out = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
-    cnt = torch.empty(world * counts.shape[0], dtype=counts.dtype, device=counts.device)
-    dist.all_gather_into_tensor(out, packed, group=group)
-    dist.all_gather_into_tensor(cnt, counts.contiguous(), group=group)
-    s, c, b = unpack_detections(out)
-    return s, c, b, cnt
+    rec = pack_detections(scores, classes, boxes, counts)
+    out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, rec, group=group)
+    return unpack_detections(out)

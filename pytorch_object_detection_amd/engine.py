@@ -111,8 +111,9 @@ def _dev(t: torch.Tensor, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------ conv helpers
 def padded_input(plan: Plan, rows: int, C: int):
     """Plan-owned staging buffer for a caller-supplied map of C channels: (Rows the convs read, Rows the copy-in writes).
-    C is rounded up to a multiple of 32 with zero channels that are never written (dedicated, not pooled)."""
-    Cp = (C + 31) // 32 * 32
+    The conv kernel reads any C % 4 == 0 (a partial 32-channel chunk is masked in its loader: EfficientNet's 48 / 136);
+    other widths are rounded up to a multiple of 4 with zero channels that are never written (dedicated, not pooled)."""
+    Cp = (C + 3) // 4 * 4
     if Cp == C:
         r = plan.pool.get(rows, C)
         return r, r
@@ -135,9 +136,9 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     else:
         pad = pad[0]
     Cin, co = w.shape[1], (w.shape[0] if Cout is None else Cout)
-    if Cin % 32 and x.co == 0 and x.C == x.cs and x.C % 32 == 0 and 0 < x.C - Cin < 32:
-        # input width that is not a multiple of 32 (EfficientNet-style backbones: 48, 136 channels): the caller staged
-        # the map into a zero-padded buffer (padded_input), the weights get matching zero input channels
+    if Cin % 4 and x.co == 0 and x.C == x.cs and x.C % 4 == 0 and 0 < x.C - Cin < 4:
+        # input width that is not a multiple of 4: the caller staged the map into a zero-padded buffer (padded_input),
+        # the weights get matching zero input channels
         w = torch.nn.functional.pad(_dev(w, dev).detach(), (0, 0, 0, 0, 0, x.C - Cin))
         Cin = x.C
     split = plan.precision == "f16x3"
@@ -166,10 +167,31 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         key = f"B{segs.batch}|{hw}|{Cin}>{co}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{x.cs}|ycs{y.cs}"
         if split:
             key = "f16x3|" + key
-        plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co, (Cin // 32) * k * k)
+        plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co, -(-Cin // 32) * k * k)
     plan.flops += 2 * out.rows * co * Cin * k * k
     plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k
     return out
+
+
+# ------------------------------------------------------------------------------------------------ plan input
+def add_input(plan: Plan, x4: Rows, batch: int, H: int, W: int, image_ref: List) -> None:
+    """First step of a detector plan: fill the stem's [N][H][W][4] input from whatever the caller hands over
+    (plan.input_mode): None = fp32 NCHW (the reference's tensor, dataset/voc.py:141-173); 'u8' = one uint8 [N,H,W,3] batch,
+    normalised on the device; 'collate' = a list of resized uint8 [h_n, w_n, 3] images of different sizes, padded to the
+    batch canvas and normalised in one launch (voc.py:128-132,141-156).  (mean, std) = plan.input_u8."""
+    mode = getattr(plan, "input_mode", None) or ("u8" if getattr(plan, "input_u8", None) else None)
+    if mode == "u8":
+        mean, std = plan.input_u8
+        plan.add("input.preprocess_u8", lambda: ops.preprocess_u8(image_ref[0], x4.buf, mean, std))
+    elif mode == "collate":
+        mean, std = plan.input_u8
+        hold = [None]
+
+        def run():
+            _, hold[0] = ops.collate_u8(image_ref[0], H, W, mean, std, out=x4.buf)   # `hold`: pointer table alive until the next run
+        plan.add("input.collate_u8", run)
+    else:
+        plan.add("input.nchw3_to_nhwc4", lambda: ops.nchw3_to_nhwc4(image_ref[0], x4.buf))
 
 
 # ------------------------------------------------------------------------------------------------ ResNet-50 trunk
@@ -177,11 +199,7 @@ def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: Lis
     """torchvision-style ResNet-50 v1.5 trunk -> (C3, C4, C5) as (Rows, Segs).  `trunk` has conv1, bn1, layer1..4."""
     dev, pool = plan.device, plan.pool
     x4 = pool.get(batch * H * W, 4)
-    if getattr(plan, "input_u8", None):   # uint8 NHWC images: normalise on the device straight into the stem layout
-        mean, std = plan.input_u8
-        plan.add("input.preprocess_u8", lambda: ops.preprocess_u8(image_ref[0], x4.buf, mean, std))
-    else:
-        plan.add("input.nchw3_to_nhwc4", lambda: ops.nchw3_to_nhwc4(image_ref[0], x4.buf))
+    add_input(plan, x4, batch, H, W, image_ref)
     s_in = Segs.make(batch, [(H, W)])
     # stem 7x7 s2 + BN + ReLU
     wp = ops.pack_stem_weight(_dev(trunk.conv1.weight, dev))
@@ -230,6 +248,89 @@ def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: Lis
         if li >= 2:
             feats.append((x, sx))
     return feats  # [(C3, segs), (C4, segs), (C5, segs)]
+
+
+# ------------------------------------------------------------------------------------------------ EfficientNet trunk
+def build_efficientnet(plan: Plan, net, batch: int, H: int, W: int, image_ref: List[torch.Tensor], keep=(2, 3, 4)):
+    """efficientnet_pytorch 0.7.1 `EfficientNet.extract_endpoints` (the call behind the reference's EfficientNetV1.forward,
+    model/backbone/efficientnetv1.py:24-26) -> [(Rows, Segs)] for reduction_1..reduction_5; endpoints not in `keep` are
+    returned to the pool as soon as the next block has consumed them (their entry is None).  `net` is the parameter
+    container model/backbone/efficientnetv1._EfficientNet.
+
+    Per MBConv block: expand 1x1 + BN + swish (MFMA conv kernel; widths that are not multiples of 32 are masked in its
+    loader) -> depthwise k x k stride s with the block's static TF-"SAME" padding + BN + swish (fd_dwconv2d_nhwc) ->
+    squeeze-excitation in place (fd_se_scale_nhwc) -> project 1x1 + BN (+ block input when stride 1 and cin == cout)."""
+    dev, pool = plan.device, plan.pool
+    x4 = pool.get(batch * H * W, 4)
+    add_input(plan, x4, batch, H, W, image_ref)
+
+    def out_hw(h: int, w: int, k: int, s: int, pad) -> Tuple[int, int]:
+        return (h + pad[0] + pad[1] - k) // s + 1, (w + pad[0] + pad[1] - k) // s + 1
+
+    def bn_fold(bn):
+        sc, sf = ops.fold_bn(_dev(bn.weight, dev), _dev(bn.bias, dev), _dev(bn.running_mean, dev), _dev(bn.running_var, dev), bn.eps)
+        plan.keep += [sc, sf]
+        return sc, sf
+
+    # stem: 3x3 stride 2 + BN + swish on the [N][H][W][4] image
+    stem = net._conv_stem
+    C0 = stem.weight.shape[0]
+    h, w = out_hw(H, W, 3, 2, net.stem_pad)
+    ws = ops.pack_stem3_weight(_dev(stem.weight, dev))
+    sc0, sf0 = bn_fold(net._bn0)
+    plan.keep.append(ws)
+    x = pool.get(batch * h * w, C0)
+    plan.add("backbone._conv_stem", lambda x=x, h=h, w=w: ops.stem_conv3(x4.buf, ws, x, batch, H, W, 3, 2, net.stem_pad[0], net.stem_pad[0],
+                                                                       h, w, sc0, sf0, ACT_SILU))
+    plan.flops += 2 * batch * h * w * C0 * 27
+    pool.put(x4)
+    blocks = list(net._blocks)
+    ends: List[Optional[Tuple[Rows, Segs]]] = []
+    for bi, blk in enumerate(blocks):
+        nm = f"backbone._blocks.{bi}"
+        segs = Segs.make(batch, [(h, w)])
+        inp = x
+        mid = blk._depthwise_conv.weight.shape[0]
+        if blk.expand != 1:
+            e = pool.get(segs.rows, mid)
+            add_conv(plan, nm + "._expand_conv", x, segs, blk._expand_conv, e, bn=blk._bn0, act=ACT_SILU)
+        else:
+            e = x
+        ho, wo = out_hw(h, w, blk.kernel, blk.stride, blk.pad)
+        if ho < 1 or wo < 1:
+            raise FdError("EfficientNet: input too small")
+        so = Segs.make(batch, [(ho, wo)])
+        d = pool.get(so.rows, mid)
+        wd = ops.pack_dwk_weight(_dev(blk._depthwise_conv.weight, dev))
+        sc, sf = bn_fold(blk._bn1)
+        plan.add(nm + "._depthwise_conv", lambda e=e, d=d, wd=wd, sc=sc, sf=sf, h=h, w=w, ho=ho, wo=wo, blk=blk:
+                 ops.dwconv2d(e, wd, d, batch, h, w, blk.kernel, blk.stride, blk.pad[0], blk.pad[0], ho, wo, sc, sf, ACT_SILU))
+        plan.flops += 2 * so.rows * mid * blk.kernel * blk.kernel
+        if e is not x:
+            pool.put(e)
+        w1 = _dev(blk._se_reduce.weight, dev).reshape(blk._se_reduce.weight.shape[0], -1).contiguous()
+        b1 = _dev(blk._se_reduce.bias, dev)
+        w2 = _dev(blk._se_expand.weight, dev).reshape(mid, -1).contiguous()
+        b2 = _dev(blk._se_expand.bias, dev)
+        sews = ops.se_workspace(batch, ho * wo, mid, dev)
+        plan.keep += [wd, w1, b1, w2, b2, sews]
+        plan.add(nm + "._se", lambda d=d, w1=w1, b1=b1, w2=w2, b2=b2, sews=sews, hw=ho * wo:
+                 ops.se_scale(d, w1, b1, w2, b2, d, batch, hw, w1.shape[0], sews))
+        out = pool.get(so.rows, blk.cout)
+        add_conv(plan, nm + "._project_conv", d, so, blk._project_conv, out, bn=blk._bn2, res=inp if blk.skip else None)
+        pool.put(d)
+        # extract_endpoints: the activation in front of every resolution drop is an endpoint (and the last block's output)
+        if ho < h and len(ends) in keep:
+            ends.append((inp, segs))
+        else:
+            if ho < h:
+                ends.append(None)
+            pool.put(inp)
+        x, h, w = out, ho, wo
+    ends.append((x, Segs.make(batch, [(h, w)])))
+    if len(ends) != 5:
+        raise FdError(f"EfficientNet: expected 5 endpoints, got {len(ends)} (input too small?)")
+    return ends
 
 
 # ------------------------------------------------------------------------------------------------ HISFCOS FPN

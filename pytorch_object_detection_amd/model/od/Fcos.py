@@ -138,12 +138,32 @@ class HeadFCOS(PlannedModule):
 
 
 class FCOS(PlannedModule):
+    """FCOS(in_channel [C5, C4, C3 widths], num_class, feature, freeze_bn, efficientnet) — reference Fcos.py:12-58.
+
+    `efficientnet=True` selects the EfficientNet trunk.  As shipped the reference hard-codes `EfficientNetV1(0)` (B0,
+    Fcos.py:31-32) and then unpacks the wrapper's FIVE endpoints into three names (Fcos.py:78), which raises; the authors'
+    recorded runs ("ef-B0", Result/propose_giou_50_61.1:77-99) imply the three deepest endpoints feed the FPN.  Here:
+    `backbone_number` (extra keyword, default 0 = the reference's B0; 3 = BASELINE Cfg5's B3) picks the model and
+    reduction_3/4/5 (strides 8/16/32) go to the FPN as (C3, C4, C5); in_channel must be their widths reversed
+    (B0 [320, 112, 40], B3 [384, 136, 48])."""
+
     def __init__(self, in_channel: List[int], num_class: int, feature: int, freeze_bn: bool = True,
-                 efficientnet: bool = False):
+                 efficientnet: bool = False, backbone_number: int = 0):
         super().__init__()
+        self.efficientnet = bool(efficientnet)
         if efficientnet:
-            raise FdError("EfficientNet backbones (efficientnet_pytorch, third-party) are not built; use ResNet-50")
-        self.backbone = ResNet50(3)
+            from ..backbone.efficientnetv1 import EfficientNetV1    # (lazy: that module imports this package's _planned)
+            self.backbone = EfficientNetV1(backbone_number)
+            want = self.backbone.endpoint_channels[:1:-1]
+            if list(in_channel) != want:
+                raise FdError(f"FCOS(efficientnet=True, backbone_number={backbone_number}) needs in_channel={want} "
+                              f"(reduction_5/4/3 widths), got {list(in_channel)}")
+            blocks = list(self.backbone.model._blocks)
+            # widest stride-2 activation: the stem output or the first stride-2 block's expanded input (plan_batch_limit)
+            self._largest_map_channels = max([self.backbone.model._conv_stem.out_channels] +
+                                             [b._depthwise_conv.in_channels for b in blocks[:next(i for i, b in enumerate(blocks) if b.stride > 1) + 1]])
+        else:
+            self.backbone = ResNet50(3)
         self.FPN = FeaturePyramidNetwork(in_channel, feature)
         self.head = HeadFCOS(feature, num_class, 0.01)
         self.backbone_freeze = freeze_bn
@@ -154,11 +174,15 @@ class FCOS(PlannedModule):
                     for p in m.parameters():
                         p.requires_grad = False
 
-    def build_plan(self, B: int, H: int, W: int, device, u8: bool = False):
+    def build_plan(self, B: int, H: int, W: int, device, input_mode=None):
         plan = engine.Plan(device, self.conv_precision)
         plan.image_ref = [None]
-        plan.input_u8 = (self.pixel_mean, self.pixel_std) if u8 else None
-        feats = engine.build_resnet50(plan, self.backbone.trunk, B, H, W, plan.image_ref)
+        plan.input_mode, plan.canvas_hw = input_mode, (H, W)
+        plan.input_u8 = (self.pixel_mean, self.pixel_std) if input_mode else None
+        if self.efficientnet:
+            feats = engine.build_efficientnet(plan, self.backbone.model, B, H, W, plan.image_ref, keep=(2, 3, 4))[2:]
+        else:
+            feats = engine.build_resnet50(plan, self.backbone.trunk, B, H, W, plan.image_ref)
         pyr, segs = engine.build_fcos_fpn(plan, self.FPN, feats)
         for r, _ in feats:
             plan.pool.put(r)
@@ -166,23 +190,12 @@ class FCOS(PlannedModule):
         plan.outs, plan.segs = outs, segs
         return plan
 
-    pixel_mean = (0.485, 0.456, 0.406)   # dataset/voc.py:57-58
-    pixel_std = (0.229, 0.224, 0.225)
-
-    def plan_for(self, x: torch.Tensor):
-        self._check_eval()
-        if x.dtype == torch.uint8:       # [B, H, W, 3] uint8: resized + padded images, normalised on the device
-            if x.dim() != 4 or x.shape[3] != 3 or not x.is_cuda or x.shape[1] % 32 or x.shape[2] % 32:
-                raise FdError("uint8 input must be a CUDA [B, H, W, 3] tensor with H, W multiples of 32")
-            B, H, W, _ = x.shape
-            return self._get_plan(("model_u8", B, H, W, str(x.device)), lambda: self.build_plan(B, H, W, x.device, True))
-        self._check_image(x)
-        B, _, H, W = x.shape
-        return self._get_plan(("model", B, H, W, str(x.device)), lambda: self.build_plan(B, H, W, x.device))
-
     def forward(self, x: torch.Tensor, events=None):
         if self.training:
             self._check_train_input(x)
+            if self.efficientnet:
+                raise FdError("FCOS(efficientnet=True) is inference-only on the HIP path: the MBConv trunk has no backward "
+                              "kernels (the reference's train.py:92-97 never builds it); call model.eval()")
             T.PACKS.refresh()        # every parameter's packed conv weights for this step, one launch
             return self.head.train_forward(self.FPN.train_forward(trunk_train_forward(self.backbone.trunk, x)))
         chunk = self.plan_batch_limit(x)

@@ -200,10 +200,11 @@ class HalfInvertedStageFCOS(PlannedModule):
                         p.requires_grad = False
             self.backbone.freeze_stages(1)
 
-    def build_plan(self, B: int, H: int, W: int, device, u8: bool = False):
+    def build_plan(self, B: int, H: int, W: int, device, input_mode=None):
         plan = engine.Plan(device, self.conv_precision)
         plan.image_ref = [None]
-        plan.input_u8 = (self.pixel_mean, self.pixel_std) if u8 else None
+        plan.input_mode, plan.canvas_hw = input_mode, (H, W)
+        plan.input_u8 = (self.pixel_mean, self.pixel_std) if input_mode else None
         feats = engine.build_resnet50(plan, self.backbone.trunk, B, H, W, plan.image_ref)
         plan.marks["backbone_end"] = (0, len(plan.steps))
         pyr, segs = engine.build_his_fpn(plan, self.fpn, feats)
@@ -213,20 +214,6 @@ class HalfInvertedStageFCOS(PlannedModule):
         outs = engine.build_his_head(plan, self.head, pyr, segs)
         plan.outs, plan.segs = outs, segs
         return plan
-
-    pixel_mean = (0.485, 0.456, 0.406)   # dataset/voc.py:57-58
-    pixel_std = (0.229, 0.224, 0.225)
-
-    def plan_for(self, x: torch.Tensor):
-        self._check_eval()
-        if x.dtype == torch.uint8:       # [B, H, W, 3] uint8: resized + padded images, normalised on the device
-            if x.dim() != 4 or x.shape[3] != 3 or not x.is_cuda or x.shape[1] % 32 or x.shape[2] % 32:
-                raise FdError("uint8 input must be a CUDA [B, H, W, 3] tensor with H, W multiples of 32")
-            B, H, W, _ = x.shape
-            return self._get_plan(("model_u8", B, H, W, str(x.device)), lambda: self.build_plan(B, H, W, x.device, True))
-        self._check_image(x)
-        B, _, H, W = x.shape
-        return self._get_plan(("model", B, H, W, str(x.device)), lambda: self.build_plan(B, H, W, x.device))
 
     def forward(self, x: torch.Tensor, events=None):
         """[B,3,H,W] fp32 CUDA -> (cls_logits, cnt_logits, reg_preds), each a list of 5 NCHW-shaped tensors

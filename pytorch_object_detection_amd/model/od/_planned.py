@@ -56,12 +56,14 @@ class PlannedModule(nn.Module):
         self._plans.clear()
 
     max_plan_batch = None    # optional cap on the images one plan handles (larger batches run as consecutive sub-batches)
+    _largest_map_channels = 64   # channels of the widest stride-2 activation (ResNet stem: 64)
 
     def plan_batch_limit(self, x: torch.Tensor) -> int:
         """Images per plan: the conv kernels address each activation buffer through a 32-bit buffer descriptor
-        (< 3 GiB); the largest map is the stem / layer1 output, H/2 * W/2 * 64 floats per image."""
+        (< 3 GiB); the largest map is the stem / layer1 output, H/2 * W/2 * 64 floats per image (EfficientNet: the first
+        stride-2 block's expanded input)."""
         H, W = (x.shape[1], x.shape[2]) if x.dtype == torch.uint8 else (x.shape[2], x.shape[3])
-        per_image = (H // 2) * (W // 2) * 64 * 4
+        per_image = (H // 2) * (W // 2) * self._largest_map_channels * 4
         lim = max(1, int((3 * 2 ** 30 - 2 ** 24) // per_image))
         return min(lim, self.max_plan_batch) if self.max_plan_batch else lim
 
@@ -87,17 +89,59 @@ class PlannedModule(nn.Module):
         if x.shape[2] % 32 or x.shape[3] % 32:
             raise FdError("H and W must be multiples of 32 (reference datasets pad to 32, dataset/voc.py:128-132)")
 
+    pixel_mean = (0.485, 0.456, 0.406)   # dataset/voc.py:57-58
+    pixel_std = (0.229, 0.224, 0.225)
+
+    def plan_for(self, x):
+        """The cached plan for an input: fp32 [B,3,H,W]; uint8 [B,H,W,3] (normalised on the device); or a list of resized
+        uint8 [h, w, 3] images of different sizes (padded to the batch canvas + normalised on the device)."""
+        self._check_eval()
+        if isinstance(x, (list, tuple)):
+            if not x or any((not isinstance(t, torch.Tensor)) or t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3 or not t.is_cuda
+                            for t in x):
+                raise FdError("forward_images expects a non-empty list of CUDA uint8 [h, w, 3] images")
+            # dataset/voc.py:128-132: pad = 32 - n % 32 (a full extra 32 when already aligned); :149-156: batch maximum
+            H = max(int(t.shape[0]) + 32 - int(t.shape[0]) % 32 for t in x)
+            W = max(int(t.shape[1]) + 32 - int(t.shape[1]) % 32 for t in x)
+            B, dev = len(x), x[0].device
+            return self._get_plan(("model_collate", B, H, W, str(dev)), lambda: self.build_plan(B, H, W, dev, "collate"))
+        if x.dtype == torch.uint8:       # [B, H, W, 3] uint8: resized + padded images, normalised on the device
+            if x.dim() != 4 or x.shape[3] != 3 or not x.is_cuda or x.shape[1] % 32 or x.shape[2] % 32:
+                raise FdError("uint8 input must be a CUDA [B, H, W, 3] tensor with H, W multiples of 32")
+            B, H, W, _ = x.shape
+            return self._get_plan(("model_u8", B, H, W, str(x.device)), lambda: self.build_plan(B, H, W, x.device, "u8"))
+        self._check_image(x)
+        B, _, H, W = x.shape
+        return self._get_plan(("model", B, H, W, str(x.device)), lambda: self.build_plan(B, H, W, x.device))
+
+    def forward_images(self, images, events=None):
+        """Input pipeline tail on the device: a list of RESIZED uint8 [h_n, w_n, 3] CUDA images (cv2.resize
+        stays on the host, dataset/voc.py:117-126) -> pad-to-32, pad to the batch maximum, ToTensor + Normalize in ONE
+        launch straight into the stem's input layout -> the model.  Returns what model(batch_imgs) returns; the canvas
+        size is `plan.canvas_hw` of `plan_for(images)`."""
+        plan = self.plan_for(list(images))
+        plan.image_ref[0] = [t.contiguous() for t in images]
+        plan.run(events)
+        return tuple(pyramid_out(o, plan.segs) for o in plan.outs)
+
     def _check_eval(self) -> None:
         if self.training:
             raise FdError("the HIP plan implements the frozen-BN inference forward; call model.eval() first")
 
+    freeze_all_bn = False   # opt-in: keep EVERY BatchNorm2d (not only the backbone's) on its running statistics in train()
+
     def train(self, mode: bool = True):
-        """nn.Module.train, except that BatchNorm layers the constructor froze stay in eval mode (the reference freezes
-        them at construction, HISFcos.py:57-68, but its unguarded model.train() silently un-freezes the statistics;
-        SURVEY.md §2 C3)."""
+        """nn.Module.train, except that the BACKBONE's BatchNorm layers stay in eval mode when the constructor froze them
+        (pretrained statistics: the reference freezes them at construction, HISFcos.py:57-68, but its unguarded
+        model.train(), train.py:151, silently un-freezes the statistics; SURVEY.md §2 C3 / §8e recommends keeping the
+        backbone frozen).  Every other BatchNorm -- the randomly initialised FPN ones (HisBlock bn1-4, fpn.gn1-3) --
+        follows nn.Module.train() exactly as in the reference: batch statistics, running-stat updates, SyncBN under DDP,
+        affine parameters frozen by the constructor.  `model.freeze_all_bn = True` pins those too (every BN folded into the
+        HIP conv epilogues: the fastest training step, for fine-tuning from a converged checkpoint)."""
         super().train(mode)
         if mode and getattr(self, "backbone_freeze", False):
-            for m in self.modules():
+            root = self if self.freeze_all_bn else getattr(self, "backbone", None)
+            for m in (root.modules() if root is not None else ()):
                 if isinstance(m, nn.BatchNorm2d):
                     m.eval()
         return self

@@ -61,21 +61,27 @@ def new_rows(rows: int, C_: int, device) -> Rows:
 
 
 # ---------------------------------------------------------------------------------------------------- weights
+def _pad_cin32(w: torch.Tensor) -> torch.Tensor:
+    """Zero input channels up to the next multiple of 32 (the kernel masks the matching activation reads: Cin % 4 == 0)."""
+    i = w.shape[1]
+    if i % 4:
+        raise FdError(f"conv weights need Cin % 4 == 0 (got {i})")
+    return torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, (-i) % 32)) if i % 32 else w
+
+
 def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     """OIHW -> [Cout][Cin/32][KH][KW][32] contiguous: K runs (32-channel chunk, tap, channel-in-chunk), the order the
     conv kernel walks its K-tiles in (taps of one chunk adjacent -> shifted input re-reads stay in L1/L2)."""
+    w = _pad_cin32(w)
     o, i, kh, kw = w.shape
-    if i % 32:
-        raise FdError(f"conv weights need Cin % 32 == 0 (got {i})")
     return w.detach().float().reshape(o, i // 32, 32, kh, kw).permute(0, 1, 3, 4, 2).contiguous()
 
 
 def pack_conv_weight_f16x3(w: torch.Tensor) -> torch.Tensor:
     """OIHW fp32 -> [Cout][Cin/32][KH][KW][2][32] f16: per K-tile of 32 the hi plane then the lo plane, where
     w = hi + lo * 2^-11 (hi = fp16(w) round-to-nearest, lo = fp16((w - hi) * 2^11)): FD_PREC_F16X3 operand format."""
+    w = _pad_cin32(w)
     o, i, kh, kw = w.shape
-    if i % 32:
-        raise FdError(f"conv weights need Cin % 32 == 0 (got {i})")
     t = w.detach().float().reshape(o, i // 32, 32, kh, kw).permute(0, 1, 3, 4, 2)      # [O, I/32, KH, KW, 32]
     hi = t.half()
     lo = ((t - hi.float()) * 2048.0).half()
@@ -93,6 +99,19 @@ def pack_stem_weight(w: torch.Tensor) -> torch.Tensor:
 def pack_dw_weight(w: torch.Tensor) -> torch.Tensor:
     """[C,1,3,3] -> [9][C]."""
     return w.detach().reshape(w.shape[0], 9).t().contiguous().float()
+
+
+def pack_dwk_weight(w: torch.Tensor) -> torch.Tensor:
+    """[C,1,K,K] -> [K*K][C] (fd_dwconv2d_nhwc)."""
+    return w.detach().reshape(w.shape[0], -1).t().contiguous().float()
+
+
+def pack_stem3_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,3,K,K] -> [K*K][4][Cout] (fd_stem_conv_nhwc4); input channel 3 is zero."""
+    co, ci, kh, kw = w.shape
+    p = torch.zeros(kh * kw, 4, co, dtype=torch.float32, device=w.device)
+    p[:, :ci, :] = w.detach().float().permute(2, 3, 1, 0).reshape(kh * kw, ci, co)
+    return p.contiguous()
 
 
 def fold_bn(weight, bias, mean, var, eps: float = 1e-5, conv_bias: Optional[torch.Tensor] = None):
@@ -337,6 +356,42 @@ def dwconv3x3(x: Rows, w9c: torch.Tensor, y: Rows, segs: Segs, scale=None, shift
                                        C.byref(segs), _stream()), "fd_dwconv3x3_nhwc")
 
 
+def dwconv2d(x: Rows, wkc: torch.Tensor, y: Rows, N: int, H: int, W: int, K: int, stride: int, pad_top: int, pad_left: int,
+             Ho: int, Wo: int, scale=None, shift=None, act: int = ACT_NONE) -> None:
+    """Depthwise K x K, stride 1 / 2, asymmetric zero padding (EfficientNet MBConv), + scale / shift + act."""
+    check(_lib.lib().fd_dwconv2d_nhwc(x.ptr, x.cs, x.co, wkc.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                      shift.data_ptr() if shift is not None else None, y.ptr, y.cs, y.co, N, H, W, x.C, K, stride,
+                                      pad_top, pad_left, Ho, Wo, act, _stream()), "fd_dwconv2d_nhwc")
+
+
+def stem_conv3(x4: torch.Tensor, w: torch.Tensor, y: Rows, N: int, H: int, W: int, K: int, stride: int, pad_top: int,
+               pad_left: int, Ho: int, Wo: int, scale=None, shift=None, act: int = ACT_NONE) -> None:
+    """3-channel stem conv on the [N*H*W, 4] image layout (w from pack_stem3_weight)."""
+    check(_lib.lib().fd_stem_conv_nhwc4(x4.data_ptr(), w.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                        shift.data_ptr() if shift is not None else None, y.ptr, y.cs, y.co, N, H, W, y.C, K, stride,
+                                        pad_top, pad_left, Ho, Wo, act, _stream()), "fd_stem_conv_nhwc4")
+
+
+def collate_u8(images: Sequence[torch.Tensor], H: int, W: int, mean, std, out: Optional[torch.Tensor] = None):
+    """Resized uint8 [h_n, w_n, 3] CUDA images of different sizes -> one normalised [N*H*W, 4] fp32 batch
+    (dataset/voc.py:128-132,141-156 on the device).  Returns (batch rows tensor, keep-alive tuple)."""
+    N = len(images)
+    dev = images[0].device
+    for t in images:
+        _need_gpu(t)
+        if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3 or not t.is_contiguous() or t.shape[0] > H or t.shape[1] > W:
+            raise FdError("collate_u8: images must be contiguous CUDA uint8 [h, w, 3] with h <= H and w <= W")
+    ptrs = torch.tensor([t.data_ptr() for t in images], dtype=torch.int64).to(dev)
+    hw = torch.tensor([[t.shape[0], t.shape[1]] for t in images], dtype=torch.int32).to(dev)
+    if out is None:
+        out = torch.empty(N * H * W, 4, dtype=torch.float32, device=dev)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s_ = (C.c_float * 3)(*[float(v) for v in std])
+    check(_lib.lib().fd_collate_u8_nhwc4(ptrs.data_ptr(), hw.data_ptr(), out.data_ptr(), N, H, W, m, s_, _stream()),
+          "fd_collate_u8_nhwc4")
+    return out, (ptrs, hw, tuple(images))
+
+
 def dwconv3x3_wgrad(x: Rows, dy: Rows, segs: Segs, scale: Optional[torch.Tensor] = None, torch_layout: bool = False) -> torch.Tensor:
     """Weight gradient of the depthwise 3x3 conv (stride 1, pad 1) given dy: [9][C], or [C][1][3][3] with torch_layout."""
     dev = x.buf.device
@@ -481,6 +536,32 @@ def clip_boxes_(boxes: torch.Tensor, img_h: int, img_w: int) -> torch.Tensor:
     assert boxes.is_contiguous() and boxes.shape[-1] == 4 and boxes.dtype == torch.float32
     check(_lib.lib().fd_clip_boxes(boxes.data_ptr(), boxes.numel() // 4, img_h, img_w, _stream()), "fd_clip_boxes")
     return boxes
+
+
+def pack_detections(scores: torch.Tensor, classes: torch.Tensor, boxes: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+    """Padded detections of B images -> one [B, K+1, 6] fp32 message (row 0 = count; then x1, y1, x2, y2, score, class)."""
+    _need_gpu(scores, classes, boxes, counts)
+    B, K = scores.shape
+    assert classes.dtype == torch.int64 and counts.dtype == torch.int32
+    rec = torch.empty(B, K + 1, 6, dtype=torch.float32, device=scores.device)
+    check(_lib.lib().fd_pack_detections(scores.contiguous().data_ptr(), classes.contiguous().data_ptr(), boxes.contiguous().data_ptr(),
+                                        counts.contiguous().data_ptr(), B, K, rec.data_ptr(), _stream()), "fd_pack_detections")
+    return rec
+
+
+def unpack_detections(rec: torch.Tensor):
+    """Inverse of pack_detections on [B, K+1, 6] records -> (scores [B,K], classes [B,K] int64, boxes [B,K,4], counts [B] int32)."""
+    _need_gpu(rec)
+    B, K1, six = rec.shape
+    assert six == 6 and rec.is_contiguous() and rec.dtype == torch.float32
+    K, dev = K1 - 1, rec.device
+    s = torch.empty(B, K, dtype=torch.float32, device=dev)
+    c = torch.empty(B, K, dtype=torch.int64, device=dev)
+    b = torch.empty(B, K, 4, dtype=torch.float32, device=dev)
+    n = torch.empty(B, dtype=torch.int32, device=dev)
+    check(_lib.lib().fd_unpack_detections(rec.data_ptr(), B, K, s.data_ptr(), c.data_ptr(), b.data_ptr(), n.data_ptr(), _stream()),
+          "fd_unpack_detections")
+    return s, c, b, n
 
 
 # ---------------------------------------------------------------------------------------------------- loss

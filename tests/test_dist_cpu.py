@@ -20,8 +20,22 @@ def test_shard_batch_partition():
 
 def test_pack_roundtrip():
     s, c, b = torch.rand(3, 7), torch.randint(1, 81, (3, 7)), torch.rand(3, 7, 4) * 640
-    s2, c2, b2 = unpack_detections(pack_detections(s, c, b))
-    assert torch.equal(s, s2) and torch.equal(c, c2) and torch.equal(b, b2)
+    n = torch.tensor([7, 0, 3], dtype=torch.int32)
+    rec = pack_detections(s, c, b, n)
+    assert rec.shape == (3, 8, 6) and rec.dtype == torch.float32      # ONE message: counts ride in row 0
+    s2, c2, b2, n2 = unpack_detections(rec)
+    assert torch.equal(s, s2) and torch.equal(c, c2) and torch.equal(b, b2) and torch.equal(n, n2) and n2.dtype == torch.int32
+
+
+def test_gather_is_a_single_collective(monkeypatch):
+    """north_star: 'a single RCCL all-gather of final detections' -- count the collectives gather_detections issues."""
+    calls = []
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "all_gather_into_tensor", lambda out, inp, group=None: (calls.append(tuple(inp.shape)), out.copy_(torch.cat([inp, inp])))[0])
+    s, c, b, n = torch.rand(2, 5), torch.randint(1, 81, (2, 5)), torch.rand(2, 5, 4), torch.tensor([5, 2], dtype=torch.int32)
+    gs, gc, gb, gn = gather_detections(s, c, b, n)
+    assert calls == [(2, 6, 6)] and gn.tolist() == [5, 2, 5, 2] and torch.equal(gs[2:], s)
 
 
 def _worker(rank, world, port):

@@ -147,3 +147,54 @@ def test_backward_abi_argument_errors_without_gpu():
     assert lib.fd_dwconv3x3_wgrad_workspace_bytes(ctypes.byref(segs), 128) > 0
     assert lib.fd_groupnorm_act_bwd_nhwc(None, 0, 0, None, 0, 0, None, None, None, 0, 0, None, None, 64, 32, 1e-5, 0,
                                          ctypes.byref(segs), None, None, None) < 0
+
+
+def test_efficientnet_containers_match_published_architecture():
+    """The EfficientNet trunk is third-party arithmetic (efficientnet_pytorch 0.7.1, absent here): pin the restated
+    architecture table to what IS published -- the parameter counts of B0..B7 -- and to the reference's own notes (B3
+    endpoints 24/32/48/136/384), for the product containers AND the oracle's independent table."""
+    from oracle import effnet_ref as E
+    from pytorch_object_detection_amd.model.backbone.efficientnetv1 import EfficientNetV1, static_same_padding
+    published = {0: 5288548, 1: 7794184, 2: 9109994, 3: 12233232, 4: 19341616, 5: 30389784, 6: 43040704, 7: 66347960}
+    for n in (0, 3, 7):
+        net = EfficientNetV1(n)
+        assert sum(p.numel() for p in net.parameters()) == published[n], n
+        stem, blocks, head, res = E.block_table(E.VALID_MODELS[n])
+        assert len(blocks) == len(net.model._blocks) and res == net.model.image_size
+        for (k, s, e, ci, co, nominal), blk in zip(blocks, net.model._blocks):
+            assert (k, s, e, ci, co) == (blk.kernel, blk.stride, blk.expand, blk.cin, blk.cout)
+            assert E.same_pad(nominal, k, s) == blk.pad
+    b3 = EfficientNetV1(3)
+    assert b3.endpoint_channels == [24, 32, 48, 136, 384]
+    # static "SAME" padding computed for the nominal 300x300 input, whatever arrives (Conv2dStaticSamePadding)
+    assert b3.model.stem_pad == (0, 1)
+    assert [(b.kernel, b.pad) for b in b3.model._blocks if b.stride == 2] == [(3, (0, 1)), (5, (2, 2)), (3, (0, 1)), (5, (2, 2))]
+    assert static_same_padding(224, 5, 2) == (1, 2) and static_same_padding(19, 5, 1) == (2, 2)
+    sd = b3.state_dict()
+    for k in ("model._conv_stem.weight", "model._bn0.running_var", "model._blocks.0._depthwise_conv.weight", "model._blocks.0._se_reduce.bias",
+              "model._blocks.2._expand_conv.weight", "model._blocks.25._project_conv.weight", "model._blocks.25._bn2.num_batches_tracked",
+              "model._conv_head.weight", "model._bn1.weight", "model._fc.bias"):
+        assert k in sd, k
+    assert "model._blocks.0._expand_conv.weight" not in sd          # expand ratio 1: no expansion conv
+    assert sd["model._blocks.2._se_reduce.weight"].shape == (6, 144, 1, 1) and b3.model._bn0.eps == 1e-3
+    f = FCOS([384, 136, 48], 80, 256, efficientnet=True, backbone_number=3)
+    assert "backbone.model._blocks.7._bn1.running_mean" in f.state_dict()
+    with pytest.raises(_lib.FdError, match="in_channel"):
+        FCOS([2048, 1024, 512], 80, 256, efficientnet=True, backbone_number=3)
+    with pytest.raises(_lib.FdError, match="GPU only"):
+        b3.eval()(torch.zeros(1, 3, 64, 64))
+
+
+def test_effnet_oracle_runs_and_is_deterministic():
+    from oracle import effnet_ref as E
+    from effnet_init import init_effnet
+    from pytorch_object_detection_amd.model.backbone.efficientnetv1 import EfficientNetV1
+    net = EfficientNetV1(0).eval()
+    init_effnet(net, 1)
+    sd = {"backbone." + k: v for k, v in net.state_dict().items()}
+    x = torch.randn(1, 3, 96, 64, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        e = E.extract_endpoints(sd, x, "efficientnet-b0")
+    assert [tuple(e[f"reduction_{i}"].shape[1:]) for i in range(1, 7)] == [(16, 48, 32), (24, 24, 16), (40, 12, 8), (112, 6, 4), (320, 3, 2),
+                                                                          (1280, 3, 2)]
+    assert all(0.05 < float(e[f"reduction_{i}"].std()) < 5 for i in range(1, 6))       # the test init keeps every endpoint O(1)

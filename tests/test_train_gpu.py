@@ -37,6 +37,7 @@ def test_train_step_matches_oracle_autograd():
     ref = R.fcos_loss(outs, tg, "giou")
     ref[3].backward()
 
+    model.freeze_all_bn = True          # every BatchNorm on its running statistics (the oracle call above does the same)
     model.to(DEV).train()
     assert not any(b.training for b in model.modules() if isinstance(b, torch.nn.BatchNorm2d))   # frozen BN stays frozen
     opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-2, momentum=0.9, weight_decay=1e-4)
@@ -269,3 +270,42 @@ def test_packed_weight_cache_follows_every_kind_of_update():
     sd["fpn.tf1.weight"] = sd["fpn.tf1.weight"] * 0.25
     model.load_state_dict(sd)
     same(fwd(), stock())
+
+
+def test_default_train_mode_fpn_batchnorm_follows_the_reference():
+    """only the BACKBONE's BatchNorms stay frozen in train(); the randomly initialised FPN BatchNorms run on batch
+    statistics and update their running statistics, as the reference's model.train() makes them (train.py:151).  Losses and
+    the updated running statistics against the oracle run with the same layers in training mode."""
+    torch.manual_seed(2)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256)
+    x = torch.randn(4, 3, 256, 256)
+    gt = torch.tensor([[[10., 12., 60., 70.]], [[30., 30., 220., 210.]], [[5., 5., 125., 130.]], [[64., 20., 200., 190.]]])
+    labels = torch.tensor([[3], [7], [1], [12]])
+    strides, ranges = [8, 16, 32, 64, 128], [[-1, 32], [32, 96], [96, 192], [192, 384], [384, 9999999]]
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    R.BN_TRAIN_PREFIXES = ("fpn.",)
+    try:
+        with torch.no_grad():
+            outs = R.hisfcos_forward(sd, x)
+    finally:
+        R.BN_TRAIN_PREFIXES = ()
+    ref = R.fcos_loss(outs, R.gen_targets([tuple(o.shape[2:]) for o in outs[0]], strides, ranges, gt, labels), "giou")
+    model.to(DEV).train()
+    bns = {n: m for n, m in model.named_modules() if isinstance(m, torch.nn.BatchNorm2d)}
+    assert all(m.training == n.startswith("fpn.") for n, m in bns.items())
+    assert not any(p.requires_grad for m in bns.values() for p in m.parameters())          # affine stays frozen (HISFcos.py:57-68)
+    out = model(x.to(DEV))
+    losses = FCOSLoss("giou")([out, FCOSGenTargets(strides, ranges)([out, gt.to(DEV), labels.to(DEV)])])
+    np.testing.assert_allclose([float(v.detach()) for v in losses], [float(v) for v in ref], rtol=5e-4)
+    losses[-1].backward()
+    for n in ("fpn.HisBlock3.bn4", "fpn.gn1", "fpn.gn2", "fpn.HisBlock7.bn1"):
+        m = bns[n]
+        assert float(m.running_mean.abs().max()) > 0                                        # moved away from the init (0, 1)
+        np.testing.assert_allclose(m.running_mean.cpu().numpy(), sd[n + ".running_mean"].numpy(), atol=2e-5, rtol=2e-4)
+        np.testing.assert_allclose(m.running_var.cpu().numpy(), sd[n + ".running_var"].numpy(), atol=2e-5, rtol=2e-4)
+    assert float(bns["fpn.gn3"].running_mean.abs().max()) == 0                              # gn3 is dead in the reference too
+    assert float(bns["backbone.extract_feature.layer2.0.bn1"].running_mean.abs().max()) == 0
+    g = model.fpn.HisBlock3.conv4.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    model.freeze_all_bn = True
+    assert not any(m.training for m in model.train().modules() if isinstance(m, torch.nn.BatchNorm2d))

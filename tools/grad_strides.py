@@ -1,0 +1,31 @@
+"""Diagnostic: which parameter gradients of the HIP training graph violate the strict gradient layout contract
+(grad.stride() != param.stride()) -- the cause of DDP's 'Grad strides do not match bucket view strides' warning."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pytorch_object_detection_amd.model.od import HalfInvertedStageFCOS
+from pytorch_object_detection_amd.model.loss import FCOSLoss
+from pytorch_object_detection_amd.model.modules.head import FCOSGenTargets
+dev = "cuda:0"
+torch.manual_seed(0)
+model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).to(dev)
+model.freeze_all_bn = len(sys.argv) > 1
+model.train()
+seen = {}
+for n, p in model.named_parameters():
+    if p.requires_grad:
+        p.register_hook(lambda g, n=n, p=p: seen.__setitem__(n, (tuple(g.shape), g.stride(), p.stride())) if g.stride() != p.stride() else None)
+x = torch.randn(2, 3, 128, 128, device=dev)
+gt = torch.tensor([[[10., 12., 60., 70.]], [[30., 20., 110., 100.]]], device=dev)
+labels = torch.tensor([[3], [7]], device=dev)
+gen = FCOSGenTargets([8, 16, 32, 64, 128], [[-1, 64], [64, 128], [128, 256], [256, 512], [512, 999999]])
+for amp in (False, True):
+    seen.clear()
+    model.zero_grad()
+    with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+        out = model(x)
+        loss = FCOSLoss("giou")([out, gen([out, gt, labels])])[-1]
+    loss.backward()
+    for n, v in seen.items():
+        print("amp" if amp else "f32", n, v)
+    print("amp" if amp else "f32", len(seen), "gradients with strides != param strides")
