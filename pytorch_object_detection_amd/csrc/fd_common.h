@@ -25,6 +25,20 @@ void fd_set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
+// One-time per-device kernel attribute (dynamic LDS above 64 KiB): `mask` is a function-local static std::atomic<unsigned>,
+// one bit per device ordinal; a second thread racing here merely sets the same attribute twice.  Keeps the entry points
+// re-entrant and correct with several devices in one process.
+#include <atomic>
+static inline void fd_set_max_lds_once(std::atomic<unsigned>& mask, const void* kern, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned bit = 1u << (dev & 31);
+    if (!(mask.load(std::memory_order_acquire) & bit)) {
+        hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        mask.fetch_or(bit, std::memory_order_release);
+    }
+}
+
 static inline int fd_segs_ok(const fd_segs* s) {
     if (!s || s->nseg < 1 || s->nseg > FD_MAX_SEG || s->batch < 1 || s->m_start[0] != 0) return 0;
     for (int i = 0; i < s->nseg; ++i) {

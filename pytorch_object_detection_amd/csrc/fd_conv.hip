@@ -39,6 +39,15 @@ struct ConvArgs {
     int res_mask;  // 1: `res` is a ReLU mask (y = res > 0 ? v : 0) instead of an addend
 };
 
+// LDS hand-off between lanes of ONE wave: the LDS pipe executes a wave's ds instructions in order, so later reads see
+// earlier writes once lgkmcnt has drained; the fence + wave barrier keep the compiler from moving accesses across.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
 // split-f16 planes: rows of 32 halves (64 B); c8 = 16-byte chunk (8 halves) 0..3, XOR-swizzled by (row>>2)&3
 __device__ __forceinline__ int lds_off_h(int row, int c8) { return row * 32 + ((c8 ^ ((row >> 2) & 3)) << 3); }
@@ -306,7 +315,7 @@ void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + l31] = acc[i][j][e] * sc + sf;
-                __syncthreads();
+                wave_lds_sync();     // the stage is private to this wave: no workgroup barrier needed
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int row = (lane >> 3) + 8 * p, c4 = (lane & 7) * 4;
@@ -341,7 +350,7 @@ void conv_igemm_kernel(ConvArgs a) {
                         *reinterpret_cast<float4*>(ybase + (size_t)m * a.y_cs + a.y_co + nn) = v;
                     }
                 }
-                __syncthreads();
+                wave_lds_sync();
             } else {
                 const int act = (n >= a.act_c0) ? a.act : FD_ACT_NONE;
 #pragma unroll
@@ -417,11 +426,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
     auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static std::atomic<unsigned> attr_mask{0};       // per kernel instantiation, one bit per device
+    fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles, (a.KT + a.kt_per - 1) / a.kt_per), dim3(NT), lds, stream, b);
     FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32");
     return FD_OK;

@@ -64,7 +64,7 @@ class Pool:
 
 
 class Plan:
-    def __init__(self, device, precision: Optional[str] = None):
+    def __init__(self, device, precision: Optional[str] = None, pair_tuned: bool = False):
         self.device = device
         self.steps: List[Callable[[], None]] = []
         self.names: List[str] = []
@@ -78,6 +78,7 @@ class Plan:
         if self.precision not in ("f32", "f16x3"):
             raise FdError(f"unknown conv precision '{self.precision}' (f32 | f16x3)")
         self.tiles: Dict[str, int] = {}
+        self.pair_tuned = pair_tuned       # block tiles picked for throughput beside a second batch (pipeline.TwoLanePipeline)
 
     def add(self, name: str, fn: Callable[[], None]) -> None:
         self.steps.append(fn)
@@ -167,7 +168,7 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         key = f"B{segs.batch}|{hw}|{Cin}>{co}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{x.cs}|ycs{y.cs}"
         if split:
             key = "f16x3|" + key
-        plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co, -(-Cin // 32) * k * k)
+        plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co, -(-Cin // 32) * k * k, pair=plan.pair_tuned and tag != 1)
     plan.flops += 2 * out.rows * co * Cin * k * k
     plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k
     return out

@@ -175,7 +175,7 @@ class FCOS(PlannedModule):
                         p.requires_grad = False
 
     def build_plan(self, B: int, H: int, W: int, device, input_mode=None):
-        plan = engine.Plan(device, self.conv_precision)
+        plan = engine.Plan(device, self.conv_precision, pair_tuned=getattr(self, "_plan_pair_tuned", False))
         plan.image_ref = [None]
         plan.input_mode, plan.canvas_hw = input_mode, (H, W)
         plan.input_u8 = (self.pixel_mean, self.pixel_std) if input_mode else None

@@ -92,10 +92,22 @@ class PlannedModule(nn.Module):
     pixel_mean = (0.485, 0.456, 0.406)   # dataset/voc.py:57-58
     pixel_std = (0.229, 0.224, 0.225)
 
-    def plan_for(self, x):
+    def outputs_of(self, plan):
+        """(cls_logits, cnt_logits, reg_preds) views of a plan's output buffers (what forward returns after plan.run())."""
+        return tuple(pyramid_out(o, plan.segs) for o in plan.outs)
+
+    def plan_for(self, x, slot: int = 0):
         """The cached plan for an input: fp32 [B,3,H,W]; uint8 [B,H,W,3] (normalised on the device); or a list of resized
-        uint8 [h, w, 3] images of different sizes (padded to the batch canvas + normalised on the device)."""
+        uint8 [h, w, 3] images of different sizes (padded to the batch canvas + normalised on the device).  `slot` picks
+        one of several independent plan instances of the same shape (own buffers: pipeline.TwoLanePipeline keeps two
+        batches in flight)."""
         self._check_eval()
+        if slot:
+            real, self._get_plan = self._get_plan, (lambda key, build: real(key + ("slot", slot), build))
+            try:
+                return self.plan_for(x, 0)
+            finally:
+                del self._get_plan
         if isinstance(x, (list, tuple)):
             if not x or any((not isinstance(t, torch.Tensor)) or t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3 or not t.is_cuda
                             for t in x):

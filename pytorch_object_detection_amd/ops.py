@@ -217,7 +217,37 @@ def heuristic_conv(M: int, Cout: int, KT: int, have_ws: bool) -> int:
     return tiles | ((ks if ks > 1 else 0) << 8)
 
 
-def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int, reps: int = 3) -> int:
+_PAIR_STREAMS: list = []
+
+
+def _time_launches(run: Callable[[], None], reps: int, pair: bool) -> float:
+    """Device milliseconds per launch.  pair=True: the launch runs beside a twin of itself on a second stream (what a layer
+    meets under pipeline.TwoLanePipeline, where the other batch's kernels fill its tail): per-launch share of the pair."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if not pair:
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+    if not _PAIR_STREAMS:
+        _PAIR_STREAMS.extend([torch.cuda.Stream(), torch.cuda.Stream()])
+    cur = torch.cuda.current_stream()
+    e0.record()
+    for st in _PAIR_STREAMS:
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            for _ in range(reps):
+                run()
+    for st in _PAIR_STREAMS:
+        cur.wait_stream(st)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / (2 * reps)
+
+
+def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int, reps: int = 3, pair: bool = False) -> int:
     """Block-tile (+ split-K factor) choice for one conv launch.  Looked up in the committed table
     (tuned/gfx950_tiles.json, measured on MI355X) first; a miss is timed on the spot under every sensible tile — and,
     for maps with few tiles, K split 2/4/8 ways — (best of 3 batches of `reps` launches) and remembered for the
@@ -231,10 +261,13 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
             p.ksplit = 1
         return code
 
+    base = key
+    if pair:                         # tiles chosen for throughput beside another batch: own table entries, serial ones as fallback
+        key = "pair|" + key
     if _TUNE_MODE != "force" and key in table:
         return apply(int(table[key]))
     if _TUNE_MODE == "0":
-        return apply(heuristic_conv(M, Cout, KT, bool(p.workspace)))
+        return apply(int(table[base]) if base in table else heuristic_conv(M, Cout, KT, bool(p.workspace)))
     cands = [(0, 1)]
     for tid, (bm, bn) in _lib.TILES.items():
         padded = -(-Cout // bn) * bn
@@ -251,13 +284,7 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
         run()  # warm
         t = float("inf")
         for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                run()
-            e1.record()
-            e1.synchronize()
-            t = min(t, e0.elapsed_time(e1) / reps)
+            t = min(t, _time_launches(run, reps, pair))
         if t < best_t * 0.985:  # an earlier (simpler) candidate wins near-ties
             best, best_t = tid | ((ks if ks > 1 else 0) << 8), t
     table[key] = best

@@ -291,3 +291,34 @@ def test_batches_beyond_the_plan_limit_run_as_sub_batches():
     fh = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
     sb = fh.detect_padded(parts)          # plain lists of NCHW tensors are accepted like the plan-owned pyramid
     assert sb[0].shape[0] == 5 and int(sb[3].min()) >= 0
+
+
+def test_two_lane_pipeline_matches_serial_steps():
+    """pipeline.TwoLanePipeline (two batches in flight on two HIP streams, the head tower of every step exclusive): every step's
+    detections equal the ones the same input gives through the plain single-stream forward."""
+    from pytorch_object_detection_amd.pipeline import TwoLanePipeline
+    torch.manual_seed(31)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).eval()
+    randomize_norms(model, 32)
+    model.to(DEV)
+    head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
+
+    def post(out, x, tag):
+        s, c, b, n = head.detect_padded(out)
+        return [t.clone() for t in (s, c, ClipBoxes()(x, b), n)] + [tag]
+
+    xs = [torch.randn(2, 3, 128, 160, device=DEV) for _ in range(5)]
+    serial = [post(model(x), x, i) for i, x in enumerate(xs)]
+    pipe = TwoLanePipeline(model, post)
+    got = []
+    for i, x in enumerate(xs):
+        r = pipe.submit(x, tag=i)
+        if r is not None:
+            got.append(r)
+    got.append(pipe.drain())
+    torch.cuda.synchronize()
+    assert [g[4] for g in got] == [0, 1, 2, 3, 4]
+    assert 0 <= pipe.cut <= pipe.lo < pipe.hi
+    for a, b in zip(serial, got):
+        for u, v in zip(a[:4], b[:4]):
+            assert torch.equal(u, v)

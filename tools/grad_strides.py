@@ -19,13 +19,22 @@ x = torch.randn(2, 3, 128, 128, device=dev)
 gt = torch.tensor([[[10., 12., 60., 70.]], [[30., 20., 110., 100.]]], device=dev)
 labels = torch.tensor([[3], [7]], device=dev)
 gen = FCOSGenTargets([8, 16, 32, 64, 128], [[-1, 64], [64, 128], [128, 256], [256, 512], [512, 999999]])
+import torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+dist.init_process_group("nccl", rank=0, world_size=1)
+net = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
+net.train()
 for amp in (False, True):
     seen.clear()
     model.zero_grad()
     with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
-        out = model(x)
+        out = net(x)
         loss = FCOSLoss("giou")([out, gen([out, gt, labels])])[-1]
     loss.backward()
     for n, v in seen.items():
         print("amp" if amp else "f32", n, v)
     print("amp" if amp else "f32", len(seen), "gradients with strides != param strides")
+    for n, p in model.named_parameters():
+        if p.grad is not None and p.grad.stride() != p.stride():
+            print("  .grad", n, tuple(p.shape), p.grad.stride(), p.stride())
+dist.destroy_process_group()

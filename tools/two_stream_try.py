@@ -34,7 +34,29 @@ def base():
         return s, c, clip(x, b), n
     return run
 
-for name, fn in (("1 plan B=16", base()), ("2 x B=8, 2 streams", make(2, 2)), ("4 x B=4, 2 streams", make(4, 2)),
+def pipelined(nslot):
+    """successive B=16 steps alternate between `nslot` plan instances on their own streams (two batches in flight)."""
+    models = [build_model(80, 0).to(dev) for _ in range(nslot)]
+    streams = [torch.cuda.Stream() for _ in range(nslot)]
+    state = {"i": 0, "last": None}
+    def run():
+        k = state["i"] % nslot
+        state["i"] += 1
+        cur = torch.cuda.current_stream()
+        st = streams[k]
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            s, c, b, n = head.detect_padded(models[k](x))
+            out = (s, c, clip(x, b), n)
+        state["last"] = out
+        return out
+    def finish():
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+    run.finish = finish
+    return run
+
+for name, fn in (("1 plan B=16", base()), ("pipelined B=16 x 2 slots", pipelined(2)), ("pipelined B=16 x 3 slots", pipelined(3)), ("2 x B=8, 2 streams", make(2, 2)), ("4 x B=4, 2 streams", make(4, 2)),
                  ("4 x B=4, 4 streams", make(4, 4)), ("2 x B=8, 1 stream", make(2, 1))):
     for _ in range(3):
         r = fn()
@@ -42,6 +64,8 @@ for name, fn in (("1 plan B=16", base()), ("2 x B=8, 2 streams", make(2, 2)), ("
     t = time.perf_counter()
     for _ in range(10):
         r = fn()
+    if hasattr(fn, "finish"):
+        fn.finish()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t) / 10
     print(f"[{prec}] {name}: {el*1e3:.2f} ms/16 images -> {16/el:.1f} img/s (model + head + clip); kept {r[3][:3].tolist()}")
