@@ -274,6 +274,39 @@ int32_t fd_se_scale_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float
                          const float* w2, const float* b2, float* y, int32_t y_cs, int32_t y_co, int32_t N,
                          int32_t HW, int32_t C, int32_t Cr, void* workspace, fd_stream_t stream);
 
+/* Backward of the call above for the train step (train.py:175-181 differentiates HisBlock.conv1_2): dx and the gradients of
+ * both 1x1 convs (dw1 [Cr][C], db1 [Cr], dw2 [C][Cr], db2 [C]).  `fwd_workspace` = the forward call's workspace, untouched
+ * since (pooled sums, gates); `workspace`: fd_se_bwd_workspace_bytes(N, HW, C).  Deterministic (fixed-order sums). */
+int64_t fd_se_bwd_workspace_bytes(int32_t N, int32_t HW, int32_t C);
+int32_t fd_se_scale_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs, int32_t dy_co,
+                             const float* w1, const float* b1, const float* w2, const float* b2, float* dx, int32_t dx_cs,
+                             int32_t dx_co, float* dw1, float* db1, float* dw2, float* db2, int32_t N, int32_t HW, int32_t C,
+                             int32_t Cr, const void* fwd_workspace, void* workspace, fd_stream_t stream);
+
+/* Elementwise activation y = act(x) on a channel view and its backward dx = dy * act'(x) (x = the saved INPUT):
+ * nn.SiLU / nn.ReLU after a BatchNorm (HISFcos.py:100,112), ScaleExp (modules.py:170-176: FD_ACT_EXP, param = scale). */
+int32_t fd_act_nhwc(const float* x, int32_t x_cs, int32_t x_co, float* y, int32_t y_cs, int32_t y_co, int64_t rows, int32_t C,
+                    int32_t act, float param, fd_stream_t stream);
+int32_t fd_act_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs, int32_t dy_co, float* dx,
+                        int32_t dx_cs, int32_t dx_co, int64_t rows, int32_t C, int32_t act, float param, fd_stream_t stream);
+
+/* Backward of fd_maxpool_nhwc (x = the forward input): dx[p] = sum of dy over the windows whose first maximum is p (the
+ * argmax torch's max_pool2d keeps).  Gather form, deterministic.  The fused "+ add" passes dy through unchanged.
+ * Backward of fd_upsample2x_add_nhwc w.r.t. its low-resolution input: dx = sum of the 2x2 block of dy (dy: [N][2H][2W]). */
+int32_t fd_maxpool_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs, int32_t dy_co, float* dx,
+                            int32_t dx_cs, int32_t dx_co, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s,
+                            int32_t pad, fd_stream_t stream);
+int32_t fd_upsample2x_bwd_nhwc(const float* dy, int32_t dy_cs, int32_t dy_co, float* dx, int32_t dx_cs, int32_t dx_co, int32_t N,
+                               int32_t H, int32_t W, int32_t C, fd_stream_t stream);
+
+/* nn.BatchNorm2d in TRAINING mode (the FPN BatchNorms under the reference's model.train(), train.py:151) runs on the
+ * GroupNorm entry points: batch statistics per channel = GroupNorm statistics of ONE image of (batch*H) x W pixels with
+ * G = C groups (fd_segs{nseg 1, batch 1, H = batch*H, W}); forward / backward are fd_groupnorm_act_nhwc /
+ * fd_groupnorm_act_bwd_nhwc.  This call then folds the batch statistics the forward left in its workspace into the running
+ * statistics (momentum update with the unbiased variance, as nn.BatchNorm2d). rows = batch*H*W. */
+int32_t fd_batchnorm_update_running(const void* gn_workspace, int64_t rows, int32_t C, float momentum, float eps,
+                                    float* running_mean, float* running_var, fd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------- */
 /* Detection post-processing (reference model/modules/head.py:8-102,152-162, utill/utills.py:58-73)   */
 

@@ -102,6 +102,70 @@ extern "C" int32_t fd_nhwc_to_nchw(const float* x, int32_t x_cs, int32_t x_co, f
     return FD_OK;
 }
 
+// ------------------------------------------------------------------------------ elementwise activation (+ backward)
+// y = act(x) on a channel view; act in {RELU, SILU, EXP (exp(x * param), ScaleExp of modules.py:170-176), SIGMOID}.
+// Backward: dx = dy * act'(x) from the saved INPUT (SiLU needs the pre-activation; ReLU / EXP / SIGMOID could use the
+// output, the input form keeps one code path).
+__device__ __forceinline__ float fd_act_deriv(float x, int act, float p) {
+    switch (act) {
+        case FD_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case FD_ACT_SILU: { const float sg = fd_sigmoid(x); return sg * (1.f + x * (1.f - sg)); }
+        case FD_ACT_EXP: return p * expf(x * p);
+        case FD_ACT_SIGMOID: { const float sg = fd_sigmoid(x); return sg * (1.f - sg); }
+        default: return 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int y_cs,
+                                                       int y_co, int C4, int act, float prm, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const long m = i / C4;
+        const float4 v = *reinterpret_cast<const float4*>(x + m * x_cs + x_co + 4 * q);
+        *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) =
+            make_float4(fd_act(v.x, act, prm), fd_act(v.y, act, prm), fd_act(v.z, act, prm), fd_act(v.w, act, prm));
+    }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ dy,
+                                                       int dy_cs, int dy_co, float* __restrict__ dx, int dx_cs, int dx_co, int C4,
+                                                       int act, float prm, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const long m = i / C4;
+        const float4 v = *reinterpret_cast<const float4*>(x + m * x_cs + x_co + 4 * q);
+        const float4 g = *reinterpret_cast<const float4*>(dy + m * dy_cs + dy_co + 4 * q);
+        *reinterpret_cast<float4*>(dx + m * dx_cs + dx_co + 4 * q) =
+            make_float4(g.x * fd_act_deriv(v.x, act, prm), g.y * fd_act_deriv(v.y, act, prm), g.z * fd_act_deriv(v.z, act, prm),
+                        g.w * fd_act_deriv(v.w, act, prm));
+    }
+}
+
+static inline bool view_ok(const void* p, int cs, int co, int C);
+
+extern "C" int32_t fd_act_nhwc(const float* x, int32_t x_cs, int32_t x_co, float* y, int32_t y_cs, int32_t y_co, int64_t rows,
+                               int32_t C, int32_t act, float param, fd_stream_t stream) {
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C) && rows >= 1, FD_E_INVAL, "fd_act: bad pointer / channel view (C=%d)", C);
+    FD_REQUIRE(act >= FD_ACT_NONE && act <= FD_ACT_SIGMOID, FD_E_INVAL, "fd_act: unknown activation %d", act);
+    const long total = (long)rows * (C / 4);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, y, y_cs, y_co, C / 4,
+                       act, param, total);
+    FD_CHECK_LAUNCH("fd_act_nhwc");
+    return FD_OK;
+}
+
+extern "C" int32_t fd_act_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs, int32_t dy_co, float* dx,
+                                   int32_t dx_cs, int32_t dx_co, int64_t rows, int32_t C, int32_t act, float param, fd_stream_t stream) {
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(dy, dy_cs, dy_co, C) && view_ok(dx, dx_cs, dx_co, C) && rows >= 1, FD_E_INVAL,
+               "fd_act_bwd: bad pointer / channel view (C=%d)", C);
+    FD_REQUIRE(act >= FD_ACT_NONE && act <= FD_ACT_SIGMOID, FD_E_INVAL, "fd_act_bwd: unknown activation %d", act);
+    const long total = (long)rows * (C / 4);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, dy, dy_cs, dy_co, dx,
+                       dx_cs, dx_co, C / 4, act, param, total);
+    FD_CHECK_LAUNCH("fd_act_bwd_nhwc");
+    return FD_OK;
+}
+
 // ------------------------------------------------------------------------------ max-pool (+ add)
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, int x_cs, int x_co,
                                                        float* __restrict__ y, int y_cs, int y_co,
@@ -182,6 +246,98 @@ extern "C" int32_t fd_upsample2x_add_nhwc(const float* x, int32_t x_cs, int32_t 
     hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs,
                        x_co, lat, lat_cs, lat_co, y, y_cs, y_co, H, W, C / 4, total);
     FD_CHECK_LAUNCH("fd_upsample2x_add_nhwc");
+    return FD_OK;
+}
+
+// ---- backward of max-pool: dx[pixel] = sum of dy over the windows whose FIRST maximum (row-major scan, strict >: the
+// element torch's max_pool2d keeps as argmax) is that pixel.  Gather form, no atomics: deterministic.  The fused "+ add"
+// of the forward passes its gradient through unchanged (dy itself).
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ dy,
+                                                           int dy_cs, int dy_co, float* __restrict__ dx, int dx_cs, int dx_co, int H,
+                                                           int W, int Ho, int Wo, int C4, int k, int s, int pad, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const long m = i / C4;
+        const int wi = (int)(m % W);
+        const long t = m / W;
+        const int hi = (int)(t % H);
+        const long n = t / H;
+        const float* xb = x + (n * H * (long)W) * x_cs + x_co + 4 * q;
+        const float4 me = *reinterpret_cast<const float4*>(xb + ((long)hi * W + wi) * x_cs);
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        const int ho_lo = max(0, (hi + pad - k + s) / s), ho_hi = min(Ho - 1, (hi + pad) / s);
+        const int wo_lo = max(0, (wi + pad - k + s) / s), wo_hi = min(Wo - 1, (wi + pad) / s);
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                // is (hi, wi) the first maximum of window (ho, wo)?  per channel
+                bool first[4] = {true, true, true, true};
+                for (int r = 0; r < k; ++r) {
+                    const int h2 = ho * s - pad + r;
+                    if ((unsigned)h2 >= (unsigned)H) continue;
+                    for (int c = 0; c < k; ++c) {
+                        const int w2 = wo * s - pad + c;
+                        if ((unsigned)w2 >= (unsigned)W || (h2 == hi && w2 == wi)) continue;
+                        const float4 u = *reinterpret_cast<const float4*>(xb + ((long)h2 * W + w2) * x_cs);
+                        const bool before = h2 < hi || (h2 == hi && w2 < wi);   // scanned earlier: wins ties
+                        first[0] = first[0] && (before ? me.x > u.x : me.x >= u.x);
+                        first[1] = first[1] && (before ? me.y > u.y : me.y >= u.y);
+                        first[2] = first[2] && (before ? me.z > u.z : me.z >= u.z);
+                        first[3] = first[3] && (before ? me.w > u.w : me.w >= u.w);
+                    }
+                }
+                const float4 d = *reinterpret_cast<const float4*>(dy + (((n * Ho + ho) * (long)Wo) + wo) * dy_cs + dy_co + 4 * q);
+                if (first[0]) g[0] += d.x;
+                if (first[1]) g[1] += d.y;
+                if (first[2]) g[2] += d.z;
+                if (first[3]) g[3] += d.w;
+            }
+        *reinterpret_cast<float4*>(dx + m * dx_cs + dx_co + 4 * q) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
+static inline bool view_ok(const void* p, int cs, int co, int C);
+
+extern "C" int32_t fd_maxpool_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs, int32_t dy_co,
+                                       float* dx, int32_t dx_cs, int32_t dx_co, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k,
+                                       int32_t s, int32_t pad, fd_stream_t stream) {
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(dy, dy_cs, dy_co, C) && view_ok(dx, dx_cs, dx_co, C), FD_E_INVAL,
+               "fd_maxpool_bwd: channel views must be 4-aligned (C=%d)", C);
+    FD_REQUIRE(N >= 1 && k >= 1 && s >= 1 && pad >= 0 && 2 * pad <= k, FD_E_INVAL, "fd_maxpool_bwd: bad geometry");
+    const int Ho = (H + 2 * pad - k) / s + 1, Wo = (W + 2 * pad - k) / s + 1;
+    FD_REQUIRE(Ho >= 1 && Wo >= 1, FD_E_INVAL, "fd_maxpool_bwd: empty output");
+    const long total = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, dy, dy_cs, dy_co,
+                       dx, dx_cs, dx_co, H, W, Ho, Wo, C / 4, k, s, pad, total);
+    FD_CHECK_LAUNCH("fd_maxpool_bwd_nhwc");
+    return FD_OK;
+}
+
+// ---- backward of nearest x2 upsample: dx[h][w] = dy[2h][2w] + dy[2h][2w+1] + dy[2h+1][2w] + dy[2h+1][2w+1] (fixed order)
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, int dy_cs, int dy_co, float* __restrict__ dx,
+                                                              int dx_cs, int dx_co, int H, int W, int C4, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const long m = i / C4;
+        const int w = (int)(m % W);
+        const long t = m / W;
+        const int h = (int)(t % H);
+        const long n = t / H;
+        const float* b = dy + ((n * 2 * H + 2 * h) * (long)(2 * W) + 2 * w) * dy_cs + dy_co + 4 * q;
+        const float4 a0 = *reinterpret_cast<const float4*>(b), a1 = *reinterpret_cast<const float4*>(b + dy_cs);
+        const float4 a2 = *reinterpret_cast<const float4*>(b + (long)2 * W * dy_cs), a3 = *reinterpret_cast<const float4*>(b + (long)(2 * W + 1) * dy_cs);
+        *reinterpret_cast<float4*>(dx + m * dx_cs + dx_co + 4 * q) =
+            make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w);
+    }
+}
+
+extern "C" int32_t fd_upsample2x_bwd_nhwc(const float* dy, int32_t dy_cs, int32_t dy_co, float* dx, int32_t dx_cs, int32_t dx_co,
+                                          int32_t N, int32_t H, int32_t W, int32_t C, fd_stream_t stream) {
+    FD_REQUIRE(view_ok(dy, dy_cs, dy_co, C) && view_ok(dx, dx_cs, dx_co, C) && N >= 1 && H >= 1 && W >= 1, FD_E_INVAL,
+               "fd_upsample2x_bwd: bad pointer / channel view (C=%d)", C);
+    const long total = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, dy_cs, dy_co, dx, dx_cs,
+                       dx_co, H, W, C / 4, total);
+    FD_CHECK_LAUNCH("fd_upsample2x_bwd_nhwc");
     return FD_OK;
 }
 
@@ -415,7 +571,7 @@ extern "C" int32_t fd_dwconv3x3_bwd_weight_nhwc(const float* x, int32_t x_cs, in
 // ------------------------------------------------------------------------------ GroupNorm + activation
 // pass 1: per (level, image, row-chunk) partial (sum, sumsq) per group, fp64, fixed order
 // pass 2: per (level, image) finalise mean / rstd from the partials, normalise + affine + act
-#define GN_MAXCHUNK 64
+#define GN_MAXCHUNK 256   /* row chunks per (level, image): BatchNorm-as-GroupNorm runs the whole batch as ONE image */
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int x_cs, int x_co, int C, int G,
                                                           SegTab tab, double* __restrict__ part) {
@@ -536,7 +692,7 @@ extern "C" int32_t fd_groupnorm_act_nhwc(const float* x, int32_t x_cs, int32_t x
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, imgs), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, C, G, tab,
                        (double*)workspace);
     FD_CHECK_LAUNCH("fd_groupnorm (partial)");
-    const int ablk = max(1, min(64, (maxhw * (C / 4) + 2047) / 2048));
+    const int ablk = max(1, min(imgs >= 16 ? 64 : 512, (maxhw * (C / 4) + 2047) / 2048));
     hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, imgs), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, gamma, beta, y,
                        y_cs, y_co, C, G, eps, act, tab, (const double*)workspace, (double*)workspace + (long)imgs * GN_MAXCHUNK * G * 2);
     FD_CHECK_LAUNCH("fd_groupnorm (apply)");
@@ -730,7 +886,7 @@ extern "C" int32_t fd_groupnorm_act_bwd_nhwc(const float* x, int32_t x_cs, int32
     FD_CHECK_LAUNCH("fd_groupnorm_bwd (partial)");
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(imgs), dim3(256), 0, st, (const double*)part, img_sums, C, tab);
     FD_CHECK_LAUNCH("fd_groupnorm_bwd (reduce)");
-    const int ablk = max(1, min(64, (maxhw * (C / 4) + 2047) / 2048));
+    const int ablk = max(1, min(imgs >= 16 ? 64 : 512, (maxhw * (C / 4) + 2047) / 2048));
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ablk, imgs), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, gamma, beta, dx,
                        dx_cs, dx_co, C, G, eps, act, tab, gstat, (const double*)img_sums);
     FD_CHECK_LAUNCH("fd_groupnorm_bwd (apply)");
@@ -849,5 +1005,185 @@ extern "C" int32_t fd_se_scale_nhwc(const float* x, int32_t x_cs, int32_t x_co, 
     hipLaunchKernelGGL(se_scale_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co,
                        (const float*)gate, y, y_cs, y_co, HW, C / 4, total);
     FD_CHECK_LAUNCH("fd_se_scale (scale)");
+    return FD_OK;
+}
+
+
+// ---- squeeze-excitation backward (train step; HisBlock.conv1_2, HISFcos.py:104, modules.py:107-121)
+//   y = x * g,  g = sigmoid(W2 s + b2),  s = silu(h),  h = W1 m + b1,  m = mean_hw(x)
+//   dgate[n][c] = sum_hw dy * x                     (pass 1, row chunks like the forward's pooling)
+//   one workgroup: for every image in order  dz = dgate g (1 - g), ds = W2^T dz, dh = ds silu'(h), dm = W1^T dh  and the
+//   parameter gradients dW2 += dz s^T, db2 += dz, dW1 += dh m^T, db1 += dh   (images added in index order: deterministic)
+//   dx = dy * g + dm / HW                            (pass 3)
+// `fwd_workspace` is the forward call's workspace, untouched since (pooled sums and gates).
+__global__ __launch_bounds__(256) void se_dgate_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ dy,
+                                                        int dy_cs, int dy_co, int HW, int C, int nchunk, int QW, double* __restrict__ part) {
+    __shared__ double s_sum[256 * 4];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int rows_per = (HW + nchunk - 1) / nchunk;
+    const int r_begin = chunk * rows_per, r_end = min(HW, r_begin + rows_per);
+    const int C4 = C >> 2, RT = 256 / QW, CW = 4 * QW;
+    const int tid = threadIdx.x, ql = tid % QW, rt = tid / QW;
+    const int q = blockIdx.z * QW + ql;
+    double su[4] = {0, 0, 0, 0};
+    if (q < C4) {
+        const float* bx = x + (long)n * HW * x_cs + x_co + 4 * q;
+        const float* bg = dy + (long)n * HW * dy_cs + dy_co + 4 * q;
+        for (int r = r_begin + rt; r < r_end; r += RT) {
+            const float4 v = *reinterpret_cast<const float4*>(bx + (long)r * x_cs);
+            const float4 g = *reinterpret_cast<const float4*>(bg + (long)r * dy_cs);
+            su[0] += (double)v.x * g.x; su[1] += (double)v.y * g.y; su[2] += (double)v.z * g.z; su[3] += (double)v.w * g.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_sum[rt * CW + 4 * ql + e] = su[e];
+    __syncthreads();
+    for (int cl = tid; cl < CW; cl += 256) {
+        const int c = blockIdx.z * CW + cl;
+        if (c >= C) continue;
+        double a = 0;
+        for (int r = 0; r < RT; ++r) a += s_sum[r * CW + cl];
+        part[((long)n * SE_MAXCHUNK + chunk) * C + c] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void se_bwd_fc_kernel(const double* __restrict__ fpart, const float* __restrict__ gate,
+                                                         const double* __restrict__ dpart, int nchunk, int N, int HW, int C, int Cr,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         float* __restrict__ dmean, float* __restrict__ dw1, float* __restrict__ db1,
+                                                         float* __restrict__ dw2, float* __restrict__ db2) {
+    __shared__ float s_m[SE_MAXC], s_dz[SE_MAXC];
+    __shared__ float s_h[SE_MAXCR], s_s[SE_MAXCR], s_dh[SE_MAXCR];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < C * Cr; i += 256) { dw1[i] = 0.f; dw2[i] = 0.f; }
+    for (int i = tid; i < Cr; i += 256) db1[i] = 0.f;
+    for (int i = tid; i < C; i += 256) db2[i] = 0.f;
+    __syncthreads();
+    for (int n = 0; n < N; ++n) {
+        for (int c = tid; c < C; c += 256) {
+            double a = 0, d = 0;
+            for (int k = 0; k < nchunk; ++k) {
+                a += fpart[((long)n * SE_MAXCHUNK + k) * C + c];
+                d += dpart[((long)n * SE_MAXCHUNK + k) * C + c];
+            }
+            s_m[c] = (float)(a / (double)HW);
+            const float g = gate[(long)n * C + c];
+            const float dz = (float)d * g * (1.f - g);
+            s_dz[c] = dz;
+            db2[c] += dz;
+        }
+        __syncthreads();
+        for (int j = wv; j < Cr; j += 4) {       // h = W1 m + b1 (same lane split and shuffle tree as the forward)
+            float a = 0.f;
+            const float* wr = w1 + (long)j * C;
+            for (int c = lane; c < C; c += 64) a = fmaf(wr[c], s_m[c], a);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0) { const float h = a + (b1 ? b1[j] : 0.f); s_h[j] = h; s_s[j] = fd_act(h, FD_ACT_SILU, 0.f); }
+        }
+        __syncthreads();
+        for (int j = wv; j < Cr; j += 4) {       // ds[j] = sum_c W2[c][j] dz[c];  dh = ds * silu'(h)
+            float a = 0.f;
+            for (int c = lane; c < C; c += 64) a = fmaf(w2[(long)c * Cr + j], s_dz[c], a);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0) {
+                const float h = s_h[j], sg = fd_sigmoid(h);
+                const float dh = a * (sg * (1.f + h * (1.f - sg)));
+                s_dh[j] = dh;
+                db1[j] += dh;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {     // dm[c] = sum_j W1[j][c] dh[j]
+            float a = 0.f;
+            for (int j = 0; j < Cr; ++j) a = fmaf(w1[(long)j * C + c], s_dh[j], a);
+            dmean[(long)n * C + c] = a;
+        }
+        for (int i = tid; i < C * Cr; i += 256) {
+            const int c2 = i / Cr, j2 = i - c2 * Cr;     // dW2[c][j] += dz[c] s[j]
+            dw2[i] += s_dz[c2] * s_s[j2];
+            const int j1 = i / C, c1 = i - j1 * C;       // dW1[j][c] += dh[j] m[c]
+            dw1[i] += s_dh[j1] * s_m[c1];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int dy_co, const float* __restrict__ gate,
+                                                            const float* __restrict__ dmean, float* __restrict__ dx, int dx_cs, int dx_co,
+                                                            int HW, int C4, float inv_hw, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const long m = i / C4;
+        const long n = m / HW;
+        const float4 v = *reinterpret_cast<const float4*>(dy + m * dy_cs + dy_co + 4 * q);
+        const float4 g = *reinterpret_cast<const float4*>(gate + n * C4 * 4 + 4 * q);
+        const float4 d = *reinterpret_cast<const float4*>(dmean + n * C4 * 4 + 4 * q);
+        *reinterpret_cast<float4*>(dx + m * dx_cs + dx_co + 4 * q) =
+            make_float4(fmaf(d.x, inv_hw, v.x * g.x), fmaf(d.y, inv_hw, v.y * g.y), fmaf(d.z, inv_hw, v.z * g.z), fmaf(d.w, inv_hw, v.w * g.w));
+    }
+}
+
+extern "C" int64_t fd_se_bwd_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
+    if (N < 1 || HW < 1 || C < 1) return -1;
+    return (int64_t)N * SE_MAXCHUNK * C * (int64_t)sizeof(double) + (int64_t)N * C * (int64_t)sizeof(float);
+}
+
+extern "C" int32_t fd_se_scale_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs, int32_t dy_co,
+                                        const float* w1, const float* b1, const float* w2, const float* b2, float* dx, int32_t dx_cs,
+                                        int32_t dx_co, float* dw1, float* db1, float* dw2, float* db2, int32_t N, int32_t HW, int32_t C,
+                                        int32_t Cr, const void* fwd_workspace, void* workspace, fd_stream_t stream) {
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(dy, dy_cs, dy_co, C) && view_ok(dx, dx_cs, dx_co, C) && w1 && w2 && dw1 && db1 && dw2 &&
+                   db2 && fwd_workspace && workspace,
+               FD_E_INVAL, "fd_se_scale_bwd: bad pointer / channel view (C=%d)", C);
+    FD_REQUIRE(N >= 1 && N <= 65535 && HW >= 1 && Cr >= 1 && Cr <= SE_MAXCR && C <= SE_MAXC, FD_E_UNSUPPORTED,
+               "fd_se_scale_bwd: C=%d Cr=%d unsupported", C, Cr);
+    FD_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)fwd_workspace & 15) == 0, FD_E_INVAL, "fd_se_scale_bwd: workspace not 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const double* fpart = (const double*)fwd_workspace;
+    const float* gate = (const float*)((const char*)fwd_workspace + (size_t)N * SE_MAXCHUNK * C * sizeof(double));
+    double* dpart = (double*)workspace;
+    float* dmean = (float*)((char*)workspace + (size_t)N * SE_MAXCHUNK * C * sizeof(double));
+    const int nchunk = min(SE_MAXCHUNK, (HW + 63) / 64);
+    int QW = 1;
+    while (QW < 64 && QW < C / 4) QW <<= 1;
+    hipLaunchKernelGGL(se_dgate_kernel, dim3(nchunk, N, (C / 4 + QW - 1) / QW), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, HW, C, nchunk,
+                       QW, dpart);
+    FD_CHECK_LAUNCH("fd_se_scale_bwd (dgate)");
+    hipLaunchKernelGGL(se_bwd_fc_kernel, dim3(1), dim3(256), 0, st, fpart, gate, (const double*)dpart, nchunk, N, HW, C, Cr, w1, b1, w2, b2,
+                       dmean, dw1, db1, dw2, db2);
+    FD_CHECK_LAUNCH("fd_se_scale_bwd (fc)");
+    const long total = (long)N * HW * (C / 4);
+    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dy, dy_cs, dy_co, gate, (const float*)dmean, dx, dx_cs,
+                       dx_co, HW, C / 4, 1.0f / (float)HW, total);
+    FD_CHECK_LAUNCH("fd_se_scale_bwd (apply)");
+    return FD_OK;
+}
+
+// ---- BatchNorm2d in TRAINING mode on the GroupNorm kernels: statistics per channel over the whole batch are GroupNorm
+// statistics of ONE image of batch*H rows with G = C groups.  This entry point folds the batch statistics the forward left in
+// its workspace into the running statistics the way nn.BatchNorm2d does (momentum update, unbiased variance; HISFcos.py FPN
+// BatchNorms under the reference's model.train(), train.py:151).
+__global__ __launch_bounds__(256) void bn_running_kernel(const double* __restrict__ gstat, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                          int C, double count, float momentum, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = gstat[2 * c], rstd = gstat[2 * c + 1];
+    double var = 1.0 / (rstd * rstd) - (double)eps;          // biased batch variance the forward normalised with
+    if (var < 0) var = 0;
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
+    rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
+}
+
+extern "C" int32_t fd_batchnorm_update_running(const void* gn_workspace, int64_t rows, int32_t C, float momentum, float eps,
+                                               float* running_mean, float* running_var, fd_stream_t stream) {
+    FD_REQUIRE(gn_workspace && running_mean && running_var && rows >= 1 && C >= 1, FD_E_INVAL, "fd_batchnorm_update_running: bad argument");
+    const double* gstat = (const double*)gn_workspace + (long)GN_MAXCHUNK * C * 2;     // imgs = 1, G = C
+    hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gstat, running_mean, running_var, C,
+                       (double)rows, momentum, eps);
+    FD_CHECK_LAUNCH("fd_batchnorm_update_running");
     return FD_OK;
 }

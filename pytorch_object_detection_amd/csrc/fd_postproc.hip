@@ -67,25 +67,28 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     reinterpret_cast<float4*>(a.boxes)[o] = make_float4(cx - l, cy - t, cx + r, cy + b);
 }
 
-// Coalesced form (C % 4 == 0, C <= 256): a wave owns 64 consecutive locations of one image and reads their class logits as
-// ONE flat run of float4 (lane l takes quads l, l + 64, ...: 1 KiB per load instruction when the rows are contiguous,
-// cs == C; 20 loads in flight per lane at C = 80), every lane reduces the four sigmoids of a quad, the per-quad (max, first
-// index) pairs meet in LDS (row stride Q | 1: conflict-free) and each lane finishes one location: first maximal class over
-// the quads in order (torch.max semantics, head.py:62), centre-ness, sqrt, LTRB decode (those loads are issued up front).
-// The one-thread-per-location kernel above walks 80 logits per lane, 320 B apart (64 cache lines per load instruction:
-// 1.8 TB/s); it stays for class counts that are not a multiple of 4.
+// Coalesced form (C % 4 == 0, C <= 256).  The one-thread-per-location kernel above is bound twice over: its loads touch 64
+// cache lines per instruction (lanes 320 B apart), and it evaluates 80 sigmoids (expf + IEEE divide) per location --
+// 10.9 M per 16-image batch, more VALU time than the 50 MB take to stream.  Here a wave owns DEC_LPW consecutive locations:
+//   1. their class logits are copied global -> LDS as ONE flat run of float4 (lane l takes quads l, l + 64, ...: 1 KiB per
+//      load instruction when rows are contiguous, all loads issued before the first LDS write);
+//   2. one lane per location scans its row in LDS: L = max logit (compare-only), then sigmoid only for the classes whose
+//      computed sigmoid could tie with or exceed the computed sigmoid(L).  sigmoid is monotonic and fd_sigmoid good to a few
+//      ulp, so those are the logits within ~1e-6 (1 + e^L) of L: normally just the maximum itself (1 sigmoid per location
+//      instead of C); equal or nearly equal logits, or a saturating L, widen the set -- up to every class -- and the first
+//      maximal SIGMOID value wins exactly as in the plain kernel (torch.max semantics, head.py:61-62).
 #define DEC_MAXQ 64
+#define DEC_LPW 32
 __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dec_smem[];
-    const int Q = a.C >> 2, QP = Q | 1;
+    const int Q = a.C >> 2, QP = Q | 1;             // row stride in float4 (odd: conflict-free ds_read_b128 across lanes)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float* s_val = reinterpret_cast<float*>(dec_smem) + wv * 64 * QP;
-    int* s_idx = reinterpret_cast<int*>(dec_smem) + (4 + wv) * 64 * QP;
+    float4* rows = reinterpret_cast<float4*>(dec_smem) + wv * DEC_LPW * QP;
     const int n = blockIdx.y;
-    const int loc0 = (blockIdx.x * 4 + wv) * 64;
-    if (loc0 >= a.L) return;                       // whole wave out of range (no workgroup barrier below)
-    const int nloc = min(64, a.L - loc0);
-    // this lane's own location: centre-ness / regression loads issued before the class sweep
+    const int loc0 = (blockIdx.x * 4 + wv) * DEC_LPW;
+    if (loc0 >= a.L) return;                        // whole wave out of range (no workgroup barrier below)
+    const int nloc = min(DEC_LPW, a.L - loc0);
+    // this lane's own location (lanes >= nloc shadow the last one and store nothing): centre-ness / regression loads first
     const int myloc = loc0 + min(lane, nloc - 1);
     int ms = 0;
 #pragma unroll
@@ -99,38 +102,28 @@ __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
     const float rl = rp[0], rt = rp[1], rr = rp[2], rb = rp[3];
 
     const int items = nloc * Q;
-    // DEC_U loads are issued back to back before the first sigmoid (a plain loop waits for every load in turn: latency-bound)
     constexpr int DEC_U = 10;
     for (int i0 = lane; i0 < items; i0 += 64 * DEC_U) {
         float4 v[DEC_U];
-        int slot[DEC_U], cbase[DEC_U];
 #pragma unroll
-        for (int u = 0; u < DEC_U; ++u) {
-            const int i = i0 + 64 * u;
-            slot[u] = -1;
-            if (i < items) {
-                const int lo = i / Q, q = i - lo * Q;
-                const int loc = loc0 + lo;
-                int s = 0;
+        for (int u = 0; u < DEC_U; ++u) {             // (index clamped, store predicated: keeps v[] in registers)
+            const int i = min(i0 + 64 * u, items - 1);
+            const int lo = i / Q, q = i - lo * Q;
+            const int loc = loc0 + lo;
+            int s = 0;
 #pragma unroll
-                for (int t = 1; t < FD_MAX_SEG; ++t)
-                    if (t < a.segs.nseg && loc >= a.loc_start[t]) s = t;
-                const long m = (long)a.segs.m_start[s] + (long)n * (a.segs.H[s] * a.segs.W[s]) + (loc - a.loc_start[s]);
-                v[u] = *reinterpret_cast<const float4*>(a.cls + m * a.cls_cs + a.cls_co + 4 * q);
-                slot[u] = lo * QP + q;
-                cbase[u] = 4 * q;
-            }
+            for (int t = 1; t < FD_MAX_SEG; ++t)
+                if (t < a.segs.nseg && loc >= a.loc_start[t]) s = t;
+            const long m = (long)a.segs.m_start[s] + (long)n * (a.segs.H[s] * a.segs.W[s]) + (loc - a.loc_start[s]);
+            v[u] = *reinterpret_cast<const float4*>(a.cls + m * a.cls_cs + a.cls_co + 4 * q);
         }
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
-            if (slot[u] < 0) continue;
-            const float s0 = fd_sigmoid(v[u].x), s1 = fd_sigmoid(v[u].y), s2 = fd_sigmoid(v[u].z), s3 = fd_sigmoid(v[u].w);
-            float best = s0; int bi = 0;
-            if (s1 > best) { best = s1; bi = 1; }
-            if (s2 > best) { best = s2; bi = 2; }
-            if (s3 > best) { best = s3; bi = 3; }
-            s_val[slot[u]] = best;
-            s_idx[slot[u]] = cbase[u] + bi;
+            const int i = i0 + 64 * u;
+            if (i < items) {
+                const int lo = i / Q, q = i - lo * Q;
+                rows[lo * QP + q] = v[u];
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -138,12 +131,39 @@ __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane < nloc) {
+        const float4* row = rows + lane * QP;
+        float L = -INFINITY;
+        int li = 0;
+        for (int q = 0; q < Q; ++q) {                 // max logit and its first index (compare-only)
+            const float4 v = row[q];
+            if (v.x > L) { L = v.x; li = 4 * q; }
+            if (v.y > L) { L = v.y; li = 4 * q + 1; }
+            if (v.z > L) { L = v.z; li = 4 * q + 2; }
+            if (v.w > L) { L = v.w; li = 4 * q + 3; }
+        }
+        // classes whose COMPUTED sigmoid could reach the computed sigmoid(L): fd_sigmoid is good to a few ulp, so only logits
+        // within ~8 ulp(s) / s'(L) = 9.5e-7 (1 + e^L) of L (doubled below) -- one candidate unless logits are (nearly) equal
+        const float eL = expf(L);
+        const float cut = L - 2.0e-6f * (1.0f + eL);  // L = +inf / NaN-free rows only; an inf window (L > 88) takes every class
+        int ncand = 0;
+        for (int q = 0; q < Q; ++q) {
+            const float4 v = row[q];
+            ncand += (v.x >= cut) + (v.y >= cut) + (v.z >= cut) + (v.w >= cut);
+        }
         float best = -1.0f;
         int besti = 0;
-        for (int q = 0; q < Q; ++q) {
-            const float v = s_val[lane * QP + q];
-            if (v > best) { best = v; besti = s_idx[lane * QP + q]; }
-        }
+        if (ncand == 1) {
+            best = fd_sigmoid(L);
+            besti = li;
+        } else if (ncand > 1) {                       // rare: evaluate every candidate, first maximal sigmoid wins (head.py:62)
+            for (int q = 0; q < Q; ++q) {
+                const float4 v = row[q];
+                if (v.x >= cut) { const float sv = fd_sigmoid(v.x); if (sv > best) { best = sv; besti = 4 * q; } }
+                if (v.y >= cut) { const float sv = fd_sigmoid(v.y); if (sv > best) { best = sv; besti = 4 * q + 1; } }
+                if (v.z >= cut) { const float sv = fd_sigmoid(v.z); if (sv > best) { best = sv; besti = 4 * q + 2; } }
+                if (v.w >= cut) { const float sv = fd_sigmoid(v.w); if (sv > best) { best = sv; besti = 4 * q + 3; } }
+            }
+        }                                             // ncand == 0: a row of NaNs -> best = -1, class 1, as the plain kernel
         const float score = sqrtf(best * fd_sigmoid(cnt_logit));
         const int py = mypix / mW, px = mypix - py * mW;
         const int st = a.stride[ms];
@@ -182,10 +202,10 @@ extern "C" int32_t fd_fcos_decode(const float* cls, int32_t cls_cs, int32_t cls_
     a.scores = scores; a.classes = classes; a.boxes = boxes;
     if (num_classes % 4 == 0 && num_classes <= 4 * DEC_MAXQ && cls_cs % 4 == 0 && cls_co % 4 == 0 && ((uintptr_t)cls & 15) == 0) {
         const int QP = (num_classes / 4) | 1;
-        const int lds = 2 * 4 * 64 * QP * 4;       // (value, index) x 4 waves x 64 locations x QP
+        const int lds = 4 * DEC_LPW * QP * 16;       // 4 waves x DEC_LPW locations x QP float4
         static std::atomic<unsigned> attr_mask{0};
-        fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(decode_coalesced_kernel), 2 * 4 * 64 * 65 * 4);
-        dim3 grid((L + 255) / 256, segs->batch);
+        fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(decode_coalesced_kernel), 4 * DEC_LPW * 65 * 16);
+        dim3 grid((L + 4 * DEC_LPW - 1) / (4 * DEC_LPW), segs->batch);
         hipLaunchKernelGGL(decode_coalesced_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
     } else {
         dim3 grid((L + 255) / 256, segs->batch);

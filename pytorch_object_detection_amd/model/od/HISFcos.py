@@ -35,8 +35,40 @@ class HisBlock(nn.Module):
         self.bn1, self.bn2, self.bn3 = nn.BatchNorm2d(half), nn.BatchNorm2d(half), nn.BatchNorm2d(half)
         self.bn4 = nn.BatchNorm2d(feature)
 
+    def train_forward_rows(self, x: torch.Tensor, segs: Segs):
+        """HisBlock on single-level NHWC rows with EVERY op on the HIP kernels, forward and backward: the 1x1 / 3x3 / dilated
+        convs (MFMA), the depthwise conv, SE (pool, gate, scale), SiLU / ReLU, and each BatchNorm in whichever mode it is in
+        (frozen: folded into the conv epilogue; training: batch statistics on the GroupNorm kernels).  None = not covered."""
+        B, HW = segs.batch, segs.H[0] * segs.W[0]
+        if not T._se_ok(self.conv1_2, x):
+            return None
+        if (T.bn_is_frozen(self.bn1) and T._dense_ok(self.conv1, x) and T._dense_ok(self.conv2, x) and self.conv1.bias is not None
+                and self.conv2.bias is not None and not T._STOCK):
+            # conv1 (+ frozen bn1) and conv2 read the same map: one 2*half-wide launch forward, one data / weight gradient backward
+            sc, sf = T._bn_fold(self.bn1)
+            half = self.conv1.out_channels
+            both = T._ConvRows.apply(x, torch.cat((self.conv1.weight, self.conv2.weight), 0), torch.cat((sc, torch.ones_like(sc))),
+                                     torch.cat((self.conv1.bias * sc + sf, self.conv2.bias)), None, segs, 1, 0, 1, ACT_NONE)
+            x1, x2 = T.act_rows(both[:, :half], ACT_SILU), both[:, half:]
+        else:
+            x1 = T.conv_norm_act_rows(self.conv1, self.bn1, x, segs, ACT_SILU)
+            x2 = T.conv_norm_act_rows(self.conv2, None, x, segs)
+        u = T.conv_norm_act_rows(self.conv1_1, self.bn2, x1, segs, ACT_RELU) if x1 is not None else None
+        if x1 is None or x2 is None or u is None:
+            return None
+        left = torch.cat((u, T.se_rows(self.conv1_2, x1, B, HW)), 1)
+        y = T.conv_norm_act_rows(self.conv3, self.bn3, left, segs, ACT_RELU)
+        if y is None:
+            return None
+        return T.conv_norm_act_rows(self.conv4, self.bn4, torch.cat((y, x2), 1), segs, ACT_SILU)
+
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
         """Training-time autograd forward (dense convs on the HIP kernels via train_ops); inference runs engine._his_block."""
+        if x.is_cuda and T._f32(x):
+            B, _, H, W = x.shape
+            out = self.train_forward_rows(T.to_rows(x), Segs.make(B, [(H, W)]))
+            if out is not None:
+                return T.from_rows(out, B, H, W)
         if T.covered(self.conv1, self.bn1, x) and T.covered(self.conv2, None, x) and self.conv1.bias is not None:
             # conv1 (+ frozen bn1) and conv2 read the same map: one 2*half-wide launch forward, one data gradient (no gradient
             # add for x) and one weight gradient backward; the halves are channel views of its output
@@ -70,7 +102,42 @@ class HalfInvertedStageFPN(PlannedModule):
         # named gn* but BatchNorm2d, as in the reference (HISFcos.py:137-142); gn3 exists and is never used
         self.gn1, self.gn2, self.gn3 = nn.BatchNorm2d(feature), nn.BatchNorm2d(feature), nn.BatchNorm2d(feature)
 
+    def train_forward_rows(self, x):
+        """The whole FPN on NHWC rows, every op a HIP launch forward and backward (laterals, the seven HisBlocks, nearest-x2
+        upsample + add, 2x2 max-pool + add).  None when some piece is not covered (odd widths, exotic BatchNorm settings)."""
+        c3, c4, c5 = x
+        if T._STOCK or not all(t.is_cuda and T._f32(t) for t in x):
+            return None
+        B = c5.shape[0]
+        hw = [(c3.shape[2], c3.shape[3]), (c4.shape[2], c4.shape[3]), (c5.shape[2], c5.shape[3])]
+        hw += [(hw[2][0] // 2, hw[2][1] // 2), (hw[2][0] // 4, hw[2][1] // 4)]
+        if hw[0] != (2 * hw[1][0], 2 * hw[1][1]) or hw[1] != (2 * hw[2][0], 2 * hw[2][1]) or hw[4][0] < 1 or hw[4][1] < 1:
+            return None
+        sg = [Segs.make(B, [h]) for h in hw]
+        pool = lambda t, lv, add=None: T._PoolAddRows.apply(t, add, (B, hw[lv][0], hw[lv][1], 2, 2, 0))  # noqa: E731
+        a = T.conv_norm_act_rows(self.tf1, self.gn1, T.to_rows(c5), sg[2], ACT_RELU)
+        l4 = T.conv_norm_act_rows(self.tf2, self.gn2, T.to_rows(c4), sg[1], ACT_RELU) if a is not None else None
+        l3 = T.conv_norm_act_rows(self.tf3, self.gn2, T.to_rows(c3), sg[0], ACT_RELU) if l4 is not None else None    # gn2 twice, as the reference
+        if l3 is None:
+            return None
+        x4 = pool(a, 2)
+        x5 = pool(x4, 3)
+        blk = lambda i, t, lv: getattr(self, f"HisBlock{i}").train_forward_rows(t, sg[lv])  # noqa: E731
+        t3 = blk(1, a, 2)
+        t4 = blk(2, T._UpAddRows.apply(t3, l4, (B, hw[2][0], hw[2][1])), 1) if t3 is not None else None
+        p3 = blk(3, T._UpAddRows.apply(t4, l3, (B, hw[1][0], hw[1][1])), 0) if t4 is not None else None
+        p4 = blk(4, pool(p3, 0, t4), 1) if p3 is not None else None
+        p5 = blk(5, pool(p4, 1, t3), 2) if p4 is not None else None
+        p6 = blk(6, pool(p5, 2, x4), 3) if p5 is not None else None
+        p7 = blk(7, pool(p6, 3, x5), 4) if p6 is not None else None
+        if p7 is None:
+            return None
+        return tuple(T.from_rows(t, B, h, w) for t, (h, w) in zip((p3, p4, p5, p6, p7), hw))
+
     def train_forward(self, x):
+        out = self.train_forward_rows(x)
+        if out is not None:
+            return out
         c3, c4, c5 = x
         up = lambda t: F.interpolate(t, scale_factor=2.0, mode="nearest")  # noqa: E731
         down = lambda t: F.max_pool2d(t, 2, 2)  # noqa: E731

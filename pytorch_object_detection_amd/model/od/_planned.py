@@ -150,6 +150,9 @@ class PlannedModule(nn.Module):
         follows nn.Module.train() exactly as in the reference: batch statistics, running-stat updates, SyncBN under DDP,
         affine parameters frozen by the constructor.  `model.freeze_all_bn = True` pins those too (every BN folded into the
         HIP conv epilogues: the fastest training step, for fine-tuning from a converged checkpoint)."""
+        if mode != self.training:
+            self._plans.clear()      # a training step rewrites weights and running statistics in place (HIP launches do not bump
+                                     # tensor version counters): plans are rebuilt on the next eval forward
         super().train(mode)
         if mode and getattr(self, "backbone_freeze", False):
             root = self if self.freeze_all_bn else getattr(self, "backbone", None)

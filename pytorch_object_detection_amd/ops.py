@@ -474,6 +474,49 @@ def se_scale(x: Rows, w1, b1, w2, b2, y: Rows, N: int, HW: int, Cr: int, ws: tor
                                       x.C, Cr, ws.data_ptr(), _stream()), "fd_se_scale_nhwc")
 
 
+def se_scale_bwd(x: Rows, dy: Rows, w1, b1, w2, b2, dx: Rows, N: int, HW: int, Cr: int, fwd_ws: torch.Tensor):
+    """Backward of se_scale: writes dx, returns (dw1 [Cr,C], db1 [Cr], dw2 [C,Cr], db2 [C])."""
+    dev = x.buf.device
+    Cc = x.C
+    n = _lib.lib().fd_se_bwd_workspace_bytes(N, HW, Cc)
+    ws = torch.empty((n + 7) // 8, dtype=torch.float64, device=dev)
+    dw1 = torch.empty(Cr, Cc, dtype=torch.float32, device=dev)
+    db1 = torch.empty(Cr, dtype=torch.float32, device=dev)
+    dw2 = torch.empty(Cc, Cr, dtype=torch.float32, device=dev)
+    db2 = torch.empty(Cc, dtype=torch.float32, device=dev)
+    check(_lib.lib().fd_se_scale_bwd_nhwc(x.ptr, x.cs, x.co, dy.ptr, dy.cs, dy.co, w1.data_ptr(), b1.data_ptr() if b1 is not None else None,
+                                          w2.data_ptr(), b2.data_ptr() if b2 is not None else None, dx.ptr, dx.cs, dx.co, dw1.data_ptr(),
+                                          db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), N, HW, Cc, Cr, fwd_ws.data_ptr(), ws.data_ptr(),
+                                          _stream()), "fd_se_scale_bwd_nhwc")
+    return dw1, db1, dw2, db2
+
+
+def act(x: Rows, y: Rows, act_id: int, param: float = 0.0) -> None:
+    check(_lib.lib().fd_act_nhwc(x.ptr, x.cs, x.co, y.ptr, y.cs, y.co, x.rows, x.C, act_id, float(param), _stream()), "fd_act_nhwc")
+
+
+def act_bwd(x: Rows, dy: Rows, dx: Rows, act_id: int, param: float = 0.0) -> None:
+    check(_lib.lib().fd_act_bwd_nhwc(x.ptr, x.cs, x.co, dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, x.rows, x.C, act_id, float(param),
+                                     _stream()), "fd_act_bwd_nhwc")
+
+
+def maxpool_bwd(x: Rows, dy: Rows, dx: Rows, N: int, H: int, W: int, k: int, s: int, pad: int) -> None:
+    check(_lib.lib().fd_maxpool_bwd_nhwc(x.ptr, x.cs, x.co, dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, N, H, W, x.C, k, s, pad,
+                                         _stream()), "fd_maxpool_bwd_nhwc")
+
+
+def upsample2x_bwd(dy: Rows, dx: Rows, N: int, H: int, W: int) -> None:
+    """dx [N,H,W] = 2x2 block sums of dy [N,2H,2W]."""
+    check(_lib.lib().fd_upsample2x_bwd_nhwc(dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, N, H, W, dx.C, _stream()), "fd_upsample2x_bwd_nhwc")
+
+
+def batchnorm_update_running(gn_ws: torch.Tensor, rows: int, Cc: int, momentum: float, eps: float, running_mean: torch.Tensor,
+                             running_var: torch.Tensor) -> None:
+    _need_gpu(gn_ws, running_mean, running_var)
+    check(_lib.lib().fd_batchnorm_update_running(gn_ws.data_ptr(), rows, Cc, float(momentum), float(eps), running_mean.data_ptr(),
+                                                 running_var.data_ptr(), _stream()), "fd_batchnorm_update_running")
+
+
 # ---------------------------------------------------------------------------------------------------- post-process
 def fcos_decode(cls: Rows, cnt: Rows, reg: Rows, segs: Segs, strides: Sequence[int]):
     """-> scores [N,L] f32, classes [N,L] i32, boxes [N,L,4] f32 (levels concatenated per image)."""

@@ -26,10 +26,10 @@ from ._lib import FdError
 
 
 class TwoLanePipeline:
-    def __init__(self, model, post: Callable, mark: str = "head.tower3x3"):
+    def __init__(self, model, post: Callable, mark: str = "head.tower3x3", pair_tuned: bool = False):
         """model: a detector with plan_for(x, slot=); post(out, x, tag) -> result (enqueued right after the model on the lane's
         stream; `tag` is whatever submit() was given for that step)."""
-        self.model, self.post, self.mark = model, post, mark
+        self.model, self.post, self.mark, self.pair_tuned = model, post, mark, pair_tuned
         self.streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         self.plans: List[Optional[object]] = [None, None]
         self.cut = None
@@ -38,9 +38,10 @@ class TwoLanePipeline:
         self.last_result = None
 
     def _setup(self, x: torch.Tensor) -> None:
-        # own plan instances (slots 1, 2; slot 0 stays the plain single-stream plan), block tiles from the "pair|" entries of
-        # the tuning table: chosen for throughput beside the other lane's kernels, not for the latency of a lone launch
-        self.model._plan_pair_tuned = True
+        # own plan instances (slots 1, 2; slot 0 stays the plain single-stream plan).  pair_tuned: take the block tiles from
+        # the "pair|" entries of the tuning table (timed beside a twin launch on a second stream, ops.autotune_conv(pair=True));
+        # measured on MI355X they do not beat the tiles timed alone (881 vs 900 img/s), so the default is off
+        self.model._plan_pair_tuned = self.pair_tuned
         try:
             self.plans = [self.model.plan_for(x, slot=k) for k in (1, 2)]
         finally:

@@ -73,6 +73,19 @@ def _r(t: torch.Tensor) -> Rows:
     return Rows(t)
 
 
+def _rv(t: torch.Tensor) -> Optional[Rows]:
+    """Rows of a 2-D tensor that may be a channel-slice VIEW of a contiguous rows buffer (x[:, a:b]); None if it is neither."""
+    if t.is_contiguous():
+        return Rows(t)
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        cs = t.stride(0)
+        co = t.storage_offset() % cs
+        if co + t.shape[1] <= cs and t.storage_offset() - co + t.shape[0] * cs <= t.untyped_storage().nbytes() // 4:
+            base = t.as_strided((t.shape[0], cs), (cs, 1), t.storage_offset() - co)
+            return Rows(base, co, t.shape[1])
+    return None
+
+
 def _pad_of(m: nn.Conv2d) -> int:
     if isinstance(m.padding, str):
         return m.dilation[0] * (m.kernel_size[0] - 1) // 2
@@ -249,6 +262,8 @@ class _ConvRows(torch.autograd.Function):
     @staticmethod
     @_fwd32
     def forward(ctx, x, weight, scale, shift, residual, segs, stride, pad, dil, act):
+        if act not in (ACT_NONE, ACT_RELU):
+            raise FdError("_ConvRows differentiates ACT_NONE / ACT_RELU epilogues only (use act_rows for SiLU: it keeps the pre-activation)")
         x = x.contiguous()
         Cout, _, k, _ = weight.shape
         so = ops.conv_out_segs(segs, k, stride, pad, dil)
@@ -267,7 +282,7 @@ class _ConvRows(torch.autograd.Function):
         segs, so, stride, pad, dil, act = ctx.geom
         g = gy.contiguous()
         if act == ACT_RELU:
-            g = torch.ops.aten.threshold_backward(g, y, 0.0)
+            g = relu_mask(g, y)
         Cin = x.shape[1]
         Cout, _, k, _ = weight.shape
         gx = gw = gshift = gres = None
@@ -364,7 +379,7 @@ class _BottleneckRows(torch.autograd.Function):
         segs, so, stride = ctx.geom
         need_x = ctx.needs_input_grad[0]
         P, Cin, C4 = w1.shape[0], w1.shape[1], w3.shape[0]
-        g = torch.ops.aten.threshold_backward(gout.contiguous(), out, 0.0)          # the one elementwise pass of the block
+        g = relu_mask(gout.contiguous(), out)                                        # the one elementwise pass of the block
         gw1 = gw2 = gw3 = gwd = gx = None
         wg = lambda xx, gg, sg, Ci, Co, k, st, pad, sc: ops.conv_wgrad(_r(xx), _r(gg), sg, Cin=Ci, Cout=Co, k=k, stride=st,  # noqa: E731
                                                                      pad=pad, dil=1, scale=sc, oihw=True)
@@ -381,7 +396,7 @@ class _BottleneckRows(torch.autograd.Function):
             B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
             g1 = torch.ops.aten.convolution_backward(from_rows(g2, B, Ho, Wo), from_rows(y1, B, H, W), w2.detach() * s2.view(-1, 1, 1, 1),
                                                      None, [stride, stride], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
-            g1 = torch.ops.aten.threshold_backward(to_rows(g1), y1, 0.0)
+            g1 = relu_mask(to_rows(g1).contiguous(), y1)
         if ctx.needs_input_grad[1]:
             gw1 = wg(x, g1, segs, Cin, P, 1, 1, 0, s1)
         if wd is not None and ctx.needs_input_grad[4]:
@@ -434,6 +449,8 @@ class _DwRows(torch.autograd.Function):
     @staticmethod
     @_fwd32
     def forward(ctx, x, weight, scale, shift, segs, act):
+        if act not in (ACT_NONE, ACT_RELU):
+            raise FdError("_DwRows differentiates ACT_NONE / ACT_RELU epilogues only (use act_rows for SiLU)")
         x = x.contiguous()
         y = torch.empty_like(x)
         ops.dwconv3x3(_r(x), ops.pack_dw_weight(weight), _r(y), segs, scale, shift, act)
@@ -448,7 +465,7 @@ class _DwRows(torch.autograd.Function):
         segs, act = ctx.geom
         g = gy.contiguous()
         if act == ACT_RELU:
-            g = torch.ops.aten.threshold_backward(g, y, 0.0)
+            g = relu_mask(g, y)
         Cc = x.shape[1]
         gx = gw = None
         if ctx.needs_input_grad[0]:
@@ -495,6 +512,193 @@ class _GroupNormRows(torch.autograd.Function):
 def groupnorm_rows(gn: nn.GroupNorm, x: torch.Tensor, segs: Segs, act=ACT_NONE) -> torch.Tensor:
     """act(GroupNorm(x)) per (level, image) on a rows buffer: two HIP launches forward, three backward."""
     return _GroupNormRows.apply(x, gn.weight, gn.bias, segs, gn.num_groups, gn.eps, _act_id(act))
+
+
+# ------------------------------------------------------------------- elementwise / pooling / SE / BatchNorm(train) nodes
+def relu_mask(g: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """g * [y > 0] on contiguous rows (the ReLU backward from the saved OUTPUT), one HIP launch."""
+    out = torch.empty_like(g)
+    ops.act_bwd(_r(y), _r(g), _r(out), ACT_RELU)
+    return out
+
+
+class _ActRows(torch.autograd.Function):
+    """y = act(x) on rows with the INPUT saved: SiLU after a BatchNorm (HISFcos.py:100,112) needs the pre-activation."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, act):
+        xr = _rv(x)                           # (a channel slice of a wider rows buffer is read in place)
+        if xr is None:
+            x = x.contiguous()
+            xr = _r(x)
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        ops.act(xr, _r(y), act)
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, gy):
+        x, = ctx.saved_tensors
+        gx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        ops.act_bwd(_rv(x), _r(gy.contiguous()), _r(gx), ctx.act)
+        return gx, None
+
+
+def act_rows(x: torch.Tensor, act: int) -> torch.Tensor:
+    return x if act == ACT_NONE else _ActRows.apply(x, act)
+
+
+class _PoolAddRows(torch.autograd.Function):
+    """y = max_pool2d(x, k, s, pad) (+ add) on single-level rows (FPN down_sample + torch.add, HISFcos.py:131-136,168-177)."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, add, geom):
+        B, H, W, k, s, pad = geom
+        x = x.contiguous()
+        Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        y = torch.empty(B * Ho * Wo, x.shape[1], dtype=torch.float32, device=x.device)
+        ops.maxpool(_r(x), _r(y), B, H, W, k, s, pad, add=_r(add.contiguous()) if add is not None else None)
+        ctx.save_for_backward(x)
+        ctx.geom = geom
+        return y
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, gy):
+        x, = ctx.saved_tensors
+        B, H, W, k, s, pad = ctx.geom
+        g = gy.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            ops.maxpool_bwd(_r(x), _r(g), _r(gx), B, H, W, k, s, pad)
+        return gx, (g if ctx.needs_input_grad[1] else None), None
+
+
+class _UpAddRows(torch.autograd.Function):
+    """y = nearest_upsample_x2(x) + lat on single-level rows (HISFcos.py:155-165)."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, lat, geom):
+        B, H, W = geom                       # geometry of the LOW-resolution input x
+        y = torch.empty_like(lat)
+        ops.upsample2x_add(_r(x.contiguous()), _r(lat.contiguous()), _r(y), B, H, W)
+        ctx.geom = geom
+        return y
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, gy):
+        B, H, W = ctx.geom
+        g = gy.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(B * H * W, g.shape[1], dtype=torch.float32, device=g.device)
+            ops.upsample2x_bwd(_r(g), _r(gx), B, H, W)
+        return gx, (g if ctx.needs_input_grad[1] else None), None
+
+
+class _SERows(torch.autograd.Function):
+    """SEBlock (modules.py:107-121) on rows: y = x * sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2), forward and backward on HIP."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, w1, b1, w2, b2, B, HW):
+        x = x.contiguous()
+        Cc, Cr = x.shape[1], w1.shape[0]
+        y = torch.empty_like(x)
+        ws = ops.se_workspace(B, HW, Cc, x.device)
+        w1f, w2f = w1.detach().reshape(Cr, Cc).contiguous(), w2.detach().reshape(Cc, Cr).contiguous()
+        b1f, b2f = b1.detach().contiguous(), b2.detach().contiguous()
+        ops.se_scale(_r(x), w1f, b1f, w2f, b2f, _r(y), B, HW, Cr, ws)
+        ctx.save_for_backward(x, w1f, b1f, w2f, b2f, ws)
+        ctx.geom = (B, HW, Cr, tuple(w1.shape), tuple(w2.shape))
+        return y
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, gy):
+        x, w1f, b1f, w2f, b2f, ws = ctx.saved_tensors
+        B, HW, Cr, s1, s2 = ctx.geom
+        gx = torch.empty_like(x)
+        dw1, db1, dw2, db2 = ops.se_scale_bwd(_r(x), _r(gy.contiguous()), w1f, b1f, w2f, b2f, _r(gx), B, HW, Cr, ws)
+        return gx, dw1.view(s1), db1, dw2.view(s2), db2, None, None
+
+
+def se_rows(se: nn.Module, x: torch.Tensor, B: int, HW: int) -> torch.Tensor:
+    ex = se.excitation
+    return _SERows.apply(x, ex[0].weight, ex[0].bias, ex[2].weight, ex[2].bias, B, HW)
+
+
+def _se_ok(se: nn.Module, x: torch.Tensor) -> bool:
+    ex = getattr(se, "excitation", None)
+    return (not _STOCK and ex is not None and len(ex) == 4 and isinstance(ex[1], nn.SiLU) and isinstance(ex[3], nn.Sigmoid)
+            and ex[0].bias is not None and ex[2].bias is not None and ex[0].in_channels % 4 == 0 and ex[0].in_channels <= 4096
+            and ex[0].out_channels <= 1024 and _f32(x))
+
+
+class _BatchNormTrainRows(torch.autograd.Function):
+    """nn.BatchNorm2d in TRAINING mode + ReLU / SiLU on rows.  Batch statistics per channel over all rows are GroupNorm
+    statistics of ONE image with G = C groups, so forward / backward are the GroupNorm kernels (fp64 partial sums in fixed
+    order); the running statistics are updated like nn.BatchNorm2d does (momentum, unbiased variance)."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, gamma, beta, rmean, rvar, momentum, eps, act):
+        x = x.contiguous()
+        rows, Cc = x.shape
+        segs = Segs.make(1, [(rows, 1)])
+        y = torch.empty_like(x)
+        ws = ops.groupnorm_workspace(segs, Cc, x.device)
+        gm, bt = gamma.detach().contiguous(), beta.detach().contiguous()
+        ops.groupnorm_act(_r(x), gm, bt, _r(y), segs, Cc, act, ws, eps)
+        if rmean is not None and momentum is not None:
+            ops.batchnorm_update_running(ws, rows, Cc, momentum, eps, rmean, rvar)
+        ctx.save_for_backward(x, gm, bt, ws)
+        ctx.geom = (segs, eps, act)
+        return y
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, gy):
+        x, gm, bt, ws = ctx.saved_tensors
+        segs, eps, act = ctx.geom
+        gx = torch.empty_like(x)
+        dgamma, dbeta = ops.groupnorm_act_bwd(_r(x), _r(gy.contiguous()), gm, bt, _r(gx), segs, x.shape[1], act, ws, eps)
+        return gx, dgamma, dbeta, None, None, None, None, None
+
+
+def _bn_train_ok(bn: nn.Module, x: torch.Tensor) -> bool:
+    Cc = getattr(bn, "num_features", 0)
+    return (not _STOCK and isinstance(bn, nn.BatchNorm2d) and bn.training and bn.affine and bn.track_running_stats
+            and bn.momentum is not None and Cc % 4 == 0 and Cc <= 1024 and 256 % (Cc // 4) == 0 and _f32(x))
+
+
+def batchnorm_train_rows(bn: nn.BatchNorm2d, x: torch.Tensor, act: int = ACT_NONE) -> torch.Tensor:
+    """act(bn(x)) with batch statistics on rows; bn.running_mean / running_var are updated in place (check with _bn_train_ok)."""
+    return _BatchNormTrainRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act)
+
+
+def conv_norm_act_rows(m: nn.Conv2d, bn: Optional[nn.Module], x: torch.Tensor, segs: Segs, act: int = ACT_NONE) -> Optional[torch.Tensor]:
+    """act(bn(m(x))) on single-level rows with every piece on the HIP kernels, whatever mode `bn` is in: a frozen BatchNorm folds
+    into the conv epilogue (ReLU fused, SiLU one extra launch that keeps the pre-activation), a BatchNorm in training mode runs
+    on batch statistics (batchnorm_train_rows).  Returns None when a piece is not covered (the caller falls back)."""
+    dense, dw = _dense_ok(m, x), _dw_ok(m, x)
+    if _STOCK or not (dense or dw):
+        return None
+    conv = conv_rows if dense else (lambda mm, xx, sg, b=None, a=ACT_NONE: dw_rows(mm, xx, sg, b, a))
+    if bn is None or bn_is_frozen(bn):
+        if act in (ACT_NONE, ACT_RELU):
+            return conv(m, x, segs, bn, act)
+        return act_rows(conv(m, x, segs, bn, ACT_NONE), act)
+    if not _bn_train_ok(bn, x) or (dw and m.bias is not None):
+        return None
+    return batchnorm_train_rows(bn, conv(m, x, segs, None, ACT_NONE), act)
 
 
 # ------------------------------------------------------------------------------------ NCHW-shaped conveniences
