@@ -130,7 +130,7 @@ def test_abi_argument_errors_without_gpu():
                             ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, None) < 0
     p = _lib.ConvParams()
     assert lib.fd_conv2d_nhwc_f32(ctypes.byref(p), None) == -1
-    assert lib.fd_groupnorm_workspace_bytes(ctypes.byref(_lib.Segs.make(2, [(8, 8), (4, 4)])), 32) == 2 * 2 * (64 + 1) * 32 * 16   # chunk partials + (mean, rstd)
+    assert lib.fd_groupnorm_workspace_bytes(ctypes.byref(_lib.Segs.make(2, [(8, 8), (4, 4)])), 32) == 2 * 2 * (256 + 1) * 32 * 16   # chunk partials + (mean, rstd)
 
 
 def test_backward_abi_argument_errors_without_gpu():

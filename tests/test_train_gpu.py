@@ -83,6 +83,28 @@ def test_train_step_matches_oracle_autograd():
             continue
         scale = float(g_ref.abs().max()) + 1e-12
         assert float((p.grad.cpu() - g_ref).abs().median()) / scale < 1e-5, name
+    # EVERY trainable parameter (not a sample of eight): a gradient exists on both sides, points the same way, agrees to
+    # rounding in the bulk (median) and to a flipped-ReLU-mask's worth at worst (see the comment above and
+    # test_relu_mask_flips_are_the_only_source_of_large_gradient_deviations)
+    n_par = 0
+    for name, p in model.named_parameters():
+        g_ref = sd[name].grad
+        if not p.requires_grad:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None and g_ref is not None, name
+        a, b = p.grad.cpu().double().flatten(), g_ref.double().flatten()
+        scale = float(b.abs().max()) + 1e-30
+        if scale < 1e-12:                               # (a conv bias whose only consumer is zero: nothing to compare)
+            assert float(a.abs().max()) < 1e-9, name
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        d = (a - b).abs() / scale
+        assert cos > 0.9995, (name, cos)
+        assert float(d.median()) < 2e-5, (name, float(d.median()))
+        assert float(d.max()) < (5e-2 if name.startswith("backbone.") else 2e-2), (name, float(d.max()))
+        n_par += 1
+    assert n_par > 150, n_par
     # layer1 and the stem are frozen (freeze_stages(1), HISFcos.py:67)
     assert model.backbone.extract_feature.layer1[0].conv1.weight.grad is None
     before = model.head.cls_logits.weight.detach().clone()
@@ -319,3 +341,81 @@ def test_default_train_mode_fpn_batchnorm_follows_the_reference():
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
     model.freeze_all_bn = True
     assert not any(m.training for m in model.train().modules() if isinstance(m, torch.nn.BatchNorm2d))
+
+
+def test_relu_mask_flips_are_the_only_source_of_large_gradient_deviations():
+    """The claim behind the loose end-to-end bars above, as a test: through a fused conv + frozen BN + ReLU node the HIP
+    gradients match torch's to 1e-4 of their maximum EVERYWHERE once the upstream gradient is zeroed at the elements whose
+    pre-activation is within 1e-5 of zero (the only elements whose ReLU mask can differ between two fp32 summation orders);
+    with those elements kept, a flipped mask element shows up as an O(1) relative deviation in its k x k neighbourhood."""
+    import torch.nn.functional as F
+    from pytorch_object_detection_amd import train_ops as T
+    from pytorch_object_detection_amd._lib import ACT_RELU
+    torch.manual_seed(8)
+    conv = torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(64).eval()
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.randn(64) * 0.1); bn.running_var.copy_(torch.rand(64) + 0.5)
+        bn.weight.copy_(torch.rand(64) + 0.5); bn.bias.copy_(torch.randn(64) * 0.05)
+    for p in bn.parameters():
+        p.requires_grad = False
+    x = torch.randn(4, 64, 40, 40)
+    z64 = bn.double()(conv.double()(x.double())).detach()                    # fp64 pre-activation
+    conv.float(); bn.float()
+    safe = (z64.abs() >= 1e-5).float()
+    assert float(safe.mean()) < 1.0                                            # the guard really removes something
+    gy = torch.randn(4, 64, 40, 40) * safe
+    xr = x.clone().requires_grad_(True)
+    F.relu(bn(conv(xr))).backward(gy)
+    gw_ref, gx_ref = conv.weight.grad.clone(), xr.grad.clone()
+    conv.zero_grad()
+    conv.to(DEV); bn.to(DEV)
+    xd = x.to(DEV).to(memory_format=torch.channels_last).requires_grad_(True)
+    out = T.conv_bn_act(conv, bn, xd, ACT_RELU)
+    out.backward(gy.to(DEV))
+    for got, ref in ((conv.weight.grad.cpu(), gw_ref), (xd.grad.cpu(), gx_ref)):
+        s = float(ref.abs().max())
+        np.testing.assert_allclose(got.numpy() / s, ref.numpy() / s, atol=1e-4)
+
+
+def test_full_size_batch_gradient_is_the_mean_of_the_per_image_gradients():
+    """Cfg4 at the reference's full shape (16 x 512 x 512, voc.yaml:7,38) through a size-independent property: FCOSLoss is a
+    mean over images and, with every BatchNorm on its running statistics, images do not interact -- so the gradient of the
+    16-image step equals the mean of the sixteen single-image gradients (other block tiles, other split-K, other pixel-range
+    splits of the weight-gradient kernels: a real cross-check of the batched kernels, not a tautology)."""
+    torch.manual_seed(12)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).to(DEV)
+    model.freeze_all_bn = True
+    model.train()
+    B, S = 16, 512
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, 3, S, S, generator=g).to(DEV)
+    c = torch.rand(B, 6, 2, generator=g) * (S - 112) + 50
+    sz = torch.rand(B, 6, 2, generator=g) * 150 + 20
+    gt = torch.cat([c - sz / 2, c + sz / 2], -1).clamp(0, S - 1).to(DEV)
+    labels = torch.randint(1, 21, (B, 6), generator=g).to(DEV)
+    gen = FCOSGenTargets([8, 16, 32, 64, 128], [[-1, 32], [32, 96], [96, 192], [192, 384], [384, 9999999]])
+    crit = FCOSLoss("giou")
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+
+    def grads(sl):
+        model.zero_grad(set_to_none=True)
+        out = model(x[sl])
+        crit([out, gen([out, gt[sl], labels[sl]])])[-1].mean().backward()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    full = grads(slice(0, B))
+    acc = None
+    for i in range(B):
+        gi = grads(slice(i, i + 1))
+        acc = gi if acc is None else {n: acc[n] + gi[n] for n in acc}
+    assert set(full) == set(acc) == set(names)
+    worst = 0.0
+    for n in names:
+        a, b = full[n].double().flatten(), (acc[n] / B).double().flatten()
+        scale = float(b.abs().max()) + 1e-30
+        d = (a - b).abs() / scale
+        assert float(d.median()) < 2e-5, (n, float(d.median()))
+        assert float(d.max()) < 5e-2, (n, float(d.max()))       # (a ReLU-mask element may flip between the 1- and 16-image plans)
+        worst = max(worst, float(d.max()))
+    assert len(names) > 150
