@@ -143,7 +143,7 @@ def test_backward_abi_argument_errors_without_gpu():
     assert lib.fd_pack_conv_weight_f32(None, None, None, 64, 64, 3, 3, 0, None) < 0
     assert lib.fd_pack_conv_weight_f32(ctypes.c_void_p(16), None, ctypes.c_void_p(16), 64, 48, 3, 3, 0, None) < 0   # Cin % 32
     segs = _lib.Segs.make(2, [(8, 8), (4, 4)])
-    assert lib.fd_groupnorm_bwd_workspace_bytes(ctypes.byref(segs), 64) == (4 * 64 + 4) * 2 * 64 * 8
+    assert lib.fd_groupnorm_bwd_workspace_bytes(ctypes.byref(segs), 64) == (4 * 256 + 4) * 2 * 64 * 8
     assert lib.fd_dwconv3x3_wgrad_workspace_bytes(ctypes.byref(segs), 128) > 0
     assert lib.fd_groupnorm_act_bwd_nhwc(None, 0, 0, None, 0, 0, None, None, None, 0, 0, None, None, 64, 32, 1e-5, 0,
                                          ctypes.byref(segs), None, None, None) < 0
