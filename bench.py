@@ -184,7 +184,15 @@ def postproc_bench(dev, ncls: int = 80, size: int = 640):
             e1.synchronize()
             return e0.elapsed_time(e1) / reps * 1e3, out            # microseconds
 
-        t_dec, (sc, cl, bx) = timed(lambda: ops.fcos_decode(cls, cnt, reg, segs, strides))
+        sc, cl, bx = ops.fcos_decode(cls, cnt, reg, segs, strides)
+        import ctypes as C
+        from pytorch_object_detection_amd import _lib
+        st = (C.c_int32 * 5)(*strides)
+        fn, stream = _lib.lib().fd_fcos_decode, torch.cuda.current_stream().cuda_stream
+        # the bare C-ABI call on preallocated outputs: the Python wrapper's allocations (~13 us of host time per call) would
+        # hide a kernel this short behind the launch rate
+        t_dec, _ = timed(lambda: fn(cls.ptr, cls.cs, cls.co, cnt.ptr, cnt.cs, cnt.co, reg.ptr, reg.cs, reg.co, ncls, C.byref(segs), st,
+                                    sc.data_ptr(), cl.data_ptr(), bx.data_ptr(), stream), reps=200)
         t_top, (ts, tc, tb) = timed(lambda: ops.fcos_topk(sc, cl, bx, 1000))
         t_nms, out = timed(lambda: ops.batched_nms(ts, tc, tb, 0.05, 0.6))
         nbytes = B * L * ((ncls + 5) * 4 + 24)

@@ -68,8 +68,18 @@ class FCOSHead(nn.Module):
         return os_, oc, ob, counts
 
     def post_process(self, preds_top_k):
+        """head.py:84-102 on arbitrary (scores [B,K], classes [B,K], boxes [B,K,4]): the reference masks any position and
+        torchvision's nms sorts internally, while fd_batched_nms wants score-descending rows (what decode_topk produces) --
+        so rows are put in descending score order first (stable: ties keep their order); NaN scores are rejected."""
         s, c, b = preds_top_k
-        os_, oc, ob, _, counts = ops.batched_nms(s.contiguous(), c.contiguous(), b.contiguous(), float(self.score),
+        if s.shape[1] > 1 and not bool((s[:, 1:] <= s[:, :-1]).all()):         # also False when a NaN is present
+            if bool(torch.isnan(s).any()):
+                raise FdError("FCOSHead.post_process: NaN scores")
+            order = torch.sort(s, dim=1, descending=True, stable=True)[1]
+            s = torch.gather(s, 1, order)
+            c = torch.gather(c, 1, order)
+            b = torch.gather(b, 1, order[..., None].expand(-1, -1, 4))
+        os_, oc, ob, _, counts = ops.batched_nms(s.contiguous(), c.contiguous().to(torch.int64), b.contiguous(), float(self.score),
                                                  float(self.nms_threshold))
         return self._stack(os_, oc, ob, counts)
 

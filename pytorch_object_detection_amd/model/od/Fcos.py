@@ -204,4 +204,4 @@ class FCOS(PlannedModule):
         plan = self.plan_for(x)
         plan.image_ref[0] = x.contiguous()
         plan.run(events)
-        return tuple(pyramid_out(o, plan.segs) for o in plan.outs)
+        return self.outputs_of(plan)

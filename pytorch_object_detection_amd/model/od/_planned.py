@@ -92,9 +92,17 @@ class PlannedModule(nn.Module):
     pixel_mean = (0.485, 0.456, 0.406)   # dataset/voc.py:57-58
     pixel_std = (0.229, 0.224, 0.225)
 
+    copy_outputs = False     # True: forward returns fresh tensors (the reference's behaviour) instead of views of plan-owned
+                             # buffers that the next forward of the same shape overwrites
+
     def outputs_of(self, plan):
-        """(cls_logits, cnt_logits, reg_preds) views of a plan's output buffers (what forward returns after plan.run())."""
-        return tuple(pyramid_out(o, plan.segs) for o in plan.outs)
+        """(cls_logits, cnt_logits, reg_preds) of a plan after plan.run(): zero-copy channels-last views of the plan's output
+        buffers (valid until the next forward of the same shape; FCOSHead consumes them in place), or -- copy_outputs --
+        independent tensors a caller may keep across iterations."""
+        outs = tuple(pyramid_out(o, plan.segs) for o in plan.outs)
+        if self.copy_outputs:
+            return tuple([t.clone() for t in grp] for grp in outs)
+        return outs
 
     def plan_for(self, x, slot: int = 0):
         """The cached plan for an input: fp32 [B,3,H,W]; uint8 [B,H,W,3] (normalised on the device); or a list of resized
@@ -134,7 +142,7 @@ class PlannedModule(nn.Module):
         plan = self.plan_for(list(images))
         plan.image_ref[0] = [t.contiguous() for t in images]
         plan.run(events)
-        return tuple(pyramid_out(o, plan.segs) for o in plan.outs)
+        return self.outputs_of(plan)
 
     def _check_eval(self) -> None:
         if self.training:

@@ -198,10 +198,15 @@ class _PackCache:
     def refresh(self) -> None:
         import ctypes as C
         live = {}
+        newest: dict = {}        # (param address, shape) -> newest data-gradient entry: a re-folded frozen BN (load_state_dict) makes
+        for key, e in self.entries.items():      # a new scale tensor and a new entry; the superseded one is dropped here
+            if key[2]:
+                newest[key[:2]] = key
         for key, e in self.entries.items():
             p = e[0]()
-            if p is not None and p.data_ptr() == key[0] and tuple(p.shape) == key[1]:
+            if p is not None and p.data_ptr() == key[0] and tuple(p.shape) == key[1] and (not key[2] or newest[key[:2]] == key):
                 live[key] = e
+        self.params = {a: r for a, r in self.params.items() if r() is not None}
         if len(live) != len(self.entries):
             self.entries, self.table = live, None
         if not live:
@@ -725,8 +730,8 @@ def conv_bn_act(m: nn.Conv2d, bn: Optional[nn.Module], x: torch.Tensor, act: int
         return from_rows(dw_rows(m, to_rows(x), segs, bn, act), B, H, W)
     if not _STOCK and bn is not None and not bn_is_frozen(bn) and covered(m, None, x):
         y = bn(conv_bn_act(m, None, x))                     # BN in training mode: conv on HIP, statistics stock
-    else:
-        y = m(x) if bn is None else bn(m(x))
+    else:                                                   # documented stock-op fallbacks of the TRAINING forward (module docstring)
+        y = nn.Conv2d.forward(m, x) if bn is None else bn(nn.Conv2d.forward(m, x))
     if residual is not None:
         y = y + residual
     return F.relu(y) if act == ACT_RELU else y

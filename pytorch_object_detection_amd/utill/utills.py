@@ -44,8 +44,11 @@ class DataEncoder:
     def _box_iou(self, box1: torch.Tensor, box2: torch.Tensor, order: str = 'xyxy') -> torch.Tensor:
         """[N,4] x [M,4] -> [N,M] IoU with the '+1' pixel convention."""
         from .. import ops
-        if order != 'xyxy':
-            raise NotImplementedError("only order='xyxy' is built")
+        if order == 'xywh':          # utills.py:196-199 _change_box_order('xywh2xyxy'): (cx, cy, w, h) -> (c - wh/2, c + wh/2)
+            box1 = torch.cat([box1[:, :2] - box1[:, 2:] / 2, box1[:, :2] + box1[:, 2:] / 2], 1)
+            box2 = torch.cat([box2[:, :2] - box2[:, 2:] / 2, box2[:, :2] + box2[:, 2:] / 2], 1)
+        elif order != 'xyxy':
+            raise ValueError(f"unknown box order '{order}'")
         return ops.pairwise_iou(box1.contiguous().float(), box2.contiguous().float(), True)
 
     def _box_nms(self, bboxes: torch.Tensor, scores: torch.Tensor, threshold: float = 0.5, mode: str = 'union') -> torch.Tensor:

@@ -348,5 +348,49 @@ def g8():
     save("g8_tiny_fcos", **out)
 
 
+# ------------------------------------------------------------------ G9 full-width single layers / blocks
+def g9():
+    """Full-width (256-channel, 80-class) reference modules on 20x20 maps: HisBlock (1x1, depthwise, SE, 3x3, dilated 3x3),
+    HISFCOSHead over two levels (pointwise / depthwise / GroupNorm(32, 512) / 3x3 towers / GroupNorm(32, 256) / 80-, 1- and
+    4-wide predictors / ScaleExp), SEBlock(128, 4), DepthWiseConv2d(512).  Weights and inputs come from tests/golden/lcg.py
+    (regenerated on both sides, not stored); stored: every 7th output element + float64 sums."""
+    sys.path.insert(0, HERE)
+    import lcg
+    from model.modules import modules as ref_mod
+    out = {}
+
+    def put(name, t):
+        a = t.detach().numpy().reshape(-1)
+        out[name + "_shape"] = np.array(t.shape)
+        out[name + "_s7"] = a[::7].copy()
+        out[name + "_sum"] = np.array([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
+
+    blk = ref_his.HisBlock(256, 4, 2).eval()
+    lcg.fill_state(blk, 91)
+    x = lcg.tensor((1, 256, 20, 20), 9101)
+    with torch.no_grad():
+        put("hisblock", blk(x))
+    head = ref_his.HISFCOSHead(256, 80, 0.01).eval()
+    lcg.fill_state(head, 92)
+    feats = [lcg.tensor((1, 256, 20, 20), 9201), lcg.tensor((1, 256, 10, 10), 9202)]
+    with torch.no_grad():
+        cls, cnt, reg = head(feats)
+    for i in range(2):
+        put(f"head_cls{i}", cls[i]); put(f"head_cnt{i}", cnt[i]); put(f"head_reg{i}", reg[i])
+    se = ref_mod.SEBlock(128, 4).eval()
+    lcg.fill_state(se, 93)
+    with torch.no_grad():
+        put("se", se(lcg.tensor((2, 128, 20, 20), 9301)))
+    dw = ref_mod.DepthWiseConv2d(512, 3).eval()
+    lcg.fill_state(dw, 94)
+    with torch.no_grad():
+        put("dw", dw(lcg.tensor((1, 512, 20, 20), 9401)))
+    pw = ref_mod.PointWiseConv(2048, 256).eval()
+    lcg.fill_state(pw, 95)
+    with torch.no_grad():
+        put("pw", pw(lcg.tensor((1, 2048, 20, 20), 9501)))
+    save("g9_full_width", **out)
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g3b(); g4(); g5(); g67(); g8()
+    g1(); g2(); g3(); g3b(); g4(); g5(); g67(); g8(); g9()

@@ -198,3 +198,27 @@ def test_effnet_oracle_runs_and_is_deterministic():
     assert [tuple(e[f"reduction_{i}"].shape[1:]) for i in range(1, 7)] == [(16, 48, 32), (24, 24, 16), (40, 12, 8), (112, 6, 4), (320, 3, 2),
                                                                           (1280, 3, 2)]
     assert all(0.05 < float(e[f"reduction_{i}"].std()) < 5 for i in range(1, 6))       # the test init keeps every endpoint O(1)
+
+
+def test_reference_checkpoint_layouts_load():
+    """test.py:273-281 / Test_coco.py:206-214: checkpoints saved from a DistributedDataParallel model carry a 7-character
+    'module.' prefix the scripts strip; ResNet50v2 checkpoints hold BOTH key sets (backbone.conv1 / bn1 / layer1.* and
+    backbone.extract_feature.*, shared tensors in the reference's fx GraphModule).  Both layouts load strictly."""
+    m = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256)
+    sd = m.state_dict()
+    assert "backbone.conv1.weight" in sd and "backbone.extract_feature.conv1.weight" in sd
+    assert sd["backbone.layer1.0.conv1.weight"].data_ptr() == sd["backbone.extract_feature.layer1.0.conv1.weight"].data_ptr()
+    ddp_ckpt = {"module." + k: v.clone() + (0.5 if v.is_floating_point() else 0) for k, v in sd.items()}
+    stripped = {k[7:]: v for k, v in ddp_ckpt.items()}                      # the reference's `k[7:]`
+    m2 = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256)
+    missing, unexpected = m2.load_state_dict(stripped, strict=True)
+    assert not missing and not unexpected
+    assert torch.equal(m2.state_dict()["fpn.tf1.weight"], sd["fpn.tf1.weight"] + 0.5)
+    # a checkpoint that carries only ONE of the two backbone key sets still fills the shared tensors
+    one = {k: v for k, v in stripped.items() if not k.startswith(("backbone.conv1", "backbone.bn1", "backbone.layer1"))}
+    m3 = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256)
+    res = m3.load_state_dict(one, strict=False)
+    assert not res.unexpected_keys and all(k.startswith(("backbone.conv1", "backbone.bn1", "backbone.layer1")) for k in res.missing_keys)
+    assert torch.equal(m3.backbone.conv1.weight, stripped["backbone.extract_feature.conv1.weight"])
+    f = FCOS([2048, 1024, 512], 20, 256)
+    f.load_state_dict({k[7:]: v for k, v in {"module." + k: v for k, v in f.state_dict().items()}.items()}, strict=True)

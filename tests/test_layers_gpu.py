@@ -570,3 +570,56 @@ def test_fused_bottleneck_autograd(stride, down):
     for a, b in pairs:
         s = float(b.abs().max())
         np.testing.assert_allclose(a.cpu().numpy() / s, b.numpy() / s, atol=3e-5)
+
+
+def test_g9_full_width_layers_on_hip(golden):
+    """SURVEY §8c G9 on the HIP path: the reference's full-width modules (fixtures generated by the real reference,
+    tests/golden/make_golden.py g9; weights / inputs regenerated from tests/golden/lcg.py) -- HisBlock(256) through the plan
+    builder, HISFCOSHead(256, 80) over two levels, and the standalone layer forwards of SEBlock / DepthWiseConv2d /
+    PointWiseConv (the reference exposes them as ordinary layers, modules.py:40-49,65-73,107-121)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import lcg
+    from pytorch_object_detection_amd import engine
+    from pytorch_object_detection_amd.model.modules.modules import DepthWiseConv2d, PointWiseConv, ScaleExp, SEBlock
+    from pytorch_object_detection_amd.model.od.HISFcos import HisBlock, HISFCOSHead
+    g = golden("g9_full_width")
+
+    def check(name, t):
+        a = t.detach().cpu().numpy().reshape(-1)
+        assert tuple(g[name + "_shape"]) == tuple(t.shape), name
+        np.testing.assert_allclose(a[::7], g[name + "_s7"], atol=1e-4, rtol=1e-4, err_msg=name)
+        ref_sum, ref_abs = g[name + "_sum"]
+        assert abs(a.astype(np.float64).sum() - ref_sum) <= 2e-5 * ref_abs + 1e-3, name
+
+    blk = HisBlock(256, 4, 2).eval(); lcg.fill_state(blk, 91); blk.to(DEV)
+    x = to_rows(lcg.tensor((1, 256, 20, 20), 9101))
+    plan = engine.Plan(torch.device(DEV))
+    segs = Segs.make(1, [(20, 20)])
+    out = ops.new_rows(400, 256, DEV)
+    engine._his_block(plan, "b", blk, x, segs, out)
+    plan.run()
+    check("hisblock", from_rows(out, 1, 20, 20))
+    head = HISFCOSHead(256, 80, 0.01).eval(); lcg.fill_state(head, 92); head.to(DEV)
+    cls, cnt, reg = head([lcg.tensor((1, 256, 20, 20), 9201).to(DEV), lcg.tensor((1, 256, 10, 10), 9202).to(DEV)])
+    for i in range(2):
+        check(f"head_cls{i}", cls[i]); check(f"head_cnt{i}", cnt[i]); check(f"head_reg{i}", reg[i])
+    with torch.no_grad():
+        se = SEBlock(128, 4).eval(); lcg.fill_state(se, 93); se.to(DEV)
+        check("se", se(lcg.tensor((2, 128, 20, 20), 9301).to(DEV)))
+        dw = DepthWiseConv2d(512, 3).eval(); lcg.fill_state(dw, 94); dw.to(DEV)
+        check("dw", dw(lcg.tensor((1, 512, 20, 20), 9401).to(DEV)))
+        pw = PointWiseConv(2048, 256).eval(); lcg.fill_state(pw, 95); pw.to(DEV)
+        check("pw", pw(lcg.tensor((1, 2048, 20, 20), 9501).to(DEV)))
+        # shapes outside the autograd kernels: 5x5 stride-2 depthwise forward, ScaleExp
+        dw5 = DepthWiseConv2d(64, 5, 2).eval().to(DEV)
+        xx = torch.randn(2, 64, 13, 17)
+        np.testing.assert_allclose(dw5(xx.to(DEV)).cpu().numpy(), F.conv2d(xx, dw5.weight.cpu(), None, 2, 2, 1, 64).numpy(), atol=1e-5, rtol=1e-5)
+        sx = ScaleExp(1.2).to(DEV)
+        np.testing.assert_allclose(sx(xx.to(DEV)).cpu().numpy(), torch.exp(xx * 1.2).numpy(), rtol=2e-6)
+    with pytest.raises(Exception, match="not covered"):
+        PointWiseConv(30, 8).to(DEV)(torch.randn(1, 30, 4, 4, device=DEV))
+    # autograd through the standalone layers stays on the HIP nodes
+    xg = torch.randn(2, 512, 8, 8, device=DEV).to(memory_format=torch.channels_last).requires_grad_(True)
+    dw(xg).sum().backward()
+    assert xg.grad is not None and dw.weight.grad is not None

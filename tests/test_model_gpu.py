@@ -322,3 +322,25 @@ def test_two_lane_pipeline_matches_serial_steps():
     for a, b in zip(serial, got):
         for u, v in zip(a[:4], b[:4]):
             assert torch.equal(u, v)
+
+
+def test_copy_outputs_returns_tensors_that_survive_the_next_forward():
+    """by default the model returns views of plan-owned buffers (zero-copy into FCOSHead) that the next forward of
+    the same shape overwrites; model.copy_outputs = True gives the reference's behaviour -- fresh tensors."""
+    torch.manual_seed(41)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).eval().to(DEV)
+    x1, x2 = torch.randn(1, 3, 128, 128, device=DEV), torch.randn(1, 3, 128, 128, device=DEV)
+    a = model(x1)[0][0]
+    keep = a.clone()
+    model(x2)
+    assert not torch.equal(a, keep)                      # the view now shows the second image's logits
+    model.copy_outputs = True
+    b = model(x1)
+    kept = [[t.clone() for t in grp] for grp in b]
+    model(x2)
+    for grp, grp0 in zip(b, kept):
+        for t, t0 in zip(grp, grp0):
+            assert torch.equal(t, t0)
+    assert torch.equal(b[0][0], keep)
+    head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
+    assert head.detect_padded(b)[0].shape[0] == 1        # plain lists of tensors are accepted by FCOSHead

@@ -148,3 +148,40 @@ def test_normalize_and_box_rescale_against_numpy():
     boxes = rng.uniform(0, 600, (9, 4)).astype(np.float32)
     e = boxes.copy(); e /= 1.3; e[:, 2] -= e[:, 0]; e[:, 3] -= e[:, 1]
     np.testing.assert_array_equal(R.boxes_rescale_xywh(boxes, 1.3), e)
+
+
+def _g9_check(g, name, t, atol=1e-4, rtol=1e-4):
+    a = t.detach().cpu().numpy().reshape(-1)
+    assert tuple(g[name + "_shape"]) == tuple(t.shape), name
+    np.testing.assert_allclose(a[::7], g[name + "_s7"], atol=atol, rtol=rtol, err_msg=name)
+    ref_sum, ref_abs = g[name + "_sum"]
+    assert abs(a.astype(np.float64).sum() - ref_sum) <= 1e-5 * ref_abs + 1e-3, name
+
+
+def test_g9_full_width_layers(golden):
+    """full-width (256 ch / 80 classes) reference modules, weights + inputs regenerated from tests/golden/lcg.py."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import lcg
+    from pytorch_object_detection_amd.model.modules.modules import DepthWiseConv2d, PointWiseConv, SEBlock
+    from pytorch_object_detection_amd.model.od.HISFcos import HisBlock, HISFCOSHead
+    g = golden("g9_full_width")
+    blk = HisBlock(256, 4, 2).eval(); lcg.fill_state(blk, 91)
+    sd = {"b." + k: v for k, v in blk.state_dict().items()}
+    with torch.no_grad():
+        _g9_check(g, "hisblock", R.his_block(sd, "b", lcg.tensor((1, 256, 20, 20), 9101)))
+    head = HISFCOSHead(256, 80, 0.01).eval(); lcg.fill_state(head, 92)
+    sd = {"head." + k: v for k, v in head.state_dict().items()}
+    with torch.no_grad():
+        cls, cnt, reg = R.his_head(sd, [lcg.tensor((1, 256, 20, 20), 9201), lcg.tensor((1, 256, 10, 10), 9202)])
+    for i in range(2):
+        _g9_check(g, f"head_cls{i}", cls[i]); _g9_check(g, f"head_cnt{i}", cnt[i]); _g9_check(g, f"head_reg{i}", reg[i])
+    se = SEBlock(128, 4).eval(); lcg.fill_state(se, 93)
+    with torch.no_grad():
+        _g9_check(g, "se", R.se_block({"s." + k: v for k, v in se.state_dict().items()}, "s", lcg.tensor((2, 128, 20, 20), 9301)))
+    dw = DepthWiseConv2d(512, 3).eval(); lcg.fill_state(dw, 94)
+    with torch.no_grad():
+        _g9_check(g, "dw", torch.nn.functional.conv2d(lcg.tensor((1, 512, 20, 20), 9401), dw.weight, None, 1, 1, 1, 512))
+    pw = PointWiseConv(2048, 256).eval(); lcg.fill_state(pw, 95)
+    with torch.no_grad():
+        _g9_check(g, "pw", torch.nn.functional.conv2d(lcg.tensor((1, 2048, 20, 20), 9501), pw.weight))
