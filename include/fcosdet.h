@@ -124,6 +124,14 @@ typedef struct fd_conv_params {
                           (train step: removes the separate threshold pass) */
     float seg_param[FD_MAX_SEG]; /* per-level scalar for FD_ACT_EXP */
     fd_segs in;     /* input geometry */
+    /* Data gradient of a STRIDED conv as parity classes (train.py:175-181; the 3x3 s2 / 1x1 s2 layers of the ResNet trunk):
+     * dX pixels with (h % s, w % s) = (a, b) only see the filter taps r = (a + pad) % s + s*t, so each class is a stride-1
+     * conv over dY with those taps (KH x KW may differ) whose outputs interleave into dX.  Single-level input only.
+     *   out_H, out_W > 0: explicit output size (instead of the size derived from pad / K): taps past the input read zero;
+     *   sc_H, sc_W > 0:   output pixel (n, i, j) is written to pixel (sc_sy*i + sc_oy, sc_sx*j + sc_ox) of an
+     *                     [N][sc_H][sc_W] map at y (and `res` is read there); y_cs / y_co / res_* describe that map. */
+    int32_t out_H, out_W;
+    int32_t sc_sy, sc_sx, sc_oy, sc_ox, sc_H, sc_W;
 } fd_conv_params;
 
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);

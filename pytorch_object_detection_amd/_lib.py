@@ -54,7 +54,9 @@ class ConvParams(C.Structure):
                 ("pad", C.c_int32), ("dil", C.c_int32),
                 ("act", C.c_int32), ("act_c0", C.c_int32), ("mode", C.c_int32), ("tile", C.c_int32), ("tag", C.c_int32), ("ksplit", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("precision", C.c_int32), ("res_mode", C.c_int32),
-                ("seg_param", C.c_float * FD_MAX_SEG), ("segs", Segs)]
+                ("seg_param", C.c_float * FD_MAX_SEG), ("segs", Segs),
+                ("out_H", C.c_int32), ("out_W", C.c_int32), ("sc_sy", C.c_int32), ("sc_sx", C.c_int32), ("sc_oy", C.c_int32),
+                ("sc_ox", C.c_int32), ("sc_H", C.c_int32), ("sc_W", C.c_int32)]
 
 
 class PackJob(C.Structure):

@@ -37,7 +37,18 @@ struct ConvArgs {
     long slice_stride;  // elements between consecutive split-K slabs in the workspace
     unsigned x_bytes, w_bytes;   // extents of the input / packed-weight buffers (raw buffer descriptors: OOB reads return 0)
     int res_mask;  // 1: `res` is a ReLU mask (y = res > 0 ? v : 0) instead of an addend
+    // output scatter (single level): output pixel (n, i, j) is written to row (n*sc_H + sc_sy*i + sc_oy)*sc_W + sc_sx*j + sc_ox of
+    // y (and reads `res` there): one parity class of the data gradient of a strided conv lands interleaved in dX
+    int sc_on, sc_sy, sc_sx, sc_oy, sc_ox, sc_H, sc_W;
 };
+
+__device__ __forceinline__ long out_row(const ConvArgs& a, int m) {
+    if (!a.sc_on) return m;
+    const int hw = a.Ho[0] * a.Wo[0];
+    const int n = m / hw, rem = m - n * hw;
+    const int i = rem / a.Wo[0], j = rem - i * a.Wo[0];
+    return ((long)n * a.sc_H + (a.sc_sy * i + a.sc_oy)) * a.sc_W + (a.sc_sx * j + a.sc_ox);
+}
 
 // LDS hand-off between lanes of ONE wave: the LDS pipe executes a wave's ds instructions in order, so later reads see
 // earlier writes once lgkmcnt has drained; the fence + wave barrier keep the compiler from moving accesses across.
@@ -286,7 +297,7 @@ void conv_igemm_kernel(ConvArgs a) {
                     const int m = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * p;
                     const int nn = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
                     rres[i][j][p] = (m < a.M && nn < a.Cout_epi)
-                                        ? *reinterpret_cast<const float4*>(a.res + (size_t)m * a.res_cs + a.res_co + nn)
+                                        ? *reinterpret_cast<const float4*>(a.res + (size_t)out_row(a, m) * a.res_cs + a.res_co + nn)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
     }
@@ -322,9 +333,10 @@ void conv_igemm_kernel(ConvArgs a) {
                     const int m = mb + row, nn = nb + c4;
                     float4 v = *reinterpret_cast<const float4*>(stage + row * 32 + c4);
                     if (m < a.M && nn < a.Cout_epi) {
+                        const size_t mo = (size_t)out_row(a, m);
                         if (a.res) {
                             float4 r;
-                            if constexpr (SPLIT) r = *reinterpret_cast<const float4*>(a.res + (size_t)m * a.res_cs + a.res_co + nn);
+                            if constexpr (SPLIT) r = *reinterpret_cast<const float4*>(a.res + mo * a.res_cs + a.res_co + nn);
                             else r = rres[i][j][p];
                             if (a.res_mask) {
                                 v.x = r.x > 0.f ? v.x : 0.f; v.y = r.y > 0.f ? v.y : 0.f;
@@ -347,7 +359,7 @@ void conv_igemm_kernel(ConvArgs a) {
                             if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, prm);
                             if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, prm);
                         }
-                        *reinterpret_cast<float4*>(ybase + (size_t)m * a.y_cs + a.y_co + nn) = v;
+                        *reinterpret_cast<float4*>(ybase + mo * a.y_cs + a.y_co + nn) = v;
                     }
                 }
                 wave_lds_sync();
@@ -357,9 +369,10 @@ void conv_igemm_kernel(ConvArgs a) {
                 for (int e = 0; e < 16; ++e) {
                     const int m = mb + 4 * lh + (e & 3) + 8 * (e >> 2);
                     if (n_ok && m < a.M) {
+                        const size_t mo = (size_t)out_row(a, m);
                         float v = acc[i][j][e] * sc + sf;
                         if (a.res) {
-                            const float r = a.res[(size_t)m * a.res_cs + a.res_co + n];
+                            const float r = a.res[mo * a.res_cs + a.res_co + n];
                             v = a.res_mask ? (r > 0.f ? v : 0.f) : v + r;
                         }
                         float prm = 0.f;
@@ -370,7 +383,7 @@ void conv_igemm_kernel(ConvArgs a) {
                                 if (t < a.nseg && m >= a.m_out[t]) s = t;
                             prm = a.seg_param[s];
                         }
-                        ybase[(size_t)m * a.y_cs + a.y_co + n] = fd_act(v, act, prm);
+                        ybase[mo * a.y_cs + a.y_co + n] = fd_act(v, act, prm);
                     }
                 }
             }
@@ -406,11 +419,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, const fl
             const int n = nn + e;
             if (n >= a.Cout) continue;
             float r = o[e] * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
+            const size_t mo = (size_t)out_row(a, (int)m);
             if (a.res) {
-                const float rv = a.res[(size_t)m * a.res_cs + a.res_co + n];
+                const float rv = a.res[mo * a.res_cs + a.res_co + n];
                 r = a.res_mask ? (rv > 0.f ? r : 0.f) : r + rv;
             }
-            a.y[(size_t)m * a.y_cs + a.y_co + n] = fd_act(r, n >= a.act_c0 ? a.act : FD_ACT_NONE, prm);
+            a.y[mo * a.y_cs + a.y_co + n] = fd_act(r, n >= a.act_c0 ? a.act : FD_ACT_NONE, prm);
         }
     }
 }
@@ -476,6 +490,10 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
             a.H[s] = p->in.H[s]; a.W[s] = p->in.W[s];
             a.Ho[s] = (p->in.H[s] + 2 * p->pad - p->dil * (p->KH - 1) - 1) / p->stride + 1;
             a.Wo[s] = (p->in.W[s] + 2 * p->pad - p->dil * (p->KW - 1) - 1) / p->stride + 1;
+            if (p->out_H > 0 || p->out_W > 0) {   // explicit output size: taps past the input read as zero (parity classes of a strided dgrad)
+                FD_REQUIRE(p->in.nseg == 1 && p->out_H > 0 && p->out_W > 0, FD_E_INVAL, "fd_conv2d: out_H / out_W need a single-level input");
+                a.Ho[s] = p->out_H; a.Wo[s] = p->out_W;
+            }
             FD_REQUIRE(a.Ho[s] >= 1 && a.Wo[s] >= 1, FD_E_INVAL, "fd_conv2d: empty output");
             a.m_in[s] = p->in.m_start[s];
             a.m_out[s] = (int)mo;
@@ -488,7 +506,16 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     a.m_out[FD_MAX_SEG] = (int)mo;
     FD_REQUIRE(mo > 0 && mo < (1L << 31), FD_E_INVAL, "fd_conv2d: row count out of range");
     a.M = (int)mo;
-    FD_REQUIRE((long)p->in.m_start[p->in.nseg] * p->x_cs < (1L << 31) && mo * p->y_cs < (1L << 31), FD_E_UNSUPPORTED,
+    a.sc_on = 0; a.sc_sy = a.sc_sx = 1; a.sc_oy = a.sc_ox = 0; a.sc_H = a.sc_W = 0;
+    long y_rows = mo;
+    if (p->sc_H > 0) {
+        FD_REQUIRE(p->in.nseg == 1 && !stem && p->sc_W > 0 && p->sc_sy >= 1 && p->sc_sx >= 1 && p->sc_oy >= 0 && p->sc_ox >= 0 &&
+                       p->sc_sy * (a.Ho[0] - 1) + p->sc_oy < p->sc_H && p->sc_sx * (a.Wo[0] - 1) + p->sc_ox < p->sc_W,
+                   FD_E_INVAL, "fd_conv2d: output scatter does not fit its %d x %d target", p->sc_H, p->sc_W);
+        a.sc_on = 1; a.sc_sy = p->sc_sy; a.sc_sx = p->sc_sx; a.sc_oy = p->sc_oy; a.sc_ox = p->sc_ox; a.sc_H = p->sc_H; a.sc_W = p->sc_W;
+        y_rows = (long)p->in.batch * p->sc_H * p->sc_W;
+    }
+    FD_REQUIRE((long)p->in.m_start[p->in.nseg] * p->x_cs < (1L << 31) && y_rows * p->y_cs < (1L << 31), FD_E_UNSUPPORTED,
                "fd_conv2d: tensor exceeds 2^31 elements");
     if (stem) { a.KT = 7; a.ntaps = 7; a.Kpacked = 7 * 32; }
     else { const int cch = (p->Cin + 31) / 32; a.ntaps = p->KH * p->KW; a.KT = a.ntaps * cch; a.Kpacked = a.ntaps * cch * 32; }
@@ -518,7 +545,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
                    "fd_conv2d: split-K needs a 16-byte aligned workspace of fd_conv_workspace_bytes() bytes");
         a.kt_per = (a.KT + ksplit - 1) / ksplit;
         a.y = (float*)p->workspace; a.y_cs = ldw; a.y_co = 0; a.slice_stride = slab; a.Cout_epi = ldw;
-        a.scale = a.shift = a.res = nullptr; a.act = FD_ACT_NONE; a.vec_epi = 1;
+        a.scale = a.shift = a.res = nullptr; a.act = FD_ACT_NONE; a.vec_epi = 1; a.sc_on = 0;
         const int rc = dispatch_conv(p, a, stem, stream);
         if (rc != FD_OK) return rc;
         const int nslice = (a.KT + a.kt_per - 1) / a.kt_per;

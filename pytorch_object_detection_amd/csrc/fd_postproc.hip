@@ -88,8 +88,10 @@ __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
     const int loc0 = (blockIdx.x * 4 + wv) * DEC_LPW;
     if (loc0 >= a.L) return;                        // whole wave out of range (no workgroup barrier below)
     const int nloc = min(DEC_LPW, a.L - loc0);
-    // this lane's own location (lanes >= nloc shadow the last one and store nothing): centre-ness / regression loads first
-    const int myloc = loc0 + min(lane, nloc - 1);
+    // lanes l and l + 32 share location l (each scans half of its row below); lanes past nloc shadow the last location and
+    // store nothing.  Centre-ness / regression loads are issued before the class sweep.
+    const int lid = lane & 31, half = lane >> 5;
+    const int myloc = loc0 + min(lid, nloc - 1);
     int ms = 0;
 #pragma unroll
     for (int t = 1; t < FD_MAX_SEG; ++t)
@@ -130,32 +132,37 @@ __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
     __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < nloc) {
-        const float4* row = rows + lane * QP;
-        float L = -INFINITY;
+    {
+        // one pass over the row, split between the two lanes of a location: largest logit L with its FIRST index, and the
+        // second largest value (compare-only)
+        const float4* row = rows + lid * QP;
+        const int q0 = half ? (Q >> 1) : 0, q1 = half ? Q : (Q >> 1);
+        float L = -INFINITY, L2 = -INFINITY;
         int li = 0;
-        for (int q = 0; q < Q; ++q) {                 // max logit and its first index (compare-only)
+        for (int q = q0; q < q1; ++q) {
             const float4 v = row[q];
-            if (v.x > L) { L = v.x; li = 4 * q; }
-            if (v.y > L) { L = v.y; li = 4 * q + 1; }
-            if (v.z > L) { L = v.z; li = 4 * q + 2; }
-            if (v.w > L) { L = v.w; li = 4 * q + 3; }
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (e[c] > L) { L2 = L; L = e[c]; li = 4 * q + c; }
+                else L2 = fmaxf(L2, e[c]);
+            }
         }
+        const float oL = __shfl_xor(L, 32), oL2 = __shfl_xor(L2, 32);
+        const int oli = __shfl_xor(li, 32);
+        // lower half holds the lower class indices: it wins ties
+        const bool take_other = half ? (oL >= L) : (oL > L);
+        L2 = fmaxf(fmaxf(L2, oL2), take_other ? L : oL);
+        if (take_other) { L = oL; li = oli; }
         // classes whose COMPUTED sigmoid could reach the computed sigmoid(L): fd_sigmoid is good to a few ulp, so only logits
-        // within ~8 ulp(s) / s'(L) = 9.5e-7 (1 + e^L) of L (doubled below) -- one candidate unless logits are (nearly) equal
-        const float eL = expf(L);
-        const float cut = L - 2.0e-6f * (1.0f + eL);  // L = +inf / NaN-free rows only; an inf window (L > 88) takes every class
-        int ncand = 0;
-        for (int q = 0; q < Q; ++q) {
-            const float4 v = row[q];
-            ncand += (v.x >= cut) + (v.y >= cut) + (v.z >= cut) + (v.w >= cut);
-        }
+        // within ~8 ulp(s) / s'(L) = 9.5e-7 (1 + e^L) of L (doubled below) -- just the maximum unless logits are (nearly) equal
+        const float cut = (L < 80.0f) ? L - 2.0e-6f * (1.0f + expf(L)) : -INFINITY;   // (e^L overflows: every class is a candidate)
         float best = -1.0f;
         int besti = 0;
-        if (ncand == 1) {
+        if (L2 < cut) {
             best = fd_sigmoid(L);
             besti = li;
-        } else if (ncand > 1) {                       // rare: evaluate every candidate, first maximal sigmoid wins (head.py:62)
+        } else if (half == 0 && lid < nloc) {           // rare: evaluate every candidate, first maximal sigmoid wins (head.py:62)
             for (int q = 0; q < Q; ++q) {
                 const float4 v = row[q];
                 if (v.x >= cut) { const float sv = fd_sigmoid(v.x); if (sv > best) { best = sv; besti = 4 * q; } }
@@ -163,7 +170,8 @@ __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
                 if (v.z >= cut) { const float sv = fd_sigmoid(v.z); if (sv > best) { best = sv; besti = 4 * q + 2; } }
                 if (v.w >= cut) { const float sv = fd_sigmoid(v.w); if (sv > best) { best = sv; besti = 4 * q + 3; } }
             }
-        }                                             // ncand == 0: a row of NaNs -> best = -1, class 1, as the plain kernel
+        }                                               // a row of NaNs: L = -inf, nothing >= cut -> best = -1, class 1 (plain kernel)
+        if (half != 0 || lid >= nloc) return;
         const float score = sqrtf(best * fd_sigmoid(cnt_logit));
         const int py = mypix / mW, px = mypix - py * mW;
         const int st = a.stride[ms];

@@ -129,7 +129,8 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
               res: Optional[Rows] = None, act: int = ACT_NONE, act_c0: int = 0,
               seg_param: Optional[Sequence[float]] = None, stem: bool = False, tile: int = 0,
               tag: int = 0, precision: int = 0, ksplit: int = 1,
-              workspace: Optional[torch.Tensor] = None, res_mask: bool = False) -> Callable[[], None]:
+              workspace: Optional[torch.Tensor] = None, res_mask: bool = False, kw: Optional[int] = None,
+              out_hw: Optional[Tuple[int, int]] = None, scatter: Optional[Tuple[int, int, int, int, int, int]] = None) -> Callable[[], None]:
     """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream."""
     _need_gpu(w_packed, scale, shift)
     p = ConvParams()
@@ -140,7 +141,11 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     p.x_cs, p.x_co, p.y_cs, p.y_co = x.cs, x.co, y.cs, y.co
     if res is not None:
         p.res_cs, p.res_co = res.cs, res.co
-    p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, k, stride, pad, dil
+    p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, (k if kw is None else kw), stride, pad, dil
+    if out_hw is not None:
+        p.out_H, p.out_W = out_hw
+    if scatter is not None:           # (sy, sx, oy, ox, H, W): output pixel (i, j) -> (sy*i + oy, sx*j + ox) of an [N, H, W] map
+        p.sc_sy, p.sc_sx, p.sc_oy, p.sc_ox, p.sc_H, p.sc_W = scatter
     p.act, p.act_c0, p.mode = act, act_c0, (_lib.CONV_STEM if stem else _lib.CONV_GENERIC)
     p.tile, p.tag, p.precision, p.ksplit = tile, tag, precision, ksplit
     p.res_mode = 1 if (res_mask and res is not None) else 0
@@ -322,6 +327,46 @@ def pack_conv_weight_hip(w: torch.Tensor, scale: Optional[torch.Tensor] = None, 
                                              out.data_ptr(), co, ci, kh, kw, 1 if dgrad else 0, _stream()),
           "fd_pack_conv_weight_f32")
     return out
+
+
+def strided_dgrad_classes(k: int, stride: int, pad: int):
+    """Parity classes of the data gradient of a k x k conv with `stride`: for input rows h = stride*i + a only the taps
+    r = r0 + stride*t contribute, and dY row = i + c - t.  Returns per class a: (r0, T taps, c) with r0 = (a + pad) % stride,
+    T = number of taps, c = (a + pad - r0) // stride; T == 0: the class is identically zero."""
+    out = []
+    for a in range(stride):
+        r0 = (a + pad) % stride
+        T = len(range(r0, k, stride))
+        out.append((r0, T, (a + pad - r0) // stride))
+    return out
+
+
+def conv_dgrad_strided(dy: Rows, w: torch.Tensor, scale: Optional[torch.Tensor], dx: Rows, N: int, H: int, W: int, k: int,
+                       stride: int, pad: int, res: Optional[Rows] = None, res_mask: bool = False) -> bool:
+    """dX of y = conv(x, w, stride >= 2, pad, dilation 1) on the MFMA conv kernel, exact FLOPs: one stride-1 launch per parity
+    class (h % stride, w % stride) over dY with that class's taps, outputs interleaved straight into dX (fd_conv_params out_H /
+    sc_*).  dx must be zero-initialised when some class has no tap (1x1 stride 2).  `scale` [Cout]: a folded frozen BatchNorm;
+    res / res_mask as in conv_call (dX geometry).  Returns False (nothing launched) for a geometry it does not cover."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    cls = strided_dgrad_classes(k, stride, pad)
+    if Cout % 32 or Cin % 4 or any(T and (T - 1 - c) != 0 for _, T, c in cls):
+        return False                      # (the class convs of k = 3 / pad 1 and k = 1 / pad 0 need no padding; others are not built)
+    segs = Segs.make(N, [(Ho, Wo)])
+    wd = w.detach()
+    for a, (r0, Ta, _) in enumerate(cls):
+        Ia = len(range(a, H, stride))
+        for b, (q0, Tb, _) in enumerate(cls):
+            Jb = len(range(b, W, stride))
+            if Ta == 0 or Tb == 0 or Ia == 0 or Jb == 0:
+                continue
+            sub = wd[:, :, r0::stride, q0::stride].contiguous()                      # [Cout, Cin, Ta, Tb]
+            out = torch.empty(Cin, Cout // 32, Ta, Tb, 32, dtype=torch.float32, device=w.device)
+            check(_lib.lib().fd_pack_conv_weight_f32(sub.data_ptr(), scale.data_ptr() if scale is not None else None, out.data_ptr(),
+                                                     Cout, Cin, Ta, Tb, 1, _stream()), "fd_pack_conv_weight_f32")
+            conv_call(dy, segs, out, dx, Cin=Cout, Cout=Cin, k=Ta, kw=Tb, stride=1, pad=0, res=res, res_mask=res_mask,
+                      out_hw=(Ia, Jb), scatter=(stride, stride, a, b, H, W))()
+    return True
 
 
 def dgrad_weight(w: torch.Tensor) -> torch.Tensor:

@@ -261,6 +261,24 @@ def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.T
     call()
 
 
+def _strided_dgrad(g: torch.Tensor, weight: torch.Tensor, scale: Optional[torch.Tensor], segs: Segs, k: int, stride: int, pad: int,
+                   res: Optional[torch.Tensor] = None, res_mask: bool = False) -> Optional[torch.Tensor]:
+    """dX rows of a strided single-level conv from dY rows `g` on the HIP conv kernel (None: geometry not covered)."""
+    if _STOCK or segs.nseg != 1:
+        return None
+    B, (H, W) = segs.batch, segs.level_hw()[0]
+    Cin = weight.shape[1]
+    empty_class = any(T == 0 for _, T, _ in ops.strided_dgrad_classes(k, stride, pad))
+    gx = (torch.zeros if empty_class else torch.empty)(B * H * W, Cin, dtype=torch.float32, device=g.device)
+    ok = ops.conv_dgrad_strided(_r(g), weight, scale, _r(gx), B, H, W, k, stride, pad, res=_r(res) if res is not None else None,
+                                res_mask=res_mask)
+    if not ok:
+        return None
+    if res_mask and empty_class and res is not None:
+        raise FdError("strided dgrad: a ReLU mask over a class-sparse gradient is not built")
+    return gx
+
+
 class _ConvRows(torch.autograd.Function):
     """y = act(conv(x, w) * scale + shift + residual) on rows; scale is a constant (frozen BN), shift may need a gradient."""
 
@@ -298,7 +316,9 @@ class _ConvRows(torch.autograd.Function):
                 gx = torch.empty_like(x)
                 _conv_launch(g, so, PACKS.get(weight, scale, dgrad=True), gx, k=k, stride=1,
                              pad=dil * (k - 1) - pad, dil=dil)
-            elif segs.nseg == 1:  # strided layers: stock op for the data gradient (single level only)
+            elif segs.nseg == 1 and stride > 1 and dil == 1 and (gx := _strided_dgrad(g, weight, scale, segs, k, stride, pad)) is not None:
+                pass                                   # strided layer: one exact-FLOP launch per parity class (ops.conv_dgrad_strided)
+            elif segs.nseg == 1:  # what is left (narrow Cout, dilated + strided): stock op for the data gradient
                 weff = weight.detach() if scale is None else weight.detach() * scale.view(-1, 1, 1, 1)
                 B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
                 gx4 = torch.ops.aten.convolution_backward(from_rows(g, B, Ho, Wo), from_rows(x, B, H, W), weff, None,
@@ -397,6 +417,8 @@ class _BottleneckRows(torch.autograd.Function):
         if stride == 1:
             g1 = torch.empty_like(y1)
             _conv_launch(g2, so, PACKS.get(w2, s2, dgrad=True), g1, k=3, stride=1, pad=1, dil=1, res=y1, res_mask=True)
+        elif (g1 := _strided_dgrad(g2, w2, s2, segs, 3, stride, 1, res=y1, res_mask=True)) is not None:
+            pass    # strided 3x3: four parity-class launches on the conv kernel, ReLU mask of y1 applied in their epilogues
         else:   # strided 3x3: stock data gradient, masked separately
             B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
             g1 = torch.ops.aten.convolution_backward(from_rows(g2, B, Ho, Wo), from_rows(y1, B, H, W), w2.detach() * s2.view(-1, 1, 1, 1),
@@ -412,6 +434,8 @@ class _BottleneckRows(torch.autograd.Function):
             elif stride == 1:
                 gid = torch.empty_like(x)
                 _conv_launch(g, so, PACKS.get(wd, sd, dgrad=True), gid, k=1, stride=1, pad=0, dil=1)
+            elif (gid := _strided_dgrad(g, wd, sd, segs, 1, stride, 0)) is not None:
+                pass    # 1x1 stride-2 downsample: the (0, 0) parity class is a plain GEMM scattered into a zeroed dX
             else:
                 B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
                 gid = to_rows(torch.ops.aten.convolution_backward(from_rows(g, B, Ho, Wo), from_rows(x, B, H, W),

@@ -623,3 +623,31 @@ def test_g9_full_width_layers_on_hip(golden):
     xg = torch.randn(2, 512, 8, 8, device=DEV).to(memory_format=torch.channels_last).requires_grad_(True)
     dw(xg).sum().backward()
     assert xg.grad is not None and dw.weight.grad is not None
+
+
+@pytest.mark.parametrize("case", [(64, 128, 3, 2, 1, 13, 21), (128, 128, 3, 2, 1, 16, 16), (256, 128, 1, 2, 0, 10, 10), (64, 32, 1, 2, 0, 7, 9),
+                                  (32, 64, 3, 2, 1, 2, 2)])
+def test_conv_dgrad_strided_parity_classes(case):
+    """Data gradient of the trunk's strided layers (3x3 s2 pad 1, 1x1 s2) on the conv kernel: one stride-1 launch per parity
+    class of dX, outputs interleaved by the epilogue's scatter -- against torch autograd; with a folded BN scale and a ReLU
+    mask in the epilogue as the fused bottleneck backward uses them."""
+    Cin, Cout, k, s, pad, H, W = case
+    gen = torch.Generator().manual_seed(sum(case))
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=gen).requires_grad_(True)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout, generator=gen) + 0.5
+    y = F.conv2d(x, w * scale.view(-1, 1, 1, 1), None, s, pad)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    Ho, Wo = y.shape[2:]
+    dx = torch.zeros(B * H * W, Cin, device=DEV)
+    assert ops.conv_dgrad_strided(to_rows(dy), w.to(DEV), scale.to(DEV), ops.Rows(dx), B, H, W, k, s, pad)
+    ref = x.grad
+    sc = float(ref.abs().max())
+    np.testing.assert_allclose(from_rows(ops.Rows(dx), B, H, W).numpy() / sc, ref.numpy() / sc, atol=2e-5)
+    if k == 3:      # ReLU mask of the layer input applied in the class launches' epilogues
+        mask_src = torch.randn(B, Cin, H, W, generator=gen)
+        dx2 = torch.empty(B * H * W, Cin, device=DEV)
+        assert ops.conv_dgrad_strided(to_rows(dy), w.to(DEV), scale.to(DEV), ops.Rows(dx2), B, H, W, k, s, pad, res=to_rows(mask_src), res_mask=True)
+        np.testing.assert_allclose(from_rows(ops.Rows(dx2), B, H, W).numpy() / sc, (ref * (mask_src > 0)).numpy() / sc, atol=2e-5)
