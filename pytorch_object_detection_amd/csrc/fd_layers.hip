@@ -617,40 +617,56 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     }
 }
 
+// pass 1b: chunk partials -> (mean, rstd) per (level, image, group), once (the apply workgroups used to redo this sum each):
+// 256 threads = G-lanes x chunk-lanes, every chunk-lane adds its chunks in index order, lanes are combined in lane order
+__global__ __launch_bounds__(256) void gn_finalize_kernel(int C, int G, float eps, SegTab tab, const double* __restrict__ part,
+                                                           double* __restrict__ gstat) {
+    __shared__ double s_a[256], s_b[256];
+    const int img = blockIdx.y;
+    const int s = img / tab.s.batch;
+    const int HW = tab.s.H[s] * tab.s.W[s];
+    const int nchunk = min(GN_MAXCHUNK, (HW + 63) / 64);
+    const int GL = 16, CL = 16;                      // 16 groups x 16 chunk lanes per workgroup
+    const int gl = threadIdx.x % GL, cl = threadIdx.x / GL;
+    const int g = blockIdx.x * GL + gl;
+    double a = 0, b = 0;
+    if (g < G)
+        for (int k = cl; k < nchunk; k += CL) {
+            const double* p = part + (((long)img * GN_MAXCHUNK + k) * G + g) * 2;
+            a += p[0]; b += p[1];
+        }
+    s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+    __syncthreads();
+    if (cl == 0 && g < G) {
+        for (int j = 1; j < CL; ++j) { a += s_a[j * GL + gl]; b += s_b[j * GL + gl]; }
+        const double cnt = (double)HW * (C / G);
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0) var = 0;
+        gstat[((long)img * G + g) * 2] = mean;
+        gstat[((long)img * G + g) * 2 + 1] = (double)(float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int x_cs, int x_co,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ y, int y_cs, int y_co, int C, int G, float eps,
-                                                        int act, SegTab tab, const double* __restrict__ part,
-                                                        double* __restrict__ gstat) {
+                                                        int act, SegTab tab, const double* __restrict__ gstat) {
     __shared__ float s_a[1024], s_b[1024];  // per-channel scale / bias
     const int img = blockIdx.y;
     const int s = img / tab.s.batch, n = img - s * tab.s.batch;
     const int HW = tab.s.H[s] * tab.s.W[s];
-    const int nchunk = min(GN_MAXCHUNK, (HW + 63) / 64);
     const int nblk = gridDim.x;
     const int rows_per = (HW + nblk - 1) / nblk;
     const int r_begin = blockIdx.x * rows_per, r_end = min(HW, r_begin + rows_per);
     if (r_begin >= r_end) return;
     const int cg = C / G, tid = threadIdx.x;
     for (int c = tid; c < C; c += 256) {
-        const int g = c / cg;
-        double a = 0, b = 0;
-        for (int k = 0; k < nchunk; ++k) {
-            const double* p = part + (((long)img * GN_MAXCHUNK + k) * G + g) * 2;
-            a += p[0]; b += p[1];
-        }
-        const double cnt = (double)HW * cg;
-        const double mean = a / cnt;
-        double var = b / cnt - mean * mean;
-        if (var < 0) var = 0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const double* p = gstat + ((long)img * G + c / cg) * 2;
+        const float rstd = (float)p[1];
         const float sc = rstd * gamma[c];
         s_a[c] = sc;
-        s_b[c] = beta[c] - (float)mean * sc;
-        if (blockIdx.x == 0 && c == g * cg) {          // kept for the backward pass (fd_groupnorm_act_bwd_nhwc)
-            gstat[((long)img * G + g) * 2] = mean;
-            gstat[((long)img * G + g) * 2 + 1] = (double)rstd;
-        }
+        s_b[c] = beta[c] - (float)p[0] * sc;
     }
     __syncthreads();
     const int C4 = C >> 2;
@@ -692,9 +708,13 @@ extern "C" int32_t fd_groupnorm_act_nhwc(const float* x, int32_t x_cs, int32_t x
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, imgs), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, C, G, tab,
                        (double*)workspace);
     FD_CHECK_LAUNCH("fd_groupnorm (partial)");
+    double* gstat = (double*)workspace + (long)imgs * GN_MAXCHUNK * G * 2;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((G + 15) / 16, imgs), dim3(256), 0, (hipStream_t)stream, C, G, eps, tab,
+                       (const double*)workspace, gstat);
+    FD_CHECK_LAUNCH("fd_groupnorm (finalize)");
     const int ablk = max(1, min(imgs >= 16 ? 64 : 512, (maxhw * (C / 4) + 2047) / 2048));
     hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, imgs), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, gamma, beta, y,
-                       y_cs, y_co, C, G, eps, act, tab, (const double*)workspace, (double*)workspace + (long)imgs * GN_MAXCHUNK * G * 2);
+                       y_cs, y_co, C, G, eps, act, tab, (const double*)gstat);
     FD_CHECK_LAUNCH("fd_groupnorm (apply)");
     return FD_OK;
 }
@@ -831,15 +851,20 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const double* __restrict__ part, double* __restrict__ img_sums, int C,
                                                              SegTab tab) {
-    const int img = blockIdx.x;
+    // 64 columns (of the 2C per-channel sums) x 4 chunk lanes per workgroup; chunk lanes add in index order, then lane order
+    __shared__ double s_p[256];
+    const int img = blockIdx.y;
     const int s = img / tab.s.batch;
     const int HW = tab.s.H[s] * tab.s.W[s];
     const int nchunk = min(GN_MAXCHUNK, (HW + 63) / 64);
-    for (int c = threadIdx.x; c < 2 * C; c += 256) {
-        double a = 0;
-        for (int k = 0; k < nchunk; ++k) a += part[((long)img * GN_MAXCHUNK + k) * 2 * C + c];
-        img_sums[(long)img * 2 * C + c] = a;
-    }
+    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double a = 0;
+    if (c < 2 * C)
+        for (int k = kl; k < nchunk; k += 4) a += part[((long)img * GN_MAXCHUNK + k) * 2 * C + c];
+    s_p[threadIdx.x] = a;
+    __syncthreads();
+    if (kl == 0 && c < 2 * C) img_sums[(long)img * 2 * C + c] = ((a + s_p[64 + cl]) + s_p[128 + cl]) + s_p[192 + cl];
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const double* __restrict__ img_sums, float* __restrict__ dgamma,
@@ -884,7 +909,7 @@ extern "C" int32_t fd_groupnorm_act_bwd_nhwc(const float* x, int32_t x_cs, int32
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, imgs), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, gamma, beta, C,
                        G, eps, act, tab, gstat, part);
     FD_CHECK_LAUNCH("fd_groupnorm_bwd (partial)");
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(imgs), dim3(256), 0, st, (const double*)part, img_sums, C, tab);
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((2 * C + 63) / 64, imgs), dim3(256), 0, st, (const double*)part, img_sums, C, tab);
     FD_CHECK_LAUNCH("fd_groupnorm_bwd (reduce)");
     const int ablk = max(1, min(imgs >= 16 ? 64 : 512, (maxhw * (C / 4) + 2047) / 2048));
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ablk, imgs), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, gamma, beta, dx,
@@ -1047,68 +1072,72 @@ __global__ __launch_bounds__(256) void se_dgate_kernel(const float* __restrict__
     }
 }
 
+// per image: dz, s = silu(h), dh, dm (one workgroup each) ...
 __global__ __launch_bounds__(256) void se_bwd_fc_kernel(const double* __restrict__ fpart, const float* __restrict__ gate,
-                                                         const double* __restrict__ dpart, int nchunk, int N, int HW, int C, int Cr,
+                                                         const double* __restrict__ dpart, int nchunk, int HW, int C, int Cr,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
-                                                         const float* __restrict__ w2, const float* __restrict__ b2,
-                                                         float* __restrict__ dmean, float* __restrict__ dw1, float* __restrict__ db1,
-                                                         float* __restrict__ dw2, float* __restrict__ db2) {
+                                                         const float* __restrict__ w2, float* __restrict__ dmean,
+                                                         float* __restrict__ vec) {   // vec[n]: m[C] | dz[C] | s[Cr] | dh[Cr]
     __shared__ float s_m[SE_MAXC], s_dz[SE_MAXC];
-    __shared__ float s_h[SE_MAXCR], s_s[SE_MAXCR], s_dh[SE_MAXCR];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int i = tid; i < C * Cr; i += 256) { dw1[i] = 0.f; dw2[i] = 0.f; }
-    for (int i = tid; i < Cr; i += 256) db1[i] = 0.f;
-    for (int i = tid; i < C; i += 256) db2[i] = 0.f;
-    __syncthreads();
-    for (int n = 0; n < N; ++n) {
-        for (int c = tid; c < C; c += 256) {
-            double a = 0, d = 0;
-            for (int k = 0; k < nchunk; ++k) {
-                a += fpart[((long)n * SE_MAXCHUNK + k) * C + c];
-                d += dpart[((long)n * SE_MAXCHUNK + k) * C + c];
-            }
-            s_m[c] = (float)(a / (double)HW);
-            const float g = gate[(long)n * C + c];
-            const float dz = (float)d * g * (1.f - g);
-            s_dz[c] = dz;
-            db2[c] += dz;
+    __shared__ float s_h[SE_MAXCR], s_dh[SE_MAXCR];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* vm = vec + (long)n * (2 * C + 2 * Cr);
+    float* vdz = vm + C; float* vs = vdz + C; float* vdh = vs + Cr;
+    for (int c = tid; c < C; c += 256) {
+        double a = 0, d = 0;
+        for (int k = 0; k < nchunk; ++k) {
+            a += fpart[((long)n * SE_MAXCHUNK + k) * C + c];
+            d += dpart[((long)n * SE_MAXCHUNK + k) * C + c];
         }
-        __syncthreads();
-        for (int j = wv; j < Cr; j += 4) {       // h = W1 m + b1 (same lane split and shuffle tree as the forward)
-            float a = 0.f;
-            const float* wr = w1 + (long)j * C;
-            for (int c = lane; c < C; c += 64) a = fmaf(wr[c], s_m[c], a);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-            if (lane == 0) { const float h = a + (b1 ? b1[j] : 0.f); s_h[j] = h; s_s[j] = fd_act(h, FD_ACT_SILU, 0.f); }
-        }
-        __syncthreads();
-        for (int j = wv; j < Cr; j += 4) {       // ds[j] = sum_c W2[c][j] dz[c];  dh = ds * silu'(h)
-            float a = 0.f;
-            for (int c = lane; c < C; c += 64) a = fmaf(w2[(long)c * Cr + j], s_dz[c], a);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-            if (lane == 0) {
-                const float h = s_h[j], sg = fd_sigmoid(h);
-                const float dh = a * (sg * (1.f + h * (1.f - sg)));
-                s_dh[j] = dh;
-                db1[j] += dh;
-            }
-        }
-        __syncthreads();
-        for (int c = tid; c < C; c += 256) {     // dm[c] = sum_j W1[j][c] dh[j]
-            float a = 0.f;
-            for (int j = 0; j < Cr; ++j) a = fmaf(w1[(long)j * C + c], s_dh[j], a);
-            dmean[(long)n * C + c] = a;
-        }
-        for (int i = tid; i < C * Cr; i += 256) {
-            const int c2 = i / Cr, j2 = i - c2 * Cr;     // dW2[c][j] += dz[c] s[j]
-            dw2[i] += s_dz[c2] * s_s[j2];
-            const int j1 = i / C, c1 = i - j1 * C;       // dW1[j][c] += dh[j] m[c]
-            dw1[i] += s_dh[j1] * s_m[c1];
-        }
-        __syncthreads();
+        const float m = (float)(a / (double)HW);
+        const float g = gate[(long)n * C + c];
+        const float dz = (float)d * g * (1.f - g);
+        s_m[c] = m; s_dz[c] = dz; vm[c] = m; vdz[c] = dz;
     }
+    __syncthreads();
+    for (int j = wv; j < Cr; j += 4) {       // h = W1 m + b1 (same lane split and shuffle tree as the forward)
+        float a = 0.f;
+        const float* wr = w1 + (long)j * C;
+        for (int c = lane; c < C; c += 64) a = fmaf(wr[c], s_m[c], a);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        float ds = 0.f;                      // ds[j] = sum_c W2[c][j] dz[c]
+        for (int c = lane; c < C; c += 64) ds = fmaf(w2[(long)c * Cr + j], s_dz[c], ds);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ds += __shfl_xor(ds, o);
+        if (lane == 0) {
+            const float h = a + (b1 ? b1[j] : 0.f), sg = fd_sigmoid(h);
+            const float dh = ds * (sg * (1.f + h * (1.f - sg)));
+            s_h[j] = h; s_dh[j] = dh;
+            vs[j] = fd_act(h, FD_ACT_SILU, 0.f); vdh[j] = dh;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {     // dm[c] = sum_j W1[j][c] dh[j]
+        float a = 0.f;
+        for (int j = 0; j < Cr; ++j) a = fmaf(w1[(long)j * C + c], s_dh[j], a);
+        dmean[(long)n * C + c] = a;
+    }
+}
+
+// ... then the parameter gradients, images added in index order: dW2[c][j] = sum_n dz s^T, dW1[j][c] = sum_n dh m^T, db2, db1
+__global__ __launch_bounds__(256) void se_bwd_param_kernel(const float* __restrict__ vec, int N, int C, int Cr, float* __restrict__ dw1,
+                                                            float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int stride = 2 * C + 2 * Cr;
+    if (i < C * Cr) {
+        const int c2 = i / Cr, j2 = i - c2 * Cr;
+        const int j1 = i / C, c1 = i - j1 * C;
+        float a2 = 0.f, a1 = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float* v = vec + (long)n * stride;
+            a2 = fmaf(v[C + c2], v[2 * C + j2], a2);
+            a1 = fmaf(v[2 * C + Cr + j1], v[c1], a1);
+        }
+        dw2[i] = a2; dw1[i] = a1;
+    }
+    if (i < C) { float a = 0.f; for (int n = 0; n < N; ++n) a += vec[(long)n * stride + C + i]; db2[i] = a; }
+    if (i < Cr) { float a = 0.f; for (int n = 0; n < N; ++n) a += vec[(long)n * stride + 2 * C + Cr + i]; db1[i] = a; }
 }
 
 __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int dy_co, const float* __restrict__ gate,
@@ -1127,8 +1156,8 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restri
 }
 
 extern "C" int64_t fd_se_bwd_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
-    if (N < 1 || HW < 1 || C < 1) return -1;
-    return (int64_t)N * SE_MAXCHUNK * C * (int64_t)sizeof(double) + (int64_t)N * C * (int64_t)sizeof(float);
+    if (N < 1 || HW < 1 || C < 1) return -1;       // chunk sums of dy*x | dmean[N][C] | per-image vectors m, dz, s, dh (<= 4C floats)
+    return (int64_t)N * SE_MAXCHUNK * C * (int64_t)sizeof(double) + (int64_t)N * C * 5 * (int64_t)sizeof(float);
 }
 
 extern "C" int32_t fd_se_scale_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs, int32_t dy_co,
@@ -1152,9 +1181,13 @@ extern "C" int32_t fd_se_scale_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_
     hipLaunchKernelGGL(se_dgate_kernel, dim3(nchunk, N, (C / 4 + QW - 1) / QW), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, HW, C, nchunk,
                        QW, dpart);
     FD_CHECK_LAUNCH("fd_se_scale_bwd (dgate)");
-    hipLaunchKernelGGL(se_bwd_fc_kernel, dim3(1), dim3(256), 0, st, fpart, gate, (const double*)dpart, nchunk, N, HW, C, Cr, w1, b1, w2, b2,
-                       dmean, dw1, db1, dw2, db2);
+    FD_REQUIRE(Cr <= C, FD_E_UNSUPPORTED, "fd_se_scale_bwd: Cr=%d > C=%d", Cr, C);
+    float* vec = dmean + (size_t)N * C;
+    hipLaunchKernelGGL(se_bwd_fc_kernel, dim3(N), dim3(256), 0, st, fpart, gate, (const double*)dpart, nchunk, HW, C, Cr, w1, b1, w2, dmean, vec);
     FD_CHECK_LAUNCH("fd_se_scale_bwd (fc)");
+    hipLaunchKernelGGL(se_bwd_param_kernel, dim3((C * Cr + 255) / 256), dim3(256), 0, st, (const float*)vec, N, C, Cr, dw1, db1, dw2, db2);
+    FD_CHECK_LAUNCH("fd_se_scale_bwd (params)");
+    (void)b2;
     const long total = (long)N * HW * (C / 4);
     hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dy, dy_cs, dy_co, gate, (const float*)dmean, dx, dx_cs,
                        dx_co, HW, C / 4, 1.0f / (float)HW, total);
