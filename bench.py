@@ -269,9 +269,12 @@ def train_step(dev, batch: int = 16, size: int = 512, steps: int = 5):
         opt.step()
         return float(losses[-1].detach())
 
-    res = {"batch": batch, "size": size, "classes": 20, "gt_boxes_per_image": 8, "loss": "giou", "optimizer": "SGD"}
-    for name, stock in (("hip_ms", False), ("stock_ops_ms", True)):
+    res = {"batch": batch, "size": size, "classes": 20, "gt_boxes_per_image": 8, "loss": "giou", "optimizer": "SGD",
+           "batchnorm": "backbone frozen (eval), FPN BatchNorms on batch statistics as under the reference's model.train() (train.py:151)"}
+    for name, stock, freeze_all in (("hip_ms", False, False), ("stock_ops_ms", True, False), ("hip_all_bn_frozen_ms", False, True)):
         train_ops._STOCK = stock
+        model.freeze_all_bn = freeze_all
+        model.train()
         try:
             for _ in range(2):
                 one()
@@ -283,11 +286,12 @@ def train_step(dev, batch: int = 16, size: int = 512, steps: int = 5):
             res[name] = round((time.perf_counter() - t0) / steps * 1e3, 2)
         finally:
             train_ops._STOCK = False
+            model.freeze_all_bn = False
     res["images_per_sec"] = round(batch / (res["hip_ms"] * 1e-3), 1)
     return res
 
 
-def train_mode(args, rank, world, dev, use_dist):
+def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
     """`--mode train` (SURVEY Cfg4): the reference's train.py step on N GPUs -- DistributedDataParallel around the model
     (gradient all-reduce over RCCL, bucketed and overlapped with backward by DDP), HIP forward / backward / target /
     loss kernels, SGD.  Weak scaling: --batch images of --size per GPU (defaults 16 x 512 x 512, 20 classes: voc.yaml)."""
@@ -367,7 +371,7 @@ def train_mode(args, rank, world, dev, use_dist):
                      "instruction": "v_mfma_f32_32x32x2_f32", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                      "flops_per_launch": wflops, "avg_launch_ms": round(wms, 4)},
-        "final_loss": round(float(loss.detach()), 5)}), flush=True)
+        "final_loss": round(float(loss.detach()), 5)}), file=out, flush=True)
 
 
 def layer_times(plan, x, path, reps=5):
@@ -397,7 +401,17 @@ def layer_times(plan, x, path, reps=5):
         f.write(f"#total_ms\t{tot:.3f}\n")
 
 
+def _claim_stdout():
+    """Rank 0 must print ONE JSON line on stdout; RCCL writes its version banner to file descriptor 1 when the first
+    communicator comes up.  Keep a private handle on the real stdout for the JSON line and point fd 1 at stderr meanwhile."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
+    out = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -442,7 +456,7 @@ def main():
     if args.mode == "train":
         if args.size == 640 and args.classes == 80:      # untouched defaults -> the reference's VOC training shape
             args.size, args.classes = 512, 20
-        train_mode(args, rank, world, dev, use_dist)
+        train_mode(args, rank, world, dev, use_dist, out)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -556,7 +570,8 @@ def main():
             line["train_step"] = train_step(dev)
         if sd_cpu is not None:
             line["cpu_baseline"] = cpu_baseline(sd_cpu, args.classes, args.height)
-        print(json.dumps(line), flush=True)
+        out.write(json.dumps(line) + "\n")
+        out.flush()
     if use_dist:
         dist.destroy_process_group()
 
