@@ -59,9 +59,9 @@ def pmc_traffic():
     for batch 16 / 640x640."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return d["head_tower_conv"]["hbm_bytes_per_launch"]
+        return d["head_tower_conv"]["hbm_bytes_per_launch"], f"profiles/{d.get('tag', '?')}_pmc_summary.json"
     except Exception:
-        return None
+        return None, None
 
 
 def usable_cores() -> int:
@@ -554,7 +554,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<...,TAG=1> head tower 3x3 (cls_conv+reg_conv fused, 5 levels, tile id %d)" % plan.tiles.get("head.tower3x3", 0),
                          "instruction": "v_mfma_f32_32x32x2_f32", "achieved": round(achieved, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": pmc_traffic(), "flops_per_launch": tower_flops, "avg_launch_ms": round(tower_ms, 4)},
+                         "traffic": pmc_traffic()[0], "traffic_source": pmc_traffic()[1],
+                         "flops_per_launch": tower_flops, "avg_launch_ms": round(tower_ms, 4)},
             "model_conv_tflops": round(plan.flops / (ms_step * 1e-3) / 1e12, 2),
             "nms_boxes_per_ms": round(args.batch * 1000 / nms_ms, 1), "nms_ms": round(nms_ms, 4),
             "detections_kept_rank0": [int(v) for v in res[3][:args.batch].tolist()][:4],

@@ -40,7 +40,23 @@ gf = [v for v in fe if "gn_apply" in v["name"]]
 gw = [v for v in wr if "gn_apply" in v["name"]]
 if gf and gw:
     cal = gf[0]["c"]["FETCH_SIZE"] / gw[0]["c"]["WRITE_SIZE"]
-out = {"head_tower_conv": {"kernel": f[0]["name"], "launches": len(f), "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
+def biggest(rows, key):
+    ks = [v for v in rows if key in v["name"]]
+    return max(ks, key=lambda v: v["grid"]) if ks else None
+
+
+dec_f, dec_w = biggest(fe, "decode_coalesced"), biggest(wr, "decode_coalesced")
+decode = None
+if dec_f and dec_w:
+    decode = {"kernel": dec_f["name"], "grid": dec_f["grid"], "FETCH_SIZE_KiB": dec_f["c"]["FETCH_SIZE"], "WRITE_SIZE_KiB": dec_w["c"]["WRITE_SIZE"],
+              "hbm_bytes_per_launch": int((2 * dec_f["c"]["FETCH_SIZE"] + dec_w["c"]["WRITE_SIZE"]) * 1024),
+              "algorithmic_bytes_batch16_640": 16 * 8525 * (85 * 4 + 24)}
+import subprocess
+try:
+    commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    commit = None
+out = {"tag": tag, "commit_of_the_working_tree_summarised": commit, "decode_kernel_largest_launch": decode, "head_tower_conv": {"kernel": f[0]["name"], "launches": len(f), "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
                            "hbm_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024),
                            "mfma_busy_frac": sum(util) / len(util), "clock_ghz": sum(clk) / len(clk),
                            "avg_dur_ms_under_pmc": sum(v["dur_ns"] for v in q) / len(q) / 1e6},
