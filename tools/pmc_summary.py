@@ -52,10 +52,11 @@ if dec_f and dec_w:
               "hbm_bytes_per_launch": int((2 * dec_f["c"]["FETCH_SIZE"] + dec_w["c"]["WRITE_SIZE"]) * 1024),
               "algorithmic_bytes_batch16_640": 16 * 8525 * (85 * 4 + 24)}
 import subprocess
+import os
 try:
-    commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+    commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
 except Exception:
-    commit = None
+    commit = os.environ.get("FD_COMMIT")          # (the GPU box has no .git: tools/gpu_*.sh pass the hash along)
 out = {"tag": tag, "commit_of_the_working_tree_summarised": commit, "decode_kernel_largest_launch": decode, "head_tower_conv": {"kernel": f[0]["name"], "launches": len(f), "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
                            "hbm_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024),
                            "mfma_busy_frac": sum(util) / len(util), "clock_ghz": sum(clk) / len(clk),
