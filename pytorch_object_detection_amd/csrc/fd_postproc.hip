@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
 //      instead of C); equal or nearly equal logits, or a saturating L, widen the set -- up to every class -- and the first
 //      maximal SIGMOID value wins exactly as in the plain kernel (torch.max semantics, head.py:61-62).
 #define DEC_MAXQ 64
-#define DEC_LPW 32
+#define DEC_LPW 16     /* locations per wave: 64 / DEC_LPW lanes share one location in the scan */
 __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dec_smem[];
     const int Q = a.C >> 2, QP = Q | 1;             // row stride in float4 (odd: conflict-free ds_read_b128 across lanes)
@@ -88,9 +88,10 @@ __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
     const int loc0 = (blockIdx.x * 4 + wv) * DEC_LPW;
     if (loc0 >= a.L) return;                        // whole wave out of range (no workgroup barrier below)
     const int nloc = min(DEC_LPW, a.L - loc0);
-    // lanes l and l + 32 share location l (each scans half of its row below); lanes past nloc shadow the last location and
-    // store nothing.  Centre-ness / regression loads are issued before the class sweep.
-    const int lid = lane & 31, half = lane >> 5;
+    // lanes l, l + 16, l + 32, l + 48 share location l (each scans a quarter of its row below); lanes past nloc shadow the
+    // last location and store nothing.  Centre-ness / regression loads are issued before the class sweep.
+    constexpr int PARTS = 64 / DEC_LPW;
+    const int lid = lane % DEC_LPW, part = lane / DEC_LPW;
     const int myloc = loc0 + min(lid, nloc - 1);
     int ms = 0;
 #pragma unroll
@@ -104,29 +105,45 @@ __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
     const float rl = rp[0], rt = rp[1], rr = rp[2], rb = rp[3];
 
     const int items = nloc * Q;
-    constexpr int DEC_U = 10;
+    // DEC_U loads are issued back to back before the first LDS write (a plain loop waits for every load in turn: latency-
+    // bound).  Item i = lane + 64*k -> (location i / Q, quad i % Q) advances without divisions: (lo, q) += (64 / Q, 64 % Q)
+    // with a carry (integer divisions and 64-bit multiplies per item made this phase VALU-bound).
+    constexpr int DEC_U = 5;
+    const int d64 = 64 / Q, r64 = 64 - d64 * Q;
+    int lo = lane / Q, q = lane - lo * Q;
+    // the wave's locations normally sit in ONE pyramid level: its row base is wave-uniform (scalar), a location costs one add
+    int s_first = 0, s_last = 0;
+#pragma unroll
+    for (int t = 1; t < FD_MAX_SEG; ++t) {
+        if (t < a.segs.nseg && loc0 >= a.loc_start[t]) s_first = t;
+        if (t < a.segs.nseg && loc0 + nloc - 1 >= a.loc_start[t]) s_last = t;
+    }
+    const bool one_level = s_first == s_last;
+    const int row_base = a.segs.m_start[s_first] + n * (a.segs.H[s_first] * a.segs.W[s_first]) - a.loc_start[s_first] + loc0;
     for (int i0 = lane; i0 < items; i0 += 64 * DEC_U) {
         float4 v[DEC_U];
-#pragma unroll
-        for (int u = 0; u < DEC_U; ++u) {             // (index clamped, store predicated: keeps v[] in registers)
-            const int i = min(i0 + 64 * u, items - 1);
-            const int lo = i / Q, q = i - lo * Q;
-            const int loc = loc0 + lo;
-            int s = 0;
-#pragma unroll
-            for (int t = 1; t < FD_MAX_SEG; ++t)
-                if (t < a.segs.nseg && loc >= a.loc_start[t]) s = t;
-            const long m = (long)a.segs.m_start[s] + (long)n * (a.segs.H[s] * a.segs.W[s]) + (loc - a.loc_start[s]);
-            v[u] = *reinterpret_cast<const float4*>(a.cls + m * a.cls_cs + a.cls_co + 4 * q);
-        }
+        int slot[DEC_U];
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
-            const int i = i0 + 64 * u;
-            if (i < items) {
-                const int lo = i / Q, q = i - lo * Q;
-                rows[lo * QP + q] = v[u];
+            const bool ok = i0 + 64 * u < items;
+            const int lc = ok ? lo : nloc - 1, qc = ok ? q : 0;     // (clamped: the load stays in range, the store is predicated)
+            int row = row_base + lc;                                                                     // < 2^31 rows
+            if (!one_level) {                                    // (uniform branch: a wave that straddles a level boundary)
+                const int loc = loc0 + lc;
+                int s = 0;
+#pragma unroll
+                for (int t = 1; t < FD_MAX_SEG; ++t)
+                    if (t < a.segs.nseg && loc >= a.loc_start[t]) s = t;
+                row = a.segs.m_start[s] + n * (a.segs.H[s] * a.segs.W[s]) + (loc - a.loc_start[s]);
             }
+            v[u] = *reinterpret_cast<const float4*>(a.cls + (long)row * a.cls_cs + a.cls_co + 4 * qc);
+            slot[u] = ok ? lc * QP + qc : -1;
+            q += r64; lo += d64;
+            if (q >= Q) { q -= Q; ++lo; }
         }
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u)
+            if (slot[u] >= 0) rows[slot[u]] = v[u];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes have landed
@@ -136,7 +153,7 @@ __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
         // one pass over the row, split between the two lanes of a location: largest logit L with its FIRST index, and the
         // second largest value (compare-only)
         const float4* row = rows + lid * QP;
-        const int q0 = half ? (Q >> 1) : 0, q1 = half ? Q : (Q >> 1);
+        const int q0 = part * Q / PARTS, q1 = (part + 1) * Q / PARTS;
         float L = -INFINITY, L2 = -INFINITY;
         int li = 0;
         for (int q = q0; q < q1; ++q) {
@@ -148,12 +165,15 @@ __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
                 else L2 = fmaxf(L2, e[c]);
             }
         }
-        const float oL = __shfl_xor(L, 32), oL2 = __shfl_xor(L2, 32);
-        const int oli = __shfl_xor(li, 32);
-        // lower half holds the lower class indices: it wins ties
-        const bool take_other = half ? (oL >= L) : (oL > L);
-        L2 = fmaxf(fmaxf(L2, oL2), take_other ? L : oL);
-        if (take_other) { L = oL; li = oli; }
+#pragma unroll
+        for (int o = DEC_LPW; o < 64; o <<= 1) {         // combine the parts; the part with the lower class indices wins ties
+            const float oL = __shfl_xor(L, o), oL2 = __shfl_xor(L2, o);
+            const int oli = __shfl_xor(li, o);
+            const bool upper = (lane & o) != 0;
+            const bool take_other = upper ? (oL >= L) : (oL > L);
+            L2 = fmaxf(fmaxf(L2, oL2), take_other ? L : oL);
+            if (take_other) { L = oL; li = oli; }
+        }
         // classes whose COMPUTED sigmoid could reach the computed sigmoid(L): fd_sigmoid is good to a few ulp, so only logits
         // within ~8 ulp(s) / s'(L) = 9.5e-7 (1 + e^L) of L (doubled below) -- just the maximum unless logits are (nearly) equal
         const float cut = (L < 80.0f) ? L - 2.0e-6f * (1.0f + expf(L)) : -INFINITY;   // (e^L overflows: every class is a candidate)
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
         if (L2 < cut) {
             best = fd_sigmoid(L);
             besti = li;
-        } else if (half == 0 && lid < nloc) {           // rare: evaluate every candidate, first maximal sigmoid wins (head.py:62)
+        } else if (part == 0 && lid < nloc) {           // rare: evaluate every candidate, first maximal sigmoid wins (head.py:62)
             for (int q = 0; q < Q; ++q) {
                 const float4 v = row[q];
                 if (v.x >= cut) { const float sv = fd_sigmoid(v.x); if (sv > best) { best = sv; besti = 4 * q; } }
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(256) void decode_coalesced_kernel(DecodeArgs a) {
                 if (v.w >= cut) { const float sv = fd_sigmoid(v.w); if (sv > best) { best = sv; besti = 4 * q + 3; } }
             }
         }                                               // a row of NaNs: L = -inf, nothing >= cut -> best = -1, class 1 (plain kernel)
-        if (half != 0 || lid >= nloc) return;
+        if (part != 0 || lid >= nloc) return;
         const float score = sqrtf(best * fd_sigmoid(cnt_logit));
         const int py = mypix / mW, px = mypix - py * mW;
         const int st = a.stride[ms];
@@ -246,66 +266,122 @@ __device__ __forceinline__ void bitonic_desc_1024(unsigned long long* c, int tid
     }
 }
 
+// descending bitonic sort of 1024 u64, ONE element per thread in a register: exchanges with a partner in the same wave
+// (j < 64) go through __shfl_xor, only the 10 steps with j >= 64 go through LDS (the all-LDS form above takes 55 barriers)
+__device__ __forceinline__ unsigned long long bitonic_desc_1024_reg(unsigned long long x, unsigned long long* c, int tid) {
+    for (int k = 2; k <= 1024; k <<= 1) {
+        const bool desc = (tid & k) == 0;
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            unsigned long long y;
+            if (j >= 64) {
+                c[tid] = x;
+                __syncthreads();
+                y = c[tid ^ j];
+                __syncthreads();
+            } else {
+                const unsigned lo = __shfl_xor((unsigned)x, j), hi = __shfl_xor((unsigned)(x >> 32), j);
+                y = ((unsigned long long)hi << 32) | lo;
+            }
+            const bool lower = (tid & j) == 0;
+            x = (lower == desc) ? (x > y ? x : y) : (x < y ? x : y);
+        }
+    }
+    return x;
+}
+
+// Radix select of the K-th largest key in THREE passes (11 + 11 + 10 bits, 2048-bin LDS histogram; the digit is found by a
+// parallel suffix scan, not a serial walk), keys held in registers across the passes when L <= TOPK_MAXE * 1024 (one global
+// read of the scores instead of five), ordered compaction (ties: lower index first), register bitonic sort.
+#define TOPK_MAXE 24
+template <bool REG>
 __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ scores, const int* __restrict__ classes,
                                                      const float* __restrict__ boxes, int L, int K,
                                                      float* top_scores, long long* top_classes, float* top_boxes,
                                                      int* top_idx) {
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned wsum[16];
     __shared__ unsigned sh_prefix, sh_need, sh_gt, sh_eqbase;
     __shared__ unsigned wave_cnt[16];
     __shared__ unsigned long long cand[1024];
     const int n = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* s = scores + (long)n * L;
+    const int nE = (L + 1023) >> 10;
 
-    // ---- radix select (MSB first) ----
+    unsigned key[REG ? TOPK_MAXE : 1];
+    if constexpr (REG) {
+#pragma unroll
+        for (int e = 0; e < TOPK_MAXE; ++e) {
+            const int i = e * 1024 + tid;
+            key[e] = (e < nE && i < L) ? fd_order_key(s[i]) : 0u;
+        }
+    }
+    auto key_at = [&](int e, int i) -> unsigned { if constexpr (REG) return key[e]; else return fd_order_key(s[i]); };
+
     unsigned prefix = 0, maskbits = 0, need = (unsigned)K;
-    for (int pass = 3; pass >= 0; --pass) {
-        if (tid < 256) hist[tid] = 0;
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        const int sh = shifts[pass];
+        const unsigned dmask = (1u << widths[pass]) - 1u;
+        hist[tid] = 0; hist[tid + 1024] = 0;
         __syncthreads();
-        const int sh = 8 * pass;
-        for (int i = tid; i < L; i += 1024) {
-            const unsigned key = fd_order_key(s[i]);
-            if ((key & maskbits) == prefix) atomicAdd(&hist[(key >> sh) & 255u], 1u);
+        if constexpr (REG) {
+#pragma unroll
+            for (int e = 0; e < TOPK_MAXE; ++e) {
+                const int i = e * 1024 + tid;
+                if (e < nE && i < L && (key[e] & maskbits) == prefix) atomicAdd(&hist[(key[e] >> sh) & dmask], 1u);
+            }
+        } else {
+            for (int i = tid; i < L; i += 1024) {
+                const unsigned kk = fd_order_key(s[i]);
+                if ((kk & maskbits) == prefix) atomicAdd(&hist[(kk >> sh) & dmask], 1u);
+            }
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned cum = 0, nd = need;
-            int d = 255;
-            for (; d > 0; --d) {
-                const unsigned h = hist[d];
-                if (cum + h >= nd) break;
-                cum += h;
-            }
-            sh_prefix = prefix | ((unsigned)d << sh);
-            sh_need = nd - cum;
+        // thread t owns digits d0 = 2047 - 2t and d0 - 1 (descending); inclusive scan of the pair sums over threads
+        const int d0 = 2047 - 2 * tid;
+        const unsigned h0 = hist[d0], h1 = hist[d0 - 1];
+        unsigned incl = h0 + h1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        unsigned before = 0;
+        for (int w = 0; w < wv; ++w) before += wsum[w];
+        const unsigned excl = before + incl - (h0 + h1);
+        if (excl < need && need <= excl + h0 + h1) {          // exactly one thread: the K-th key's digit is here
+            if (need <= excl + h0) { sh_prefix = prefix | ((unsigned)d0 << sh); sh_need = need - excl; }
+            else { sh_prefix = prefix | ((unsigned)(d0 - 1) << sh); sh_need = need - excl - h0; }
         }
         __syncthreads();
         prefix = sh_prefix;
         need = sh_need;
-        maskbits |= 0xFFu << sh;
+        maskbits |= dmask << sh;
         __syncthreads();
     }
-    const unsigned T = prefix;              // K-th largest key
+    const unsigned T = prefix;                 // K-th largest key
     const unsigned n_gt = (unsigned)K - need;  // keys strictly above T; 'need' ties are taken lowest-index-first
 
     // ---- compaction ----
     cand[tid] = 0ull;
     if (tid == 0) { sh_gt = 0; sh_eqbase = 0; }
     __syncthreads();
-    const int lane = tid & 63, wv = tid >> 6;
-    for (int base = 0; base < L; base += 1024) {
-        const int i = base + tid;
-        unsigned key = 0;
+    for (int e = 0; e < nE; ++e) {
+        const int i = e * 1024 + tid;
+        unsigned kk = 0;
         bool gt = false, eq = false;
         if (i < L) {
-            key = fd_order_key(s[i]);
-            gt = key > T;
-            eq = key == T;
+            kk = REG ? key_at(e < TOPK_MAXE ? e : 0, i) : fd_order_key(s[i]);
+            gt = kk > T;
+            eq = kk == T;
         }
         if (gt) {
             const unsigned slot = atomicAdd(&sh_gt, 1u);
-            cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            cand[slot] = ((unsigned long long)kk << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
         }
         const unsigned long long bal = __ballot(eq);
         if (lane == 0) wave_cnt[wv] = (unsigned)__popcll(bal);
@@ -314,7 +390,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ sc
         for (int w = 0; w < wv; ++w) before += wave_cnt[w];
         const unsigned rank = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
         if (eq && rank < need)
-            cand[n_gt + rank] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            cand[n_gt + rank] = ((unsigned long long)kk << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
         __syncthreads();
         if (tid == 0) {
             unsigned tot = 0;
@@ -325,10 +401,10 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ sc
     }
 
     // ---- sort (score desc, index asc) ----
-    bitonic_desc_1024(cand, tid);
+    const unsigned long long mine = bitonic_desc_1024_reg(cand[tid], cand, tid);
 
     if (tid < K) {
-        const unsigned idx = 0xFFFFFFFFu - (unsigned)(cand[tid] & 0xFFFFFFFFull);
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(mine & 0xFFFFFFFFull);
         const long o = (long)n * K + tid;
         const long src = (long)n * L + idx;
         top_scores[o] = s[idx];
@@ -348,8 +424,12 @@ extern "C" int32_t fd_fcos_topk(const float* scores, const int32_t* classes, con
     FD_REQUIRE(N >= 1 && L >= 1 && K >= 1 && K <= L, FD_E_INVAL, "fd_fcos_topk: need 1 <= K <= L (K=%d L=%d)", K, L);
     FD_REQUIRE(K <= 1024, FD_E_UNSUPPORTED, "fd_fcos_topk: K=%d > 1024 not supported", K);
     FD_REQUIRE((((uintptr_t)boxes | (uintptr_t)top_boxes) & 15) == 0, FD_E_INVAL, "fd_fcos_topk: boxes not 16-byte aligned");
-    hipLaunchKernelGGL(topk_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, scores, classes, boxes, L, K,
-                       top_scores, (long long*)top_classes, top_boxes, top_idx);
+    if (L <= TOPK_MAXE * 1024)
+        hipLaunchKernelGGL(topk_kernel<true>, dim3(N), dim3(1024), 0, (hipStream_t)stream, scores, classes, boxes, L, K,
+                           top_scores, (long long*)top_classes, top_boxes, top_idx);
+    else
+        hipLaunchKernelGGL(topk_kernel<false>, dim3(N), dim3(1024), 0, (hipStream_t)stream, scores, classes, boxes, L, K,
+                           top_scores, (long long*)top_classes, top_boxes, top_idx);
     FD_CHECK_LAUNCH("fd_fcos_topk");
     return FD_OK;
 }
