@@ -438,6 +438,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 control flow on a ONE-GPU box (RCCL refuses two ranks on one device): FD_BENCH_BACKEND=gloo puts
+    # every rank on cuda:0 and carries the collectives through gloo.  Never a measurement; the driver's runs use RCCL.
+    backend = os.environ.get("FD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL (must precede HIP initialisation)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -451,7 +456,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.mode == "train":
         if args.size == 640 and args.classes == 80:      # untouched defaults -> the reference's VOC training shape
@@ -523,12 +531,12 @@ def main():
     if args.save_tuning and rank == 0:      # (after the warm-up: the two-lane plans and their "pair|" entries exist by now)
         ops.save_tune_table()
     if use_dist:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(**({"device_ids": [local_rank]} if backend == "nccl" else {}))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     res = run_steps(args.steps, True)
     if use_dist:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(**({"device_ids": [local_rank]} if backend == "nccl" else {}))
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if use_dist:

@@ -194,6 +194,8 @@ def save_tune_table() -> None:
 
 
 KSPLIT_MAX = 8
+import re as _re
+_BKEY = _re.compile(r"^(f16x3\|)?B(\d+)(\|.*)$")
 
 
 def heuristic_conv(M: int, Cout: int, KT: int, have_ws: bool) -> int:
@@ -272,7 +274,25 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
     if _TUNE_MODE != "force" and key in table:
         return apply(int(table[key]))
     if _TUNE_MODE == "0":
-        return apply(int(table[base]) if base in table else heuristic_conv(M, Cout, KT, bool(p.workspace)))
+        if base in table:
+            return apply(int(table[base]))
+        # the table is keyed by exact shape incl. batch: for another batch size take the measured choice of the nearest larger
+        # (else nearest smaller) batch of the same layer geometry, when its tile count says the same regime; else the heuristic
+        m = _BKEY.match(base)
+        if m:
+            pre, b0, rest = m.group(1) or "", int(m.group(2)), m.group(3)
+            near = []
+            for k2 in table:
+                m2 = _BKEY.match(k2)
+                if m2 and (m2.group(1) or "") == pre and m2.group(3) == rest:
+                    b2 = int(m2.group(2))
+                    near.append((abs(b2 - b0) + (0.5 if b2 < b0 else 0.0), b2, k2))
+            if near:
+                _, b2, k2 = min(near)
+                code = int(table[k2])
+                if 0.5 <= b0 / b2 <= 2.0 and (code >> 8) <= 1:        # (split-K factors depend on the tile count: not transferred)
+                    return apply(code)
+        return apply(heuristic_conv(M, Cout, KT, bool(p.workspace)))
     cands = [(0, 1)]
     for tid, (bm, bn) in _lib.TILES.items():
         padded = -(-Cout // bn) * bn
