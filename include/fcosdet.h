@@ -95,7 +95,15 @@ const char* fd_last_error(void);
 #define FD_TILE_256x128 10   /* 8 waves (512 threads), 4 x 2 wave tiles of 64 x 64 */
 #define FD_TILE_256x128_SB 11
 #define FD_TILE_128x96_SB 12
-#define FD_TILE_COUNT 12
+#define FD_TILE_128x128_PATCH 13 /* 3x3 stride-1 'same' convs only: the (128-row tile + halo) input patch is staged ONCE per
+                                    32-channel chunk in LDS and the 9 taps are formed from it (9x less L2 -> LDS traffic for
+                                    the activations); needs 128 + 2*dil*(W + 1) <= 320 rows, no split-K */
+#define FD_TILE_WINOGRAD 14 /* 3x3 stride-1 'same' convs (dilation 1 or 2), fp32: Winograd F(2x2, 3x3) on the fp32 MFMA -- 16 multiplies
+                               per (cin, cout) and 2x2 output tile instead of 36 (fd_conv_wino.hip).  `w` must be the
+                               fd_wino_pack_weights_f32 packing; Cin % 8 == 0, Cout % 4 == 0, 16-byte addressable y / res / scale /
+                               shift; same epilogue contract; the result differs from the direct kernel's fma chain by fp32
+                               rounding (~1e-6 relative), deterministically */
+#define FD_TILE_COUNT 14
 
 typedef struct fd_conv_params {
     const float* x;
@@ -136,6 +144,14 @@ typedef struct fd_conv_params {
 
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
 int64_t fd_conv_workspace_bytes(int64_t out_rows, int32_t Cout, int32_t ksplit);
+
+/* Weights for FD_TILE_WINOGRAD: OIHW fp32 [Cout][Cin][3][3] -> U = G g G^T (computed in double, rounded once) packed
+ * [ceil(Cout/32)][Cin/8][16 frequencies][32 cout][8 cin] (fd_wino_weight_bytes(Cout, Cin) bytes, zero rows past Cout).
+ * mode 0: forward weights.  mode 1: weights of the stride-1 data-gradient conv (output channels = Cin, reduction over Cout,
+ * Cout % 8 == 0): g'[ci][co][r][q] = g[co][ci][2-r][2-q] * (scale ? scale[co] : 1); buffer of fd_wino_weight_bytes(Cin, Cout). */
+int64_t fd_wino_weight_bytes(int32_t Cout, int32_t Cin);
+int32_t fd_wino_pack_weights_f32(const float* w, const float* scale, float* out, int32_t Cout, int32_t Cin, int32_t mode,
+                                 fd_stream_t stream);
 
 /* Convolution backward for the train step (reference train.py:175-181: scaler.scale(loss).backward() runs torch's
  * convolution_backward through cuDNN / MIOpen).

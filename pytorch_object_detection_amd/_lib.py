@@ -11,7 +11,10 @@ PREC_F32, PREC_F16X3 = 0, 1
 TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (128, 32), 6: (128, 96),
          7: (128, 128), 8: (128, 64), 9: (64, 128),   # 7-9: single-LDS-buffer variants
          10: (256, 128), 11: (256, 128),             # 8-wave tile (11: single LDS buffer)
-         12: (128, 96)}                              # 128x96, single LDS buffer
+         12: (128, 96),                              # 128x96, single LDS buffer
+         13: (128, 128)}                             # 128x128 with the 3x3 input patch staged in LDS (3x3 stride-1 'same' only)
+PATCH_TILE = 13
+WINO_TILE = 14      # Winograd F(2x2, 3x3) kernel (own weight packing: ops.pack_conv_weight_wino); not a member of TILES
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcosdet_hip.so")
@@ -84,6 +87,8 @@ _SIGS = {
     "fd_conv_wgrad_workspace_bytes": (_L, [_L, _I, _I, _I, _I]),
     "fd_pack_conv_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fd_pack_conv_weights_batch_f32": (_I, [_P, _I, _L, _P]),
+    "fd_wino_weight_bytes": (_L, [_I, _I]),
+    "fd_wino_pack_weights_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fd_conv2d_bwd_weight_f32": (_I, [C.POINTER(WgradParams), _P]),
     "fd_nchw3_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _P]),
     "fd_nhwc_to_nchw": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),

@@ -11,57 +11,7 @@
 //   Epilogue: y = act(acc*scale[n] + shift[n] + res), columns (n) on lanes -> 128-byte coalesced NHWC stores.
 //
 // Replaces nn.Conv2d(+BatchNorm2d eval)+ReLU/SiLU(+add) of the reference models (see include/fcosdet.h).
-#include "fd_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-#define FD_SPLIT_SCALE 2048.0f   // lo = (x - hi) * 2^11 keeps the low half in f16's normal range
-
-struct ConvArgs {
-    const float* x; const float* w; const float* scale; const float* shift; const float* res; float* y;
-    int x_cs, x_co, res_cs, res_co, y_cs, y_co;
-    int Cin, Cout, KW, stride, pad, dil, act, act_c0;
-    int M, KT, ntaps, Kpacked;
-    int nseg;
-    int H[FD_MAX_SEG], W[FD_MAX_SEG], Ho[FD_MAX_SEG], Wo[FD_MAX_SEG];
-    int m_in[FD_MAX_SEG];        // first input row of the segment
-    int m_out[FD_MAX_SEG + 1];   // first output row of the segment
-    float seg_param[FD_MAX_SEG];
-    int mtiles, ntiles;
-    int vec_epi;   // output / residual views are 16-byte addressable: transposed float4 epilogue
-    int is_gemm;   // 1x1 stride-1 unpadded conv: pure GEMM addressing
-    int Cout_epi;  // output-channel bound of the epilogue (= Cout, or the padded row length of a split-K slab)
-    int kt_per;    // K-tiles per split-K slice (blockIdx.y = slice); KT when split-K is off
-    long slice_stride;  // elements between consecutive split-K slabs in the workspace
-    unsigned x_bytes, w_bytes;   // extents of the input / packed-weight buffers (raw buffer descriptors: OOB reads return 0)
-    int res_mask;  // 1: `res` is a ReLU mask (y = res > 0 ? v : 0) instead of an addend
-    // output scatter (single level): output pixel (n, i, j) is written to row (n*sc_H + sc_sy*i + sc_oy)*sc_W + sc_sx*j + sc_ox of
-    // y (and reads `res` there): one parity class of the data gradient of a strided conv lands interleaved in dX
-    int sc_on, sc_sy, sc_sx, sc_oy, sc_ox, sc_H, sc_W;
-};
-
-__device__ __forceinline__ long out_row(const ConvArgs& a, int m) {
-    if (!a.sc_on) return m;
-    const int hw = a.Ho[0] * a.Wo[0];
-    const int n = m / hw, rem = m - n * hw;
-    const int i = rem / a.Wo[0], j = rem - i * a.Wo[0];
-    return ((long)n * a.sc_H + (a.sc_sy * i + a.sc_oy)) * a.sc_W + (a.sc_sx * j + a.sc_ox);
-}
-
-// LDS hand-off between lanes of ONE wave: the LDS pipe executes a wave's ds instructions in order, so later reads see
-// earlier writes once lgkmcnt has drained; the fence + wave barrier keep the compiler from moving accesses across.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
-// split-f16 planes: rows of 32 halves (64 B); c8 = 16-byte chunk (8 halves) 0..3, XOR-swizzled by (row>>2)&3
-__device__ __forceinline__ int lds_off_h(int row, int c8) { return row * 32 + ((c8 ^ ((row >> 2) & 3)) << 3); }
+#include "fd_conv_common.h"
 
 template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT>
 __global__ __launch_bounds__(WGM * WGN * 64, (TM * TN == 4) ? ((SPLIT || WGM * WGN == 8) ? 2 : (SB ? 3 : 1)) : 1)
@@ -285,110 +235,7 @@ void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // residual tile prefetch (vector epilogue): all 16-byte loads of the wave's tile issued back to back right after the K loop (they fly while the first sub-tile is staged)
-    float4 rres[SPLIT ? 1 : TM][SPLIT ? 1 : TN][4];
-    if (!SPLIT && a.res && a.vec_epi) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int m = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * p;
-                    const int nn = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
-                    rres[i][j][p] = (m < a.M && nn < a.Cout_epi)
-                                        ? *reinterpret_cast<const float4*>(a.res + (size_t)out_row(a, m) * a.res_cs + a.res_co + nn)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-    }
-    // ---- epilogue: acc reg e of lane l is C[row = (e&3) + 8*(e>>2) + 4*(l>>5)][col = l&31] ----
-    // Vector path: each 32x32 sub-tile is transposed through a per-wave LDS stage so that a lane owns 4 consecutive
-    // channels of one pixel: residual loads / output stores are 16 B per lane, 8 full 128-B lines per instruction
-    // (4x fewer memory instructions than storing straight from the accumulator layout).
-    if constexpr (SPLIT) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] += cor[i][j] * (1.0f / FD_SPLIT_SCALE);
-    }
-    float* stage = reinterpret_cast<float*>(smem) + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + (wn * TN + j) * 32;
-        const int n = nb + l31;
-        const bool n_ok = n < a.Cout_epi;
-        const float sc = (a.scale && n_ok) ? a.scale[n] : 1.0f;
-        const float sf = (a.shift && n_ok) ? a.shift[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm * TM + i) * 32;
-            if (a.vec_epi) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + l31] = acc[i][j][e] * sc + sf;
-                wave_lds_sync();     // the stage is private to this wave: no workgroup barrier needed
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int row = (lane >> 3) + 8 * p, c4 = (lane & 7) * 4;
-                    const int m = mb + row, nn = nb + c4;
-                    float4 v = *reinterpret_cast<const float4*>(stage + row * 32 + c4);
-                    if (m < a.M && nn < a.Cout_epi) {
-                        const size_t mo = (size_t)out_row(a, m);
-                        if (a.res) {
-                            float4 r;
-                            if constexpr (SPLIT) r = *reinterpret_cast<const float4*>(a.res + mo * a.res_cs + a.res_co + nn);
-                            else r = rres[i][j][p];
-                            if (a.res_mask) {
-                                v.x = r.x > 0.f ? v.x : 0.f; v.y = r.y > 0.f ? v.y : 0.f;
-                                v.z = r.z > 0.f ? v.z : 0.f; v.w = r.w > 0.f ? v.w : 0.f;
-                            } else {
-                                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                            }
-                        }
-                        if (a.act != FD_ACT_NONE) {
-                            float prm = 0.f;
-                            if (a.act == FD_ACT_EXP) {
-                                int s = 0;
-#pragma unroll
-                                for (int t = 1; t < FD_MAX_SEG; ++t)
-                                    if (t < a.nseg && m >= a.m_out[t]) s = t;
-                                prm = a.seg_param[s];
-                            }
-                            if (nn + 0 >= a.act_c0) v.x = fd_act(v.x, a.act, prm);
-                            if (nn + 1 >= a.act_c0) v.y = fd_act(v.y, a.act, prm);
-                            if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, prm);
-                            if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, prm);
-                        }
-                        *reinterpret_cast<float4*>(ybase + mo * a.y_cs + a.y_co + nn) = v;
-                    }
-                }
-                wave_lds_sync();
-            } else {
-                const int act = (n >= a.act_c0) ? a.act : FD_ACT_NONE;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mb + 4 * lh + (e & 3) + 8 * (e >> 2);
-                    if (n_ok && m < a.M) {
-                        const size_t mo = (size_t)out_row(a, m);
-                        float v = acc[i][j][e] * sc + sf;
-                        if (a.res) {
-                            const float r = a.res[mo * a.res_cs + a.res_co + n];
-                            v = a.res_mask ? (r > 0.f ? v : 0.f) : v + r;
-                        }
-                        float prm = 0.f;
-                        if (act == FD_ACT_EXP) {
-                            int s = 0;
-#pragma unroll
-                            for (int t = 1; t < FD_MAX_SEG; ++t)
-                                if (t < a.nseg && m >= a.m_out[t]) s = t;
-                            prm = a.seg_param[s];
-                        }
-                        ybase[mo * a.y_cs + a.y_co + n] = fd_act(v, act, prm);
-                    }
-                }
-            }
-        }
-    }
+#include "fd_conv_epilogue.inc"
 }
 
 // split-K combine: y = act(sum_slices(ws) * scale + shift + res); one float4 of output channels per thread, slices
@@ -477,6 +324,8 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
         FD_REQUIRE(p->stride == 1 && 2 * p->pad == p->dil * (p->KH - 1) && p->KH == p->KW, FD_E_INVAL,
                    "fd_conv2d: multi-level input needs stride 1 and 'same' padding");
 
+    if (p->tile == FD_TILE_WINOGRAD) return fd_launch_conv_wino(p, stream);   // own argument block, own weight packing
+
     ConvArgs a;
     a.x = p->x; a.w = p->w; a.scale = p->scale; a.shift = p->shift; a.res = p->res; a.y = p->y;
     a.x_cs = p->x_cs; a.x_co = p->x_co; a.res_cs = p->res_cs; a.res_co = p->res_co; a.y_cs = p->y_cs; a.y_co = p->y_co;
@@ -534,6 +383,17 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
             FD_REQUIRE((long)p->in.W[sg] * p->x_cs * 4 < (1L << 23), FD_E_UNSUPPORTED, "fd_conv2d: image row of %ld bytes exceeds the 24-bit row-stride path", (long)p->in.W[sg] * p->x_cs * 4);
     }
     a.Cout_epi = a.Cout; a.kt_per = a.KT; a.slice_stride = 0;
+    a.p_halo = 0;
+    if (p->tile == FD_TILE_128x128_PATCH) {     // 3x3 stride-1 'same' conv with the input patch staged in LDS (fd_conv_patch.hip)
+        int wmax = 0;
+        for (int sg = 0; sg < p->in.nseg; ++sg) wmax = p->in.W[sg] > wmax ? p->in.W[sg] : wmax;
+        FD_REQUIRE(!stem && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == p->dil && p->ksplit <= 1 && !a.sc_on &&
+                       p->out_H <= 0 && FD_PATCH_BM + 2 * p->dil * (wmax + 1) <= FD_PATCH_MAXROWS,
+                   FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_128x128_PATCH needs a 3x3 stride-1 'same' conv with 128 + 2*dil*(W+1) <= %d rows (W=%d dil=%d)",
+                   FD_PATCH_MAXROWS, wmax, p->dil);
+        a.p_halo = p->dil * (wmax + 1);
+        return fd_launch_conv_patch(a, p->tag == 1, p->precision == FD_PREC_F16X3, stream);
+    }
 
     const int ksplit = p->ksplit > 1 ? p->ksplit : 1;
     if (ksplit > 1) {

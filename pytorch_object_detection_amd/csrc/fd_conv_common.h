@@ -1,0 +1,61 @@
+// fd_conv_common.h -- what the implicit-GEMM conv kernels share: argument block, LDS swizzles, the fused epilogue.
+#pragma once
+#include "fd_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define FD_SPLIT_SCALE 2048.0f   // lo = (x - hi) * 2^11 keeps the low half in f16's normal range
+
+struct ConvArgs {
+    const float* x; const float* w; const float* scale; const float* shift; const float* res; float* y;
+    int x_cs, x_co, res_cs, res_co, y_cs, y_co;
+    int Cin, Cout, KW, stride, pad, dil, act, act_c0;
+    int M, KT, ntaps, Kpacked;
+    int nseg;
+    int H[FD_MAX_SEG], W[FD_MAX_SEG], Ho[FD_MAX_SEG], Wo[FD_MAX_SEG];
+    int m_in[FD_MAX_SEG];        // first input row of the segment
+    int m_out[FD_MAX_SEG + 1];   // first output row of the segment
+    float seg_param[FD_MAX_SEG];
+    int mtiles, ntiles;
+    int vec_epi;   // output / residual views are 16-byte addressable: transposed float4 epilogue
+    int is_gemm;   // 1x1 stride-1 unpadded conv: pure GEMM addressing
+    int Cout_epi;  // output-channel bound of the epilogue (= Cout, or the padded row length of a split-K slab)
+    int kt_per;    // K-tiles per split-K slice (blockIdx.y = slice); KT when split-K is off
+    long slice_stride;  // elements between consecutive split-K slabs in the workspace
+    unsigned x_bytes, w_bytes;   // extents of the input / packed-weight buffers (raw buffer descriptors: OOB reads return 0)
+    int res_mask;  // 1: `res` is a ReLU mask (y = res > 0 ? v : 0) instead of an addend
+    // output scatter (single level): output pixel (n, i, j) is written to row (n*sc_H + sc_sy*i + sc_oy)*sc_W + sc_sx*j + sc_ox of
+    // y (and reads `res` there): one parity class of the data gradient of a strided conv lands interleaved in dX
+    int sc_on, sc_sy, sc_sx, sc_oy, sc_ox, sc_H, sc_W;
+    int p_halo;    // patch kernel (fd_conv_patch.hip): input rows staged on either side of an M-tile = dil * (max level width + 1)
+};
+
+// fd_conv_patch.hip: 3x3 stride-1 'same' conv with the (tile + halo) input patch staged ONCE per 32-channel chunk in LDS
+#define FD_PATCH_BM 128
+#define FD_PATCH_MAXROWS 320     /* FD_PATCH_BM + 2 * halo <= this (W <= 95 at dilation 1, <= 47 at dilation 2) */
+int fd_launch_conv_patch(const ConvArgs& a, int tag, int split, hipStream_t stream);
+// fd_conv_wino.hip: 3x3 stride-1 'same' conv as Winograd F(2x2, 3x3) (FD_TILE_WINOGRAD; p->w is the fd_wino_pack_weights_f32 packing)
+int fd_launch_conv_wino(const fd_conv_params* p, hipStream_t stream);
+
+__device__ __forceinline__ long out_row(const ConvArgs& a, int m) {
+    if (!a.sc_on) return m;
+    const int hw = a.Ho[0] * a.Wo[0];
+    const int n = m / hw, rem = m - n * hw;
+    const int i = rem / a.Wo[0], j = rem - i * a.Wo[0];
+    return ((long)n * a.sc_H + (a.sc_sy * i + a.sc_oy)) * a.sc_W + (a.sc_sx * j + a.sc_ox);
+}
+
+// LDS hand-off between lanes of ONE wave: the LDS pipe executes a wave's ds instructions in order, so later reads see
+// earlier writes once lgkmcnt has drained; the fence + wave barrier keep the compiler from moving accesses across.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
+// split-f16 planes: rows of 32 halves (64 B); c8 = 16-byte chunk (8 halves) 0..3, XOR-swizzled by (row>>2)&3
+__device__ __forceinline__ int lds_off_h(int row, int c8) { return row * 32 + ((c8 ^ ((row >> 2) & 3)) << 3); }

@@ -1,0 +1,356 @@
+// fd_conv_wino.hip — 3x3 stride-1 'same' convolution (dilation 1 or 2) as Winograd F(2x2, 3x3) on the fp32 MFMA of gfx950.
+//
+// The direct implicit-GEMM kernel (fd_conv.hip) already runs the head tower at 92 % of what v_mfma_f32_32x32x2_f32 delivers at the
+// clock the chip holds (130 of ~141 TFLOP/s at 2.16 GHz): in exact fp32 the only lever left is executing fewer multiplies.
+// F(2x2, 3x3) computes a 2x2 output tile from a 4x4 input patch with 16 multiplies per (cin, cout) instead of 36:
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A          U = G g G^T is packed once per layer (fd_wino_pack_weights_f32),
+// so the conv becomes 16 independent GEMMs  M_f[tile][cout] = sum_c V_f[tile][c] * U_f[cout][c]  (f = frequency 0..15)
+// with 2.25x fewer MFMAs.  Everything stays fp32 (the transforms only add, subtract and halve): the result differs from the fma
+// chain of the direct kernel by rounding, ~1e-6 relative, inside the 1e-4 parity bar, and is the same on every run.
+//
+// One workgroup (4 waves) = 32 tiles (128 output pixels) x 64 output channels x all 16 frequencies:
+//   * tiles are enumerated over (level, image, dilation parity class, tile row, tile column): a dilated conv is a plain one on
+//     each of the dil^2 sub-lattices (h % dil, w % dil), so dilation only changes the address arithmetic;
+//   * per 8-channel chunk every thread loads ONE row of one tile's 4x4 patch (4 x 16 B raw buffer loads, zero outside the
+//     image), transforms along the row in registers, exchanges with the other three rows of its quad by DPP (quad_perm) for
+//     the column pass and writes V[f][tile][8 c] to LDS (16 KB per chunk, double buffered): the input transform never touches
+//     HBM and its 4x patch overlap is served by L1/L2;
+//   * wave (fh, ch) owns frequencies 8 fh .. 8 fh + 7 and output channels 32 ch .. 32 ch + 31: 8 accumulators of 32 x 32
+//     (128 VGPRs).  The U operand goes global -> registers directly in MFMA layout (packed so that one frequency block of
+//     32 cout x 8 c is 1 KB contiguous, L2 resident: blocks of one XCD walk the M tiles of ONE cout tile before the next);
+//   * epilogue: each wave reduces its two patch rows of frequencies to partial 2x2 outputs, the pair (fh = 0, 1) meets in LDS,
+//     then y = act(v * scale + shift (+ / mask) res) with 16-byte stores, exactly the direct kernel's epilogue contract.
+#include "fd_conv_common.h"
+
+struct WinoArgs {
+    const float* x; const float* u; const float* scale; const float* shift; const float* res; float* y;
+    int x_cs, x_co, res_cs, res_co, y_cs, y_co;
+    int Cin, Cout, dil, act, act_c0, res_mask;
+    int NC;                       // 8-channel chunks
+    int nseg;
+    int H[FD_MAX_SEG], W[FD_MAX_SEG], TH[FD_MAX_SEG], TW[FD_MAX_SEG];   // TH x TW tiles per parity class
+    int m0[FD_MAX_SEG];           // first row of the level (input rows == output rows)
+    int t0[FD_MAX_SEG + 1];       // first tile of the level
+    float seg_param[FD_MAX_SEG];
+    int T;                        // tiles in all
+    int mtiles, ntiles, mt_per;   // M tiles (32 tiles each), N tiles (64 cout), M tiles per XCD
+    unsigned x_bytes, u_bytes;
+};
+
+#define WINO_TB 32     // tiles per workgroup
+#define WINO_NB 64     // output channels per workgroup
+#define WINO_KC 8      // channels per chunk
+
+struct TilePos { int s, n, h0, w0; bool ok; };
+
+__device__ __forceinline__ TilePos wino_decode(const WinoArgs& a, int t) {
+    TilePos p;
+    p.ok = t < a.T;
+    if (!p.ok) t = 0;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < FD_MAX_SEG; ++i)
+        if (i < a.nseg && t >= a.t0[i]) s = i;
+    const int local = t - a.t0[s];
+    const int ct = a.TH[s] * a.TW[s];
+    const int tpi = a.dil * a.dil * ct;
+    const int n = local / tpi, r = local - n * tpi;
+    const int cls = r / ct, r2 = r - cls * ct;
+    const int ti = r2 / a.TW[s], tj = r2 - ti * a.TW[s];
+    const int ca = cls / a.dil, cb = cls - ca * a.dil;
+    p.s = s; p.n = n;
+    p.h0 = ca + 2 * a.dil * ti;
+    p.w0 = cb + 2 * a.dil * tj;
+    return p;
+}
+
+__device__ __forceinline__ float dpp_quad_2211(float v) {   // lane i of a quad reads lane {2, 2, 1, 1}[i]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
+}
+
+template <int TAG>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Vs = reinterpret_cast<float*>(smem);          // [2][16 f][32 tiles][8 c]; the epilogue reuses all 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fh = wave & 1, ch = wave >> 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-aware order: XCD x owns M tiles [x * mt_per, (x + 1) * mt_per) and walks them cout tile by cout tile, so the 64 workgroups
+    // resident on an XCD share one cout tile's U (<= 1 MB at Cin = 256) in its L2 while the input streams through
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int mt_lo = xcd * a.mt_per;
+    const int cnt = min(a.mtiles - mt_lo, a.mt_per);
+    if (cnt <= 0 || idx >= cnt * a.ntiles) return;
+    const int nt = idx / cnt, mt = mt_lo + (idx - nt * cnt);
+    const int tile0 = mt * WINO_TB, n0 = nt * WINO_NB;
+
+    constexpr unsigned OOB = 0xC0000000u;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, (int)a.u_bytes, 0x00020000);
+
+    // ---- loader role: thread = (tile lt, channel quad q, patch row pi) ----
+    const int pi = tid & 3, q = (tid >> 2) & 1, lt = tid >> 3;
+    unsigned a_off[4];
+    {
+        const TilePos p = wino_decode(a, tile0 + lt);
+        const int H = a.H[p.s], W = a.W[p.s];
+        const int hh = p.h0 + (pi - 1) * a.dil;
+        const bool row_ok = p.ok && (unsigned)hh < (unsigned)H;
+        const int rowbase = a.m0[p.s] + (p.n * H + hh) * W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ww = p.w0 + (j - 1) * a.dil;
+            a_off[j] = (row_ok && (unsigned)ww < (unsigned)W)
+                           ? ((unsigned)(rowbase + ww) * (unsigned)a.x_cs + (unsigned)(a.x_co + q * 4)) * 4u : OOB;
+        }
+    }
+    // column pass of B^T d B across the quad: V[pi][j] = ss * t[pi][j] + so * t[{2, 2, 1, 1}[pi]][j]
+    const float ss = (pi == 3) ? -1.f : 1.f;
+    const float so = (pi & 1) ? 1.f : -1.f;
+    // V[f = 4 pi + j][tile][8 c]: tile rows XORed with pi (conflict-free ds_write_b128 over a quad), 16-B halves with tile bit 4
+    // (conflict-free ds_read_b128 of the MFMA feed)
+    const int v_wr = (pi * 4 * WINO_TB + (lt ^ pi)) * WINO_KC + 4 * (q ^ ((lt >> 4) & 1));
+
+    // ---- MFMA role ----
+    // U packed [cout / 32][chunk][16 f][32 cout][8 c]: this wave's 8 frequency blocks of a chunk are 8 KB contiguous
+    const int nb = (n0 >> 5) + ch;
+    const bool nb_ok = nb * 32 < ((a.Cout + 31) & ~31);
+    const unsigned u_off0 = nb_ok ? ((unsigned)(nb * a.NC) * 16u + 8u * fh) * 1024u + (unsigned)(l31 * 32 + lh * 16) : OOB;
+    const int v_rd = (8 * fh * WINO_TB) * WINO_KC + 4 * (lh ^ ((l31 >> 4) & 1));   // + (fi * 32 + (l31 ^ row_xor(f))) * 8
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    float4 pr[4], bq[8];
+    auto load_patch = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            pr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(a_off[j] + (unsigned)cc * 32u), 0, 0));
+    };
+    auto load_u = [&](int cc, int fi) {
+        bq[fi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (int)(u_off0 + ((unsigned)cc * 16u + fi) * 1024u), 0, 0));
+    };
+    auto store_v = [&](int buf) {
+        const f32x4 d0 = {pr[0].x, pr[0].y, pr[0].z, pr[0].w}, d1 = {pr[1].x, pr[1].y, pr[1].z, pr[1].w};
+        const f32x4 d2 = {pr[2].x, pr[2].y, pr[2].z, pr[2].w}, d3 = {pr[3].x, pr[3].y, pr[3].z, pr[3].w};
+        f32x4 t[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+        float* dst = Vs + buf * (16 * WINO_TB * WINO_KC) + v_wr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaf(so, dpp_quad_2211(t[j][c]), ss * t[j][c]);
+            *reinterpret_cast<f32x4*>(dst + j * (WINO_TB * WINO_KC)) = v;
+        }
+    };
+
+    load_patch(0);
+#pragma unroll
+    for (int fi = 0; fi < 8; ++fi) load_u(0, fi);
+    store_v(0);
+    __syncthreads();
+    for (int cc = 0; cc < a.NC; ++cc) {
+        const int buf = cc & 1;
+        const bool more = cc + 1 < a.NC;
+        if (more) load_patch(cc + 1);
+        const float* Vb = Vs + buf * (16 * WINO_TB * WINO_KC) + v_rd;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi) {
+            // plane f = 8 fh + fi was written with tile rows XORed by its patch row (f >> 2) = 2 fh + (fi >> 2)
+            const float4 fa = *reinterpret_cast<const float4*>(Vb + (fi * WINO_TB + (l31 ^ (2 * fh + (fi >> 2)))) * WINO_KC);
+            const float4 fb = bq[fi];
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[fi], 0, 0, 0);
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[fi], 0, 0, 0);
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc[fi], 0, 0, 0);
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc[fi], 0, 0, 0);
+            if (more) load_u(cc + 1, fi);        // the next chunk's block lands in the same registers under the remaining MFMAs
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) store_v(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- output transform: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1] ----
+    // acc[fi][e]: frequency (i = 2 fh + (fi >> 2), j = fi & 3), tile row (e & 3) + 8 (e >> 2) + 4 lh, cout column l31.
+    // Column pass per patch row i: r_i[0] = M_i0 + M_i1 + M_i2, r_i[1] = M_i1 - M_i2 - M_i3; row pass split over the pair:
+    //   fh = 0 (i = 0, 1): P[0][y] = r_0[y] + r_1[y], P[1][y] = r_1[y];   fh = 1 (i = 2, 3): P[0][y] = r_2[y], P[1][y] = -r_2[y] - r_3[y]
+    // stage S[ch][fh][xy][32 tiles][32 cout] floats (64 KB): the pair's partials are added by the transposed reader
+    float* S = reinterpret_cast<float*>(smem) + (ch * 2 + fh) * (4 * 32 * 32);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float ra0 = acc[0][e] + acc[1][e] + acc[2][e], ra1 = acc[1][e] - acc[2][e] - acc[3][e];
+        const float rb0 = acc[4][e] + acc[5][e] + acc[6][e], rb1 = acc[5][e] - acc[6][e] - acc[7][e];
+        float p00, p01, p10, p11;
+        if (fh == 0) { p00 = ra0 + rb0; p01 = ra1 + rb1; p10 = rb0; p11 = rb1; }
+        else { p00 = ra0; p01 = ra1; p10 = -ra0 - rb0; p11 = -ra1 - rb1; }
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float* d = S + row * 32 + l31;
+        d[0 * 1024] = p00; d[1 * 1024] = p01; d[2 * 1024] = p10; d[3 * 1024] = p11;
+    }
+    __syncthreads();
+    {
+        const int tp = tid & 127, c4 = tp & 7, rg = tp >> 3;
+        const float* S0 = reinterpret_cast<const float*>(smem) + (ch * 2) * (4 * 32 * 32);
+        const int nn = n0 + ch * 32 + c4 * 4;
+        if (nn < a.Cout) {
+            const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + nn) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 sf = a.shift ? *reinterpret_cast<const float4*>(a.shift + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int row = rg + 16 * half;
+                const TilePos p = wino_decode(a, tile0 + row);
+                if (!p.ok) continue;
+                const int H = a.H[p.s], W = a.W[p.s];
+                const float prm = a.seg_param[p.s];
+#pragma unroll
+                for (int xy = 0; xy < 4; ++xy) {
+                    const int h = p.h0 + (xy >> 1) * a.dil, w = p.w0 + (xy & 1) * a.dil;
+                    if (h >= H || w >= W) continue;
+                    const size_t m = (size_t)(a.m0[p.s] + (p.n * H + h) * W + w);
+                    const float4 va = *reinterpret_cast<const float4*>(S0 + (xy * 32 + row) * 32 + c4 * 4);
+                    const float4 vb = *reinterpret_cast<const float4*>(S0 + 4096 + (xy * 32 + row) * 32 + c4 * 4);
+                    float4 v = make_float4((va.x + vb.x) * sc.x + sf.x, (va.y + vb.y) * sc.y + sf.y,
+                                           (va.z + vb.z) * sc.z + sf.z, (va.w + vb.w) * sc.w + sf.w);
+                    if (a.res) {
+                        const float4 r = *reinterpret_cast<const float4*>(a.res + m * a.res_cs + a.res_co + nn);
+                        if (a.res_mask) {
+                            v.x = r.x > 0.f ? v.x : 0.f; v.y = r.y > 0.f ? v.y : 0.f;
+                            v.z = r.z > 0.f ? v.z : 0.f; v.w = r.w > 0.f ? v.w : 0.f;
+                        } else {
+                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        }
+                    }
+                    if (a.act != FD_ACT_NONE) {
+                        if (nn + 0 >= a.act_c0) v.x = fd_act(v.x, a.act, prm);
+                        if (nn + 1 >= a.act_c0) v.y = fd_act(v.y, a.act, prm);
+                        if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, prm);
+                        if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, prm);
+                    }
+                    *reinterpret_cast<float4*>(a.y + m * a.y_cs + a.y_co + nn) = v;
+                }
+            }
+        }
+    }
+}
+
+// U = G g G^T per (cout, cin), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], computed in double and rounded once; packed
+// [ceil(Cout / 32)][Cin / 8][16 f][32 cout][8 c] (zero rows past Cout).  mode 1 = the weights of the data-gradient conv
+// (N = Cin, K = Cout): g'[ci][co][r][q] = g[co][ci][2 - r][2 - q] * (scale ? scale[co] : 1).
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
+                                                        int N, int K, int mode) {
+    const int Np = (N + 31) & ~31;
+    const long total = (long)Np * K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / K), k = (int)(i - (long)n * K);
+        double g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double v = 0.0;
+                if (n < N) {
+                    if (mode == 0) v = w[((long)n * K + k) * 9 + r * 3 + c];
+                    else v = (double)w[((long)k * N + n) * 9 + (2 - r) * 3 + (2 - c)] * (scale ? (double)scale[k] : 1.0);
+                }
+                g[r][c] = v;
+            }
+        double t[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            t[0][c] = g[0][c];
+            t[1][c] = 0.5 * (g[0][c] + g[1][c] + g[2][c]);
+            t[2][c] = 0.5 * (g[0][c] - g[1][c] + g[2][c]);
+            t[3][c] = g[2][c];
+        }
+        const int nbk = n >> 5, nl = n & 31, cc = k >> 3, kl = k & 7;
+        float* o = out + (((long)nbk * (K >> 3) + cc) * 16) * 256 + nl * 8 + kl;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            o[(a * 4 + 0) * 256] = (float)t[a][0];
+            o[(a * 4 + 1) * 256] = (float)(0.5 * (t[a][0] + t[a][1] + t[a][2]));
+            o[(a * 4 + 2) * 256] = (float)(0.5 * (t[a][0] - t[a][1] + t[a][2]));
+            o[(a * 4 + 3) * 256] = (float)t[a][2];
+        }
+    }
+}
+
+extern "C" int64_t fd_wino_weight_bytes(int32_t Cout, int32_t Cin) {
+    if (Cout < 1 || Cin < 8 || Cin % 8) return -1;
+    return (int64_t)((Cout + 31) & ~31) * Cin * 16 * 4;
+}
+
+extern "C" int32_t fd_wino_pack_weights_f32(const float* w, const float* scale, float* out, int32_t Cout, int32_t Cin, int32_t mode,
+                                            fd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FD_REQUIRE(w && out && Cout >= 1 && Cin >= 1 && (mode == 0 || mode == 1), FD_E_INVAL, "fd_wino_pack_weights: bad arguments");
+    const int N = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+    FD_REQUIRE(K % 8 == 0, FD_E_UNSUPPORTED, "fd_wino_pack_weights: the reduction width (%d) must be a multiple of 8", K);
+    const long total = (long)((N + 31) & ~31) * K;
+    long g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)g), dim3(256), 0, stream, w, scale, out, N, K, mode);
+    FD_CHECK_LAUNCH("fd_wino_pack_weights_f32");
+    return FD_OK;
+}
+
+template <int TAG>
+static int launch_wino(const WinoArgs& a, hipStream_t stream) {
+    constexpr int lds = 64 * 1024;
+    auto kern = conv3x3_wino_kernel<TAG>;
+    static std::atomic<unsigned> attr_mask{0};
+    fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
+    hipLaunchKernelGGL(kern, dim3(8 * a.mt_per * a.ntiles), dim3(256), lds, stream, a);
+    FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (winograd)");
+    return FD_OK;
+}
+
+// Called by fd_conv2d_nhwc_f32 for tile == FD_TILE_WINOGRAD (p->w = the fd_wino_pack_weights_f32 packing).
+int fd_launch_conv_wino(const fd_conv_params* p, hipStream_t stream) {
+    FD_REQUIRE(p->mode == FD_CONV_GENERIC && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == p->dil &&
+                   (p->dil == 1 || p->dil == 2) && p->ksplit <= 1 && p->out_H <= 0 && p->sc_H <= 0 && p->precision == FD_PREC_F32,
+               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD needs an fp32 3x3 stride-1 'same' conv with dilation 1 or 2 (no split-K / scatter)");
+    FD_REQUIRE(p->Cin % 8 == 0 && p->Cout % 4 == 0, FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD needs Cin %% 8 == 0 and Cout %% 4 == 0 (Cin=%d Cout=%d)",
+               p->Cin, p->Cout);
+    FD_REQUIRE(p->y_cs % 4 == 0 && p->y_co % 4 == 0 && ((uintptr_t)p->y & 15) == 0 &&
+                   (!p->res || (p->res_cs % 4 == 0 && p->res_co % 4 == 0 && ((uintptr_t)p->res & 15) == 0)) &&
+                   (!p->scale || ((uintptr_t)p->scale & 15) == 0) && (!p->shift || ((uintptr_t)p->shift & 15) == 0),
+               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD needs 16-byte addressable output / residual / scale / shift views");
+    WinoArgs a;
+    a.x = p->x; a.u = p->w; a.scale = p->scale; a.shift = p->shift; a.res = p->res; a.y = p->y;
+    a.x_cs = p->x_cs; a.x_co = p->x_co; a.res_cs = p->res_cs; a.res_co = p->res_co; a.y_cs = p->y_cs; a.y_co = p->y_co;
+    a.Cin = p->Cin; a.Cout = p->Cout; a.dil = p->dil; a.act = p->act; a.act_c0 = p->act_c0;
+    a.res_mask = (p->res && p->res_mode == 1) ? 1 : 0;
+    a.NC = p->Cin / 8;
+    a.nseg = p->in.nseg;
+    long t = 0;
+    for (int s = 0; s < FD_MAX_SEG; ++s) {
+        a.t0[s] = (int)t;
+        if (s < p->in.nseg) {
+            a.H[s] = p->in.H[s]; a.W[s] = p->in.W[s];
+            a.TH[s] = ((p->in.H[s] + p->dil - 1) / p->dil + 1) / 2;
+            a.TW[s] = ((p->in.W[s] + p->dil - 1) / p->dil + 1) / 2;
+            a.m0[s] = p->in.m_start[s];
+            t += (long)p->in.batch * p->dil * p->dil * a.TH[s] * a.TW[s];
+        } else {
+            a.H[s] = a.W[s] = a.TH[s] = a.TW[s] = 1; a.m0[s] = 0;
+        }
+        a.seg_param[s] = p->seg_param[s];
+    }
+    a.t0[FD_MAX_SEG] = (int)t;
+    FD_REQUIRE(t > 0 && t < (1L << 30), FD_E_INVAL, "fd_conv2d: tile count out of range");
+    a.T = (int)t;
+    const long rows = p->in.m_start[p->in.nseg];
+    FD_REQUIRE(rows * p->x_cs < (1L << 31) && rows * p->y_cs < (1L << 31), FD_E_UNSUPPORTED, "fd_conv2d: tensor exceeds 2^31 elements");
+    const long xb = rows * p->x_cs * 4, ub = (long)((p->Cout + 31) & ~31) * p->Cin * 64;
+    FD_REQUIRE(xb < 0xC0000000L - 65536 && ub < 0xC0000000L, FD_E_UNSUPPORTED, "fd_conv2d: input / weight buffer exceeds 3 GiB");
+    a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub;
+    a.mtiles = (a.T + WINO_TB - 1) / WINO_TB;
+    a.ntiles = (p->Cout + WINO_NB - 1) / WINO_NB;
+    a.mt_per = (a.mtiles + 7) / 8;
+    return p->tag == 1 ? launch_wino<1>(a, stream) : launch_wino<0>(a, stream);
+}

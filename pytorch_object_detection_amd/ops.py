@@ -349,6 +349,30 @@ def pack_conv_weight_hip(w: torch.Tensor, scale: Optional[torch.Tensor] = None, 
     return out
 
 
+def pack_conv_weight_wino(w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False) -> torch.Tensor:
+    """OIHW [Cout, Cin, 3, 3] -> the Winograd F(2x2, 3x3) operand of FD_TILE_WINOGRAD: U = G g G^T per (cout, cin), packed
+    [ceil(N/32)][K/8][16][32][8] (N = Cout, K = Cin; dgrad=True: the flipped / transposed weights of the data-gradient conv,
+    N = Cin, K = Cout, times an optional per-Cout scale).  One HIP launch (fd_wino_pack_weights_f32)."""
+    w = w.detach().float().contiguous()
+    _need_gpu(w, scale)
+    co, ci, kh, kw = w.shape
+    if kh != 3 or kw != 3:
+        raise FdError("Winograd weights need a 3x3 filter")
+    n, k = (ci, co) if dgrad else (co, ci)
+    nbytes = _lib.lib().fd_wino_weight_bytes(n, k)
+    if nbytes < 0:
+        raise FdError(f"Winograd weights need a reduction width that is a multiple of 8 (got {k})")
+    out = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+    check(_lib.lib().fd_wino_pack_weights_f32(w.data_ptr(), scale.data_ptr() if (scale is not None and dgrad) else None,
+                                              out.data_ptr(), co, ci, 1 if dgrad else 0, _stream()), "fd_wino_pack_weights_f32")
+    return out
+
+
+def wino_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bool:
+    """Shapes FD_TILE_WINOGRAD covers (the output / residual views must also be 16-byte addressable)."""
+    return k == 3 and stride == 1 and pad == dil and dil in (1, 2) and Cin % 8 == 0 and Cout % 4 == 0
+
+
 def strided_dgrad_classes(k: int, stride: int, pad: int):
     """Parity classes of the data gradient of a k x k conv with `stride`: for input rows h = stride*i + a only the taps
     r = r0 + stride*t contribute, and dY row = i + c - t.  Returns per class a: (r0, T taps, c) with r0 = (a + pad) % stride,

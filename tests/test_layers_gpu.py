@@ -66,11 +66,18 @@ def test_conv_single_level(case, prec):
     y = ops.new_rows(B * Ho * Wo, Cout, DEV)
     rr = to_rows(res) if use_res else None
     wp = ops.pack_conv_weight_f16x3(w.to(DEV)) if prec == "f16x3" else ops.pack_conv_weight(w.to(DEV))
+    from pytorch_object_detection_amd._lib import PATCH_TILE
+    patch_ok = k == 3 and stride == 1 and pad == dil
     for tile in ([0] if prec == "f32" else []) + sorted(_TILE_IDS):
         y.buf.fill_(float("nan"))
-        ops.conv_call(xr, segs, wp, y, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil,
-                      scale=scale.to(DEV) if use_bn else None, shift=shift.to(DEV), res=rr, act=act, tile=tile,
-                      precision=1 if prec == "f16x3" else 0)()
+        call = ops.conv_call(xr, segs, wp, y, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil,
+                             scale=scale.to(DEV) if use_bn else None, shift=shift.to(DEV), res=rr, act=act, tile=tile,
+                             precision=1 if prec == "f16x3" else 0)
+        if tile == PATCH_TILE and not patch_ok:      # the patch tile is 3x3 stride-1 'same' only: a clean error, no launch
+            with pytest.raises(Exception, match="PATCH"):
+                call()
+            continue
+        call()
         np.testing.assert_allclose(from_rows(y, B, Ho, Wo).numpy(), ref.numpy(), atol=ATOL, rtol=RTOL, err_msg=f"tile {tile}")
 
 
@@ -651,3 +658,128 @@ def test_conv_dgrad_strided_parity_classes(case):
         dx2 = torch.empty(B * H * W, Cin, device=DEV)
         assert ops.conv_dgrad_strided(to_rows(dy), w.to(DEV), scale.to(DEV), ops.Rows(dx2), B, H, W, k, s, pad, res=to_rows(mask_src), res_mask=True)
         np.testing.assert_allclose(from_rows(ops.Rows(dx2), B, H, W).numpy() / sc, (ref * (mask_src > 0)).numpy() / sc, atol=2e-5)
+
+
+PATCH_CASES = [
+    # Cin, Cout, dil, level sizes, act, res
+    (256, 256, 1, [(20, 20)], ACT_RELU, False),
+    (64, 128, 1, [(13, 21)], ACT_NONE, True),
+    (256, 256, 2, [(20, 20)], ACT_SILU, False),            # HisBlock conv4 (dilation 2)
+    (128, 512, 1, [(40, 40), (20, 20), (10, 10), (5, 5), (3, 3)], ACT_NONE, False),     # head tower over a pyramid
+    (48, 80, 1, [(9, 95)], ACT_NONE, False),               # widest map the patch fits (W = 95), Cin % 32 != 0, Cout % 128 != 0
+    (32, 5, 1, [(7, 7), (4, 4)], ACT_NONE, False),
+    (256, 128, 2, [(1, 1), (2, 3)], ACT_RELU, True),
+]
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_conv3x3_patch_kernel(case, prec):
+    """FD_TILE_128x128_PATCH: 3x3 stride-1 'same' conv with the (tile + halo) input patch staged once per channel chunk in
+    LDS (north_star: 'LDS-staged input patches') against F.conv2d, on single maps and pyramids, through channel views."""
+    from pytorch_object_detection_amd import _lib
+    Cin, Cout, dil, hw, act, use_res = case
+    gen = torch.Generator().manual_seed(Cin + Cout + dil + len(hw))
+    B = 3
+    xs = [torch.randn(B, Cin, h, w, generator=gen) for h, w in hw]
+    wt = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    sc, sf = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen) * 0.1
+    rs = [torch.randn(B, Cout, h, w, generator=gen) for h, w in hw]
+    segs = Segs.make(B, hw)
+    ref = []
+    for x, r in zip(xs, rs):
+        y = F.conv2d(x, wt, None, 1, dil, dil) * sc[None, :, None, None] + sf[None, :, None, None]
+        if use_res:
+            y = y + r
+        ref.append(act_ref(y, act))
+    xb = torch.full((segs.rows, Cin + 8), float("nan"), device=DEV)      # a channel slice of a wider buffer
+    xb[:, 4:4 + Cin] = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cin) for t in xs]).to(DEV)
+    rb = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cout) for t in rs]).contiguous().to(DEV)
+    y = ops.new_rows(segs.rows, Cout, DEV)
+    wp = (ops.pack_conv_weight_f16x3 if prec == "f16x3" else ops.pack_conv_weight)(wt.to(DEV))
+    ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, scale=sc.to(DEV), shift=sf.to(DEV),
+                  res=ops.Rows(rb) if use_res else None, act=act, tile=_lib.PATCH_TILE, precision=1 if prec == "f16x3" else 0)()
+    got = y.tensor().cpu()
+    for i, ((h, w), r) in enumerate(zip(hw, ref)):
+        g = got[segs.m_start[i]:segs.m_start[i + 1]].reshape(B, h, w, Cout).permute(0, 3, 1, 2)
+        np.testing.assert_allclose(g.numpy(), r.numpy(), atol=ATOL, rtol=1e-4, err_msg=f"level {i}")
+    # not a 3x3 'same' conv / too wide a map: a clean error, no launch
+    with pytest.raises(Exception, match="PATCH|multi-level"):
+        ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=0, dil=1, tile=_lib.PATCH_TILE)()
+
+
+WINO_CASES = [
+    # Cin, Cout, dil, level sizes, act, res
+    (256, 256, 1, [(20, 20)], ACT_RELU, False),
+    (64, 128, 1, [(13, 21)], ACT_NONE, True),                # odd sizes: half tiles at the right / bottom edge
+    (256, 256, 2, [(20, 20)], ACT_SILU, False),              # HisBlock conv4 (dilation 2): four parity classes
+    (128, 512, 1, [(40, 40), (20, 20), (10, 10), (5, 5), (3, 3)], ACT_NONE, False),     # head tower over a pyramid
+    (48, 80, 1, [(9, 95)], ACT_NONE, False),                 # Cin % 32 != 0, Cout % 64 != 0 (cls_logits width)
+    (8, 4, 1, [(7, 7), (4, 4)], ACT_NONE, False),
+    (256, 128, 2, [(1, 1), (2, 3), (5, 7)], ACT_RELU, True), # dilation 2 on maps smaller than a tile
+    (512, 512, 1, [(6, 6)], ACT_RELU, False),                # layer4 conv2: K = 512
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv3x3_winograd(case):
+    """FD_TILE_WINOGRAD (fd_conv_wino.hip): F(2x2, 3x3) on the fp32 MFMA against F.conv2d -- pyramids, dilation 2 (parity classes),
+    ragged sizes, channel views whose neighbours are NaN, BN fold + residual + activation epilogue.  Same bar as the direct kernel."""
+    from pytorch_object_detection_amd import _lib
+    Cin, Cout, dil, hw, act, use_res = case
+    gen = torch.Generator().manual_seed(Cin + Cout + dil + len(hw))
+    B = 3
+    xs = [torch.randn(B, Cin, h, w, generator=gen) for h, w in hw]
+    wt = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    sc, sf = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen) * 0.1
+    rs = [torch.randn(B, Cout, h, w, generator=gen) for h, w in hw]
+    segs = Segs.make(B, hw)
+    ref = []
+    for x, r in zip(xs, rs):
+        y = F.conv2d(x, wt, None, 1, dil, dil) * sc[None, :, None, None] + sf[None, :, None, None]
+        if use_res:
+            y = y + r
+        ref.append(act_ref(y, act))
+    xb = torch.full((segs.rows, Cin + 8), float("nan"), device=DEV)      # a channel slice of a wider buffer
+    xb[:, 4:4 + Cin] = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cin) for t in xs]).to(DEV)
+    rb = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cout) for t in rs]).contiguous().to(DEV)
+    yb = torch.full((segs.rows, Cout + 8), float("nan"), device=DEV)
+    y = ops.Rows(yb, 4, Cout)
+    wp = ops.pack_conv_weight_wino(wt.to(DEV))
+    ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, scale=sc.to(DEV), shift=sf.to(DEV),
+                  res=ops.Rows(rb) if use_res else None, act=act, tile=_lib.WINO_TILE)()
+    got = yb.cpu()
+    assert torch.isnan(got[:, :4]).all() and torch.isnan(got[:, 4 + Cout:]).all(), "wrote outside its channel view"
+    got = got[:, 4:4 + Cout]
+    for i, ((h, w), r) in enumerate(zip(hw, ref)):
+        g = got[segs.m_start[i]:segs.m_start[i + 1]].reshape(B, h, w, Cout).permute(0, 3, 1, 2)
+        np.testing.assert_allclose(g.numpy(), r.numpy(), atol=ATOL, rtol=1e-4, err_msg=f"level {i}")
+    with pytest.raises(Exception, match="WINOGRAD|multi-level"):     # not a stride-1 'same' 3x3: a clean error, no launch
+        ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=0, dil=1, tile=_lib.WINO_TILE)()
+
+
+def test_winograd_weight_pack_and_dgrad():
+    """fd_wino_pack_weights_f32: U = G g G^T against a float64 einsum, in both modes; the mode-1 packing makes the kernel the
+    data gradient of the conv (dX = conv(dY, flipped / transposed w * scale))."""
+    from pytorch_object_detection_amd import _lib
+    gen = torch.Generator().manual_seed(5)
+    Cout, Cin = 40, 24
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    U = torch.einsum("ir,ocrq,jq->ijoc", G, w.double(), G).reshape(16, Cout, Cin)
+    got = ops.pack_conv_weight_wino(w.to(DEV)).cpu().reshape(2, Cin // 8, 16, 32, 8)      # [nb][cc][f][co][c]
+    exp = torch.zeros(16, 64, Cin, dtype=torch.float64)
+    exp[:, :Cout] = U
+    exp = exp.reshape(16, 2, 32, Cin // 8, 8).permute(1, 3, 0, 2, 4)
+    np.testing.assert_allclose(got.numpy(), exp.float().numpy(), rtol=0, atol=0)
+    # data gradient through the same kernel
+    B, H, W = 2, 9, 11
+    scale = torch.rand(Cout, generator=gen) + 0.5
+    x = torch.randn(B, Cin, H, W, generator=gen, requires_grad=True)
+    dy = torch.randn(B, Cout, H, W, generator=gen)
+    (F.conv2d(x, w, None, 1, 1, 1) * scale.view(1, -1, 1, 1)).backward(dy)
+    segs = Segs.make(B, [(H, W)])
+    dx = ops.new_rows(B * H * W, Cin, DEV)
+    wp = ops.pack_conv_weight_wino(w.to(DEV), scale.to(DEV), dgrad=True)
+    ops.conv_call(to_rows(dy), segs, wp, dx, Cin=Cout, Cout=Cin, k=3, pad=1, dil=1, tile=_lib.WINO_TILE)()
+    np.testing.assert_allclose(from_rows(dx, B, H, W).numpy(), x.grad.numpy(), atol=ATOL, rtol=1e-4)
