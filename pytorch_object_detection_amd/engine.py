@@ -17,6 +17,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import ops
+from . import _lib
 from ._lib import ACT_EXP, ACT_NONE, ACT_RELU, ACT_SILU, FdError, Segs
 from .ops import Rows
 
@@ -27,6 +28,9 @@ import os as _os
 # conv except the 7x7 stem (K = 147 is too short to matter).  See include/fcosdet.h FD_PREC_*.
 CONV_PRECISION = _os.environ.get("FD_CONV_PRECISION", "f32")
 AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see ops.autotune_conv, FD_AUTOTUNE)
+# FD_WINOGRAD: "1" (default) = 3x3 stride-1 'same' convs (dilation 1 / 2, Cin % 8 == 0) of an exact-fp32 plan run on the Winograd
+# F(2x2, 3x3) kernel (fd_conv_wino.hip: 2.25x fewer MFMAs, still fp32 arithmetic); "0" = every conv on the direct implicit-GEMM kernel
+WINOGRAD = _os.environ.get("FD_WINOGRAD", "1") != "0"
 
 
 class PRows(Rows):
@@ -78,6 +82,7 @@ class Plan:
         if self.precision not in ("f32", "f16x3"):
             raise FdError(f"unknown conv precision '{self.precision}' (f32 | f16x3)")
         self.tiles: Dict[str, int] = {}
+        self.winograd = WINOGRAD and self.precision == "f32"
         self.pair_tuned = pair_tuned       # block tiles picked for throughput beside a second batch (pipeline.TwoLanePipeline)
 
     def add(self, name: str, fn: Callable[[], None]) -> None:
@@ -143,7 +148,12 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         w = torch.nn.functional.pad(_dev(w, dev).detach(), (0, 0, 0, 0, 0, x.C - Cin))
         Cin = x.C
     split = plan.precision == "f16x3"
-    wp = ops.pack_conv_weight_f16x3(_dev(w, dev)) if split else ops.pack_conv_weight(_dev(w, dev))
+    wino = (plan.winograd and ops.wino_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0 and
+            (res is None or (res.cs % 4 == 0 and res.co % 4 == 0)))
+    if wino:
+        wp = ops.pack_conv_weight_wino(_dev(w, dev))
+    else:
+        wp = ops.pack_conv_weight_f16x3(_dev(w, dev)) if split else ops.pack_conv_weight(_dev(w, dev))
     scale = shift = None
     if fold is not None:
         scale, shift = fold
@@ -156,14 +166,17 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     out = ops.conv_out_segs(segs, k, stride, pad, dil)
     # split-K scratch: taken from the pool and handed straight back (stream order makes the sharing safe)
     ws_rows = ops.KSPLIT_MAX * out.rows
-    ws = plan.pool.get(ws_rows, (co + 3) & ~3) if (plan.autotune and ws_rows * ((co + 3) & ~3) <= 64 * 1024 * 1024) else None
+    ws = plan.pool.get(ws_rows, (co + 3) & ~3) if (plan.autotune and not wino and ws_rows * ((co + 3) & ~3) <= 64 * 1024 * 1024) else None
     call = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                          shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param, tag=tag,
-                         precision=1 if split else 0, workspace=ws.buf if ws is not None else None)
+                         precision=1 if split else 0, workspace=ws.buf if ws is not None else None,
+                         tile=_lib.WINO_TILE if wino else 0)
     plan.add(name, call)
     if ws is not None:
         plan.pool.put(ws)
-    if plan.autotune:
+    if wino:
+        plan.tiles[name] = _lib.WINO_TILE
+    elif plan.autotune:
         hw = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
         key = f"B{segs.batch}|{hw}|{Cin}>{co}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{x.cs}|ycs{y.cs}"
         if split:
