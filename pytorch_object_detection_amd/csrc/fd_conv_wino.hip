@@ -21,6 +21,7 @@
 //   * epilogue: each wave reduces its two patch rows of frequencies to partial 2x2 outputs, the pair (fh = 0, 1) meets in LDS,
 //     then y = act(v * scale + shift (+ / mask) res) with 16-byte stores, exactly the direct kernel's epilogue contract.
 #include "fd_conv_common.h"
+#include <stdlib.h>
 
 struct WinoArgs {
     const float* x; const float* u; const float* scale; const float* shift; const float* res; float* y;
@@ -68,10 +69,10 @@ __device__ __forceinline__ float dpp_quad_2211(float v) {   // lane i of a quad 
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
 }
 
-template <int TAG>
+template <int TAG, int SV, int DIAG = 0, int UAUX = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Vs = reinterpret_cast<float*>(smem);          // [2][16 f][32 tiles][8 c]; the epilogue reuses all 64 KB
+    float* Vs = reinterpret_cast<float*>(smem);          // [2 stages][16 f][32 tiles][8 c]; the epilogue reuses all 64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fh = wave & 1, ch = wave >> 1;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -125,61 +126,120 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    float4 pr[4], bq[8];
-    auto load_patch = [&](int cc) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            pr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(a_off[j] + (unsigned)cc * 32u), 0, 0));
-    };
+    // Main loop, one 8-channel chunk per iteration and workgroup barrier (two chunks per barrier measured 17 % SLOWER).  With
+    // everything but the MFMAs, the V reads and the barrier compiled out the loop runs at the matrix pipe's full rate; measured
+    // costs on top (head tower): patch loads + transform + LDS writes 17 %, U loads 6 %, epilogue 4 %.  So:
+    //   * the patch rows are fetched TWO chunks ahead (pr[2][4]; they miss L2 -- the input streams from the Infinity Cache / HBM --
+    //     and one iteration of MFMAs does not cover that latency under load);
+    //   * the transform of chunk cc + 1 is spread over the MFMA groups of iteration cc (row pass in group 2, one output column
+    //     = 4 fmac-with-DPP + 4 mul + one ds_write_b128 in each of groups 3..6), so its VALU issue fits the MFMAs' shadow;
+    //   * the U block of (cc + 1, fi) is fetched into the registers the MFMAs of fi have just consumed; V fragments are read two
+    //     frequencies ahead.
+    // The issue order is pinned with sched_barriers (left alone the compiler hoists the transform -- and with it a wait on loads it
+    // has just issued -- to the top of the iteration, or sinks all U prefetches to its end).  No data-dependent branches: the last
+    // iterations re-fetch the last chunk and write a stage nobody reads.
+    float4 pr[2][4], bq[8];
+    f32x4 tr[4];
     auto load_u = [&](int cc, int fi) {
-        bq[fi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (int)(u_off0 + ((unsigned)cc * 16u + fi) * 1024u), 0, 0));
+        bq[fi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (int)(u_off0 + ((unsigned)cc * 16u + fi) * 1024u), 0, UAUX));
     };
-    auto store_v = [&](int buf) {
-        const f32x4 d0 = {pr[0].x, pr[0].y, pr[0].z, pr[0].w}, d1 = {pr[1].x, pr[1].y, pr[1].z, pr[1].w};
-        const f32x4 d2 = {pr[2].x, pr[2].y, pr[2].z, pr[2].w}, d3 = {pr[3].x, pr[3].y, pr[3].z, pr[3].w};
-        f32x4 t[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
-        float* dst = Vs + buf * (16 * WINO_TB * WINO_KC) + v_wr;
+    constexpr int PLANE = WINO_TB * WINO_KC, STAGE = 16 * PLANE;
+    // plane f = 8 fh + fi was written with tile rows XORed by its patch row (f >> 2) = 2 fh + (fi >> 2)
+    auto read_v = [&](const float* Vb, int fi) {
+        return *reinterpret_cast<const float4*>(Vb + (fi * WINO_TB + (l31 ^ (2 * fh + (fi >> 2)))) * WINO_KC);
+    };
+#define WINO_LOAD_PATCH(SLOT, CC)                                                                                                  \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                              \
+        pr[SLOT][j_] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(a_off[j_] + (unsigned)(CC) * 32u), 0, 0))
+    // row pass of B^T d B in registers.  (The patch registers pass through an empty volatile asm: the transform is a pure function of
+    // them, and without this pin instruction selection starts it -- and the wait on the loads -- at the top of the iteration.)
+#define WINO_ROW_PASS(SLOT)                                                                                                        \
+    do {                                                                                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                          \
+            asm volatile("" : "+v"(pr[SLOT][j_].x), "+v"(pr[SLOT][j_].y), "+v"(pr[SLOT][j_].z), "+v"(pr[SLOT][j_].w));           \
+        const f32x4 d0_ = {pr[SLOT][0].x, pr[SLOT][0].y, pr[SLOT][0].z, pr[SLOT][0].w};                                           \
+        const f32x4 d1_ = {pr[SLOT][1].x, pr[SLOT][1].y, pr[SLOT][1].z, pr[SLOT][1].w};                                           \
+        const f32x4 d2_ = {pr[SLOT][2].x, pr[SLOT][2].y, pr[SLOT][2].z, pr[SLOT][2].w};                                           \
+        const f32x4 d3_ = {pr[SLOT][3].x, pr[SLOT][3].y, pr[SLOT][3].z, pr[SLOT][3].w};                                           \
+        tr[0] = d0_ - d2_; tr[1] = d1_ + d2_; tr[2] = d2_ - d1_; tr[3] = d1_ - d3_;                                               \
+    } while (0)
+    // column pass across the quad + LDS write of output column j: v = ss * t + so * t[lane {2, 2, 1, 1} of the quad] (v_fmac with DPP)
+    auto col_store = [&](int stage, int j) {
+        f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 v;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaf(so, dpp_quad_2211(t[j][c]), ss * t[j][c]);
-            *reinterpret_cast<f32x4*>(dst + j * (WINO_TB * WINO_KC)) = v;
+        for (int c = 0; c < 4; ++c) {
+            float r = ss * tr[j][c];
+            asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(tr[j][c]), "v"(so));
+            v[c] = r;
         }
+        *reinterpret_cast<f32x4*>(Vs + stage * STAGE + v_wr + j * PLANE) = v;
     };
+    // one iteration: MFMAs of chunk cc (LDS stage cc & 1), transform of chunk cc + 1 (fetched an iteration ago into pr[SLOT ^ 1]) into the
+    // other stage, fetch of chunk cc + 2 into pr[SLOT] (SLOT = cc & 1, a compile-time constant: the loop is unrolled by two)
+#define WINO_ITER(SLOT, CC)                                                                                                        \
+    do {                                                                                                                           \
+        const int cc_ = (CC);                                                                                                      \
+        const int cn1_ = min(cc_ + 1, a.NC - 1), cn2_ = min(cc_ + 2, a.NC - 1);                                                    \
+        const float* Vb = Vs + (SLOT) * STAGE + v_rd;                                                                              \
+        float4 fa[8];                                                                                                              \
+        if (!(DIAG & 2) && !(DIAG & 16)) { WINO_LOAD_PATCH(SLOT, cn2_); }                                                          \
+        fa[0] = read_v(Vb, 0);                                                                                                     \
+        fa[1] = read_v(Vb, 1);                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                                             \
+        _Pragma("unroll") for (int fi = 0; fi < 8; ++fi) {                                                                        \
+            const float4 fb = bq[fi];                                                                                              \
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fi].x, fb.x, acc[fi], 0, 0, 0);                                      \
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fi].y, fb.y, acc[fi], 0, 0, 0);                                      \
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fi].z, fb.z, acc[fi], 0, 0, 0);                                      \
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fi].w, fb.w, acc[fi], 0, 0, 0);                                      \
+            if (!(DIAG & 4)) load_u(cn1_, fi);                                                                                     \
+            if (fi + 2 < 8) fa[fi + 2] = read_v(Vb, fi + 2);                                                                       \
+            if (!(DIAG & 2) && !(DIAG & 8)) {                                                                                      \
+                if (fi == 2) WINO_ROW_PASS((SLOT) ^ 1);                                                                            \
+                if (fi >= 3 && fi <= 6) col_store((SLOT) ^ 1, fi - 3);                                                             \
+            }                                                                                                                      \
+            if ((DIAG & 8) && fi == 2) {   /* (diagnostic: loads only -- keep them alive, no transform / LDS writes) */            \
+                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                  \
+                    asm volatile("" :: "v"(pr[(SLOT) ^ 1][j_].x), "v"(pr[(SLOT) ^ 1][j_].y), "v"(pr[(SLOT) ^ 1][j_].z), "v"(pr[(SLOT) ^ 1][j_].w)); \
+            }                                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        }                                                                                                                          \
+        __builtin_amdgcn_s_setprio(0);                                                                                             \
+        __syncthreads();                                                                                                           \
+    } while (0)
 
-    load_patch(0);
+    WINO_LOAD_PATCH(0, 0);
+    WINO_LOAD_PATCH(1, min(1, a.NC - 1));
 #pragma unroll
     for (int fi = 0; fi < 8; ++fi) load_u(0, fi);
-    store_v(0);
-    __syncthreads();
-    for (int cc = 0; cc < a.NC; ++cc) {
-        const int buf = cc & 1;
-        const bool more = cc + 1 < a.NC;
-        if (more) load_patch(cc + 1);
-        const float* Vb = Vs + buf * (16 * WINO_TB * WINO_KC) + v_rd;
-        __builtin_amdgcn_s_setprio(1);
+    WINO_ROW_PASS(0);
+    asm volatile("s_nop 4");      // (VALU write -> DPP read of the same VGPR needs 2 wait states; the hazard recogniser does not see into asm)
 #pragma unroll
-        for (int fi = 0; fi < 8; ++fi) {
-            // plane f = 8 fh + fi was written with tile rows XORed by its patch row (f >> 2) = 2 fh + (fi >> 2)
-            const float4 fa = *reinterpret_cast<const float4*>(Vb + (fi * WINO_TB + (l31 ^ (2 * fh + (fi >> 2)))) * WINO_KC);
-            const float4 fb = bq[fi];
-            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[fi], 0, 0, 0);
-            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[fi], 0, 0, 0);
-            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc[fi], 0, 0, 0);
-            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc[fi], 0, 0, 0);
-            if (more) load_u(cc + 1, fi);        // the next chunk's block lands in the same registers under the remaining MFMAs
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (more) store_v(buf ^ 1);
-        __syncthreads();
+    for (int j = 0; j < 4; ++j) col_store(0, j);
+    __syncthreads();
+    for (int cc = 0; cc < a.NC; cc += 2) {
+        WINO_ITER(0, cc);
+        if (cc + 1 < a.NC) WINO_ITER(1, cc + 1);
     }
+#undef WINO_ITER
+#undef WINO_ROW_PASS
+#undef WINO_LOAD_PATCH
 
     // ---- output transform: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1] ----
     // acc[fi][e]: frequency (i = 2 fh + (fi >> 2), j = fi & 3), tile row (e & 3) + 8 (e >> 2) + 4 lh, cout column l31.
     // Column pass per patch row i: r_i[0] = M_i0 + M_i1 + M_i2, r_i[1] = M_i1 - M_i2 - M_i3; row pass split over the pair:
     //   fh = 0 (i = 0, 1): P[0][y] = r_0[y] + r_1[y], P[1][y] = r_1[y];   fh = 1 (i = 2, 3): P[0][y] = r_2[y], P[1][y] = -r_2[y] - r_3[y]
     // stage S[ch][fh][xy][32 tiles][32 cout] floats (64 KB): the pair's partials are added by the transposed reader
+    if (DIAG & 1) {      // (timing diagnostic: no epilogue)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sum += acc[i][e];
+        if (sum == 123.456f) a.y[0] = sum;
+        return;
+    }
     float* S = reinterpret_cast<float*>(smem) + (ch * 2 + fh) * (4 * 32 * 32);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -298,10 +358,10 @@ extern "C" int32_t fd_wino_pack_weights_f32(const float* w, const float* scale, 
     return FD_OK;
 }
 
-template <int TAG>
+template <int TAG, int SV, int DIAG = 0, int UAUX = 0>
 static int launch_wino(const WinoArgs& a, hipStream_t stream) {
-    constexpr int lds = 64 * 1024;
-    auto kern = conv3x3_wino_kernel<TAG>;
+    const int lds = getenv("FD_WINO_LDS") ? atoi(getenv("FD_WINO_LDS")) * 1024 : 64 * 1024;
+    auto kern = conv3x3_wino_kernel<TAG, SV, DIAG, UAUX>;
     static std::atomic<unsigned> attr_mask{0};
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(8 * a.mt_per * a.ntiles), dim3(256), lds, stream, a);
@@ -352,5 +412,17 @@ int fd_launch_conv_wino(const fd_conv_params* p, hipStream_t stream) {
     a.mtiles = (a.T + WINO_TB - 1) / WINO_TB;
     a.ntiles = (p->Cout + WINO_NB - 1) / WINO_NB;
     a.mt_per = (a.mtiles + 7) / 8;
-    return p->tag == 1 ? launch_wino<1>(a, stream) : launch_wino<0>(a, stream);
+    // SV = 4: the input transform rides in the shadow of the iteration's last four frequency groups (SV 3..8 measured within 5 %)
+    static const int var = getenv("FD_WINO_VAR") ? atoi(getenv("FD_WINO_VAR")) : 0;    // (development knob)
+    if (var == 8) return launch_wino<0, 4, 8>(a, stream);     // patch loads only
+    if (var == 16) return launch_wino<0, 4, 16>(a, stream);   // transform + LDS writes only
+    if (var == 10) return launch_wino<0, 4, 0, 2>(a, stream);    // U loads nt
+    if (var == 11) return launch_wino<0, 4, 0, 1>(a, stream);    // U loads sc0
+    if (var == 12) return launch_wino<0, 4, 0, 17>(a, stream);   // U loads sc0 sc1
+    if (var == 1) return launch_wino<0, 4, 1>(a, stream);
+    if (var == 2) return launch_wino<0, 4, 2>(a, stream);
+    if (var == 4) return launch_wino<0, 4, 4>(a, stream);
+    if (var == 6) return launch_wino<0, 4, 6>(a, stream);
+    if (var == 7) return launch_wino<0, 4, 7>(a, stream);
+    return p->tag == 1 ? launch_wino<1, 4>(a, stream) : launch_wino<0, 4>(a, stream);
 }

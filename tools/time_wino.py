@@ -38,6 +38,13 @@ def bench(name, B, hw, Cin, Cout, dil, tiles):
 
 
 pyr = [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
+if os.environ.get("WINO_SHORT"):
+    bench("tower 256>512 pyramid B16", 16, pyr, 256, 512, 1, (7,))
+    bench("HisBlock3.conv4 256>256 d2 80x80", 16, [(80, 80)], 256, 256, 2, (9,))
+    bench("layer3.conv2 256>256 40x40", 16, [(40, 40)], 256, 256, 1, (4,))
+    bench("layer1.conv2 64>64 160x160", 16, [(160, 160)], 64, 64, 1, (8,))
+    bench("cls_logits 256>80 pyramid", 16, pyr, 256, 80, 1, (12,))
+    sys.exit(0)
 bench("tower 256>512 pyramid B16", 16, pyr, 256, 512, 1, (7, 1))
 bench("HisBlock3.conv4 256>256 d2 80x80", 16, [(80, 80)], 256, 256, 2, (9, 7))
 bench("HisBlock3.conv3 256>128 80x80", 16, [(80, 80)], 256, 128, 1, (9, 4))
