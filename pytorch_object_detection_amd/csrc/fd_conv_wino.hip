@@ -21,7 +21,6 @@
 //   * epilogue: each wave reduces its two patch rows of frequencies to partial 2x2 outputs, the pair (fh = 0, 1) meets in LDS,
 //     then y = act(v * scale + shift (+ / mask) res) with 16-byte stores, exactly the direct kernel's epilogue contract.
 #include "fd_conv_common.h"
-#include <stdlib.h>
 
 struct WinoArgs {
     const float* x; const float* u; const float* scale; const float* shift; const float* res; float* y;
@@ -69,7 +68,7 @@ __device__ __forceinline__ float dpp_quad_2211(float v) {   // lane i of a quad 
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
 }
 
-template <int TAG, int SV, int DIAG = 0, int UAUX = 0>
+template <int TAG>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Vs = reinterpret_cast<float*>(smem);          // [2 stages][16 f][32 tiles][8 c]; the epilogue reuses all 64 KB
@@ -106,9 +105,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
                            ? ((unsigned)(rowbase + ww) * (unsigned)a.x_cs + (unsigned)(a.x_co + q * 4)) * 4u : OOB;
         }
     }
-    // column pass of B^T d B across the quad: V[pi][j] = ss * t[pi][j] + so * t[{2, 2, 1, 1}[pi]][j]
-    const float ss = (pi == 3) ? -1.f : 1.f;
-    const float so = (pi & 1) ? 1.f : -1.f;
+    // column pass of B^T d B across the quad: V[pi][j] = t[pi][j] + so * t[{2, 2, 1, 1}[pi]][j]; patch row 3 is kept with the
+    // opposite sign (t3 - t1 = -V3: the weight packing negates U on its four frequencies, the products are unchanged)
+    const float so = (pi == 1) ? 1.f : -1.f;
     // V[f = 4 pi + j][tile][8 c]: tile rows XORed with pi (conflict-free ds_write_b128 over a quad), 16-B halves with tile bit 4
     // (conflict-free ds_read_b128 of the MFMA feed)
     const int v_wr = (pi * 4 * WINO_TB + (lt ^ pi)) * WINO_KC + 4 * (q ^ ((lt >> 4) & 1));
@@ -126,13 +125,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    // Main loop, one 8-channel chunk per iteration and workgroup barrier (two chunks per barrier measured 17 % SLOWER).  With
-    // everything but the MFMAs, the V reads and the barrier compiled out the loop runs at the matrix pipe's full rate; measured
-    // costs on top (head tower): patch loads + transform + LDS writes 17 %, U loads 6 %, epilogue 4 %.  So:
+    // Main loop, one 8-channel chunk per iteration and workgroup barrier.  With everything but the MFMAs, the V reads and the barrier
+    // compiled out the loop runs at the matrix pipe's full rate (head tower: 1.01 ms = 141 TFLOP/s at the clock the chip holds);
+    // measured costs on top: patch loads 11 %, transform + LDS writes 8 %, U loads 6 %, epilogue 4 %.  Tried and dropped: two chunks
+    // per barrier (slower), 16-channel stages with two patch rows per thread (64 B per pixel and load instruction, half the barriers:
+    // equal), L1-bypassing / non-temporal U loads (equal / 18 % slower), one workgroup per CU (13 % slower).  So:
     //   * the patch rows are fetched TWO chunks ahead (pr[2][4]; they miss L2 -- the input streams from the Infinity Cache / HBM --
     //     and one iteration of MFMAs does not cover that latency under load);
     //   * the transform of chunk cc + 1 is spread over the MFMA groups of iteration cc (row pass in group 2, one output column
-    //     = 4 fmac-with-DPP + 4 mul + one ds_write_b128 in each of groups 3..6), so its VALU issue fits the MFMAs' shadow;
+    //     = 4 v_fmac with a DPP operand + one ds_write_b128 in each of groups 3..6), so its VALU issue fits the MFMAs' shadow;
     //   * the U block of (cc + 1, fi) is fetched into the registers the MFMAs of fi have just consumed; V fragments are read two
     //     frequencies ahead.
     // The issue order is pinned with sched_barriers (left alone the compiler hoists the transform -- and with it a wait on loads it
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     float4 pr[2][4], bq[8];
     f32x4 tr[4];
     auto load_u = [&](int cc, int fi) {
-        bq[fi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (int)(u_off0 + ((unsigned)cc * 16u + fi) * 1024u), 0, UAUX));
+        bq[fi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (int)(u_off0 + ((unsigned)cc * 16u + fi) * 1024u), 0, 0));
     };
     constexpr int PLANE = WINO_TB * WINO_KC, STAGE = 16 * PLANE;
     // plane f = 8 fh + fi was written with tile rows XORed by its patch row (f >> 2) = 2 fh + (fi >> 2)
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float r = ss * tr[j][c];
+            float r = tr[j][c];
             asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(tr[j][c]), "v"(so));
             v[c] = r;
         }
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         const int cn1_ = min(cc_ + 1, a.NC - 1), cn2_ = min(cc_ + 2, a.NC - 1);                                                    \
         const float* Vb = Vs + (SLOT) * STAGE + v_rd;                                                                              \
         float4 fa[8];                                                                                                              \
-        if (!(DIAG & 2) && !(DIAG & 16)) { WINO_LOAD_PATCH(SLOT, cn2_); }                                                          \
+        WINO_LOAD_PATCH(SLOT, cn2_);                                                                                               \
         fa[0] = read_v(Vb, 0);                                                                                                     \
         fa[1] = read_v(Vb, 1);                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
@@ -193,16 +194,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
             acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fi].y, fb.y, acc[fi], 0, 0, 0);                                      \
             acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fi].z, fb.z, acc[fi], 0, 0, 0);                                      \
             acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fi].w, fb.w, acc[fi], 0, 0, 0);                                      \
-            if (!(DIAG & 4)) load_u(cn1_, fi);                                                                                     \
+            load_u(cn1_, fi);                                                                                                      \
             if (fi + 2 < 8) fa[fi + 2] = read_v(Vb, fi + 2);                                                                       \
-            if (!(DIAG & 2) && !(DIAG & 8)) {                                                                                      \
-                if (fi == 2) WINO_ROW_PASS((SLOT) ^ 1);                                                                            \
-                if (fi >= 3 && fi <= 6) col_store((SLOT) ^ 1, fi - 3);                                                             \
-            }                                                                                                                      \
-            if ((DIAG & 8) && fi == 2) {   /* (diagnostic: loads only -- keep them alive, no transform / LDS writes) */            \
-                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                  \
-                    asm volatile("" :: "v"(pr[(SLOT) ^ 1][j_].x), "v"(pr[(SLOT) ^ 1][j_].y), "v"(pr[(SLOT) ^ 1][j_].z), "v"(pr[(SLOT) ^ 1][j_].w)); \
-            }                                                                                                                      \
+            if (fi == 2) WINO_ROW_PASS((SLOT) ^ 1);                                                                                \
+            if (fi >= 3 && fi <= 6) col_store((SLOT) ^ 1, fi - 3);                                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                                     \
         }                                                                                                                          \
         __builtin_amdgcn_s_setprio(0);                                                                                             \
@@ -226,80 +221,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #undef WINO_ROW_PASS
 #undef WINO_LOAD_PATCH
 
-    // ---- output transform: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1] ----
-    // acc[fi][e]: frequency (i = 2 fh + (fi >> 2), j = fi & 3), tile row (e & 3) + 8 (e >> 2) + 4 lh, cout column l31.
-    // Column pass per patch row i: r_i[0] = M_i0 + M_i1 + M_i2, r_i[1] = M_i1 - M_i2 - M_i3; row pass split over the pair:
-    //   fh = 0 (i = 0, 1): P[0][y] = r_0[y] + r_1[y], P[1][y] = r_1[y];   fh = 1 (i = 2, 3): P[0][y] = r_2[y], P[1][y] = -r_2[y] - r_3[y]
-    // stage S[ch][fh][xy][32 tiles][32 cout] floats (64 KB): the pair's partials are added by the transposed reader
-    if (DIAG & 1) {      // (timing diagnostic: no epilogue)
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sum += acc[i][e];
-        if (sum == 123.456f) a.y[0] = sum;
-        return;
-    }
-    float* S = reinterpret_cast<float*>(smem) + (ch * 2 + fh) * (4 * 32 * 32);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const float ra0 = acc[0][e] + acc[1][e] + acc[2][e], ra1 = acc[1][e] - acc[2][e] - acc[3][e];
-        const float rb0 = acc[4][e] + acc[5][e] + acc[6][e], rb1 = acc[5][e] - acc[6][e] - acc[7][e];
-        float p00, p01, p10, p11;
-        if (fh == 0) { p00 = ra0 + rb0; p01 = ra1 + rb1; p10 = rb0; p11 = rb1; }
-        else { p00 = ra0; p01 = ra1; p10 = -ra0 - rb0; p11 = -ra1 - rb1; }
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        float* d = S + row * 32 + l31;
-        d[0 * 1024] = p00; d[1 * 1024] = p01; d[2 * 1024] = p10; d[3 * 1024] = p11;
-    }
-    __syncthreads();
-    {
-        const int tp = tid & 127, c4 = tp & 7, rg = tp >> 3;
-        const float* S0 = reinterpret_cast<const float*>(smem) + (ch * 2) * (4 * 32 * 32);
-        const int nn = n0 + ch * 32 + c4 * 4;
-        if (nn < a.Cout) {
-            const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + nn) : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float4 sf = a.shift ? *reinterpret_cast<const float4*>(a.shift + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int row = rg + 16 * half;
-                const TilePos p = wino_decode(a, tile0 + row);
-                if (!p.ok) continue;
-                const int H = a.H[p.s], W = a.W[p.s];
-                const float prm = a.seg_param[p.s];
-#pragma unroll
-                for (int xy = 0; xy < 4; ++xy) {
-                    const int h = p.h0 + (xy >> 1) * a.dil, w = p.w0 + (xy & 1) * a.dil;
-                    if (h >= H || w >= W) continue;
-                    const size_t m = (size_t)(a.m0[p.s] + (p.n * H + h) * W + w);
-                    const float4 va = *reinterpret_cast<const float4*>(S0 + (xy * 32 + row) * 32 + c4 * 4);
-                    const float4 vb = *reinterpret_cast<const float4*>(S0 + 4096 + (xy * 32 + row) * 32 + c4 * 4);
-                    float4 v = make_float4((va.x + vb.x) * sc.x + sf.x, (va.y + vb.y) * sc.y + sf.y,
-                                           (va.z + vb.z) * sc.z + sf.z, (va.w + vb.w) * sc.w + sf.w);
-                    if (a.res) {
-                        const float4 r = *reinterpret_cast<const float4*>(a.res + m * a.res_cs + a.res_co + nn);
-                        if (a.res_mask) {
-                            v.x = r.x > 0.f ? v.x : 0.f; v.y = r.y > 0.f ? v.y : 0.f;
-                            v.z = r.z > 0.f ? v.z : 0.f; v.w = r.w > 0.f ? v.w : 0.f;
-                        } else {
-                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                        }
-                    }
-                    if (a.act != FD_ACT_NONE) {
-                        if (nn + 0 >= a.act_c0) v.x = fd_act(v.x, a.act, prm);
-                        if (nn + 1 >= a.act_c0) v.y = fd_act(v.y, a.act, prm);
-                        if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, prm);
-                        if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, prm);
-                    }
-                    *reinterpret_cast<float4*>(a.y + m * a.y_cs + a.y_co + nn) = v;
-                }
-            }
-        }
-    }
+#include "fd_conv_wino_epilogue.inc"
 }
 
 // U = G g G^T per (cout, cin), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], computed in double and rounded once; packed
-// [ceil(Cout / 32)][Cin / 8][16 f][32 cout][8 c] (zero rows past Cout).  mode 1 = the weights of the data-gradient conv
+// [ceil(Cout / 32)][Cin / 8][16 f][32 cout][8 c] (zero rows past Cout; frequencies 12..15 negated, see the kernels).  mode 1 = the weights of the data-gradient conv
 // (N = Cin, K = Cout): g'[ci][co][r][q] = g[co][ci][2 - r][2 - q] * (scale ? scale[co] : 1).
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
                                                         int N, int K, int mode) {
@@ -331,10 +257,11 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
         float* o = out + (((long)nbk * (K >> 3) + cc) * 16) * 256 + nl * 8 + kl;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            o[(a * 4 + 0) * 256] = (float)t[a][0];
-            o[(a * 4 + 1) * 256] = (float)(0.5 * (t[a][0] + t[a][1] + t[a][2]));
-            o[(a * 4 + 2) * 256] = (float)(0.5 * (t[a][0] - t[a][1] + t[a][2]));
-            o[(a * 4 + 3) * 256] = (float)t[a][2];
+            const double sg = (a == 3) ? -1.0 : 1.0;     // the kernels form patch row 3 of B^T d B with the opposite sign
+            o[(a * 4 + 0) * 256] = (float)(sg * t[a][0]);
+            o[(a * 4 + 1) * 256] = (float)(sg * 0.5 * (t[a][0] + t[a][1] + t[a][2]));
+            o[(a * 4 + 2) * 256] = (float)(sg * 0.5 * (t[a][0] - t[a][1] + t[a][2]));
+            o[(a * 4 + 3) * 256] = (float)(sg * t[a][2]);
         }
     }
 }
@@ -358,10 +285,10 @@ extern "C" int32_t fd_wino_pack_weights_f32(const float* w, const float* scale, 
     return FD_OK;
 }
 
-template <int TAG, int SV, int DIAG = 0, int UAUX = 0>
+template <int TAG>
 static int launch_wino(const WinoArgs& a, hipStream_t stream) {
-    const int lds = getenv("FD_WINO_LDS") ? atoi(getenv("FD_WINO_LDS")) * 1024 : 64 * 1024;
-    auto kern = conv3x3_wino_kernel<TAG, SV, DIAG, UAUX>;
+    constexpr int lds = 64 * 1024;
+    auto kern = conv3x3_wino_kernel<TAG>;
     static std::atomic<unsigned> attr_mask{0};
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(8 * a.mt_per * a.ntiles), dim3(256), lds, stream, a);
@@ -412,17 +339,5 @@ int fd_launch_conv_wino(const fd_conv_params* p, hipStream_t stream) {
     a.mtiles = (a.T + WINO_TB - 1) / WINO_TB;
     a.ntiles = (p->Cout + WINO_NB - 1) / WINO_NB;
     a.mt_per = (a.mtiles + 7) / 8;
-    // SV = 4: the input transform rides in the shadow of the iteration's last four frequency groups (SV 3..8 measured within 5 %)
-    static const int var = getenv("FD_WINO_VAR") ? atoi(getenv("FD_WINO_VAR")) : 0;    // (development knob)
-    if (var == 8) return launch_wino<0, 4, 8>(a, stream);     // patch loads only
-    if (var == 16) return launch_wino<0, 4, 16>(a, stream);   // transform + LDS writes only
-    if (var == 10) return launch_wino<0, 4, 0, 2>(a, stream);    // U loads nt
-    if (var == 11) return launch_wino<0, 4, 0, 1>(a, stream);    // U loads sc0
-    if (var == 12) return launch_wino<0, 4, 0, 17>(a, stream);   // U loads sc0 sc1
-    if (var == 1) return launch_wino<0, 4, 1>(a, stream);
-    if (var == 2) return launch_wino<0, 4, 2>(a, stream);
-    if (var == 4) return launch_wino<0, 4, 4>(a, stream);
-    if (var == 6) return launch_wino<0, 4, 6>(a, stream);
-    if (var == 7) return launch_wino<0, 4, 7>(a, stream);
-    return p->tag == 1 ? launch_wino<1, 4>(a, stream) : launch_wino<0, 4>(a, stream);
+    return p->tag == 1 ? launch_wino<1>(a, stream) : launch_wino<0>(a, stream);
 }

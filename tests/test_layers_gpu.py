@@ -770,6 +770,7 @@ def test_winograd_weight_pack_and_dgrad():
     got = ops.pack_conv_weight_wino(w.to(DEV)).cpu().reshape(2, Cin // 8, 16, 32, 8)      # [nb][cc][f][co][c]
     exp = torch.zeros(16, 64, Cin, dtype=torch.float64)
     exp[:, :Cout] = U
+    exp[12:] = -exp[12:]          # the kernels form patch row 3 of B^T d B with the opposite sign: U carries the sign back
     exp = exp.reshape(16, 2, 32, Cin // 8, 8).permute(1, 3, 0, 2, 4)
     np.testing.assert_allclose(got.numpy(), exp.float().numpy(), rtol=0, atol=0)
     # data gradient through the same kernel
