@@ -192,7 +192,7 @@ typedef struct fd_pack_job {
     const float* w;      /* [Cout][Cin][KH][KW] */
     const float* scale;  /* [Cout] or NULL (mode 1 only) */
     float* out;
-    int32_t Cout, Cin, KH, KW, mode, reserved;
+    int32_t Cout, Cin, KH, KW, mode, reserved; /* mode: 0 / 1 as fd_pack_conv_weight_f32; 2 / 3 = the Winograd packing of fd_wino_pack_weights_f32 (mode 0 / 1), 3x3 only */
 } fd_pack_job;
 int32_t fd_pack_conv_weights_batch_f32(const fd_pack_job* jobs_dev, int32_t n_jobs, int64_t max_elems, fd_stream_t stream);
 

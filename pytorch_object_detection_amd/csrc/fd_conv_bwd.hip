@@ -12,7 +12,7 @@
 // Replaces the weight-gradient half of torch's convolution_backward for the reference's train step (train.py:175-181).
 #include <algorithm>
 
-#include "fd_common.h"
+#include "fd_conv_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -258,6 +258,15 @@ extern "C" int32_t fd_pack_conv_weight_f32(const float* w, const float* scale, f
 // device memory, one workgroup range per job (blockIdx.y = job, grid-stride over its elements).
 __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const fd_pack_job* __restrict__ jobs) {
     const fd_pack_job j = jobs[blockIdx.y];
+    if (j.mode >= 2) {       // Winograd packing (fd_conv_wino.hip): mode 2 = forward, 3 = data-gradient weights; one (n, k) filter per thread
+        const int N = j.mode == 2 ? j.Cout : j.Cin, K = j.mode == 2 ? j.Cin : j.Cout;
+        const long total = (long)((N + 31) & ~31) * K;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int n = (int)(i / K), k = (int)(i - (long)n * K);
+            fd_wino_pack_one(j.w, j.scale, j.out, N, K, j.mode - 2, n, k);
+        }
+        return;
+    }
     const int taps = j.KH * j.KW;
     const int K = j.mode ? j.Cout : j.Cin;
     const long total = (long)j.Cout * j.Cin * taps;

@@ -59,3 +59,41 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
 // split-f16 planes: rows of 32 halves (64 B); c8 = 16-byte chunk (8 halves) 0..3, XOR-swizzled by (row>>2)&3
 __device__ __forceinline__ int lds_off_h(int row, int c8) { return row * 32 + ((c8 ^ ((row >> 2) & 3)) << 3); }
+
+// Winograd F(2x2, 3x3) weight transform of ONE (n, k) filter: U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], computed in double
+// and rounded once, written to the [ceil(N / 32)][K / 8][16 f][32 n][8 k] packing of fd_conv_wino.hip (frequencies 12..15 negated: the
+// kernel forms patch row 3 of B^T d B with the opposite sign).  mode 0: g = w[n][k] (N = Cout, K = Cin).  mode 1 (data-gradient
+// conv: N = Cin, K = Cout): g[r][q] = w[k][n][2 - r][2 - q] * (scale ? scale[k] : 1).  n >= N writes zeros (padding rows).
+__device__ __forceinline__ void fd_wino_pack_one(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
+                                                 int N, int K, int mode, int n, int k) {
+    double g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = 0.0;
+            if (n < N) {
+                if (mode == 0) v = w[((long)n * K + k) * 9 + r * 3 + c];
+                else v = (double)w[((long)k * N + n) * 9 + (2 - r) * 3 + (2 - c)] * (scale ? (double)scale[k] : 1.0);
+            }
+            g[r][c] = v;
+        }
+    double t[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        t[0][c] = g[0][c];
+        t[1][c] = 0.5 * (g[0][c] + g[1][c] + g[2][c]);
+        t[2][c] = 0.5 * (g[0][c] - g[1][c] + g[2][c]);
+        t[3][c] = g[2][c];
+    }
+    const int nbk = n >> 5, nl = n & 31, cc = k >> 3, kl = k & 7;
+    float* o = out + (((long)nbk * (K >> 3) + cc) * 16) * 256 + nl * 8 + kl;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double sg = (a == 3) ? -1.0 : 1.0;
+        o[(a * 4 + 0) * 256] = (float)(sg * t[a][0]);
+        o[(a * 4 + 1) * 256] = (float)(sg * 0.5 * (t[a][0] + t[a][1] + t[a][2]));
+        o[(a * 4 + 2) * 256] = (float)(sg * 0.5 * (t[a][0] - t[a][1] + t[a][2]));
+        o[(a * 4 + 3) * 256] = (float)(sg * t[a][2]);
+    }
+}

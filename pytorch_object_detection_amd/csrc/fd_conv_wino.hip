@@ -233,36 +233,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     const long total = (long)Np * K;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int n = (int)(i / K), k = (int)(i - (long)n * K);
-        double g[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double v = 0.0;
-                if (n < N) {
-                    if (mode == 0) v = w[((long)n * K + k) * 9 + r * 3 + c];
-                    else v = (double)w[((long)k * N + n) * 9 + (2 - r) * 3 + (2 - c)] * (scale ? (double)scale[k] : 1.0);
-                }
-                g[r][c] = v;
-            }
-        double t[4][3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            t[0][c] = g[0][c];
-            t[1][c] = 0.5 * (g[0][c] + g[1][c] + g[2][c]);
-            t[2][c] = 0.5 * (g[0][c] - g[1][c] + g[2][c]);
-            t[3][c] = g[2][c];
-        }
-        const int nbk = n >> 5, nl = n & 31, cc = k >> 3, kl = k & 7;
-        float* o = out + (((long)nbk * (K >> 3) + cc) * 16) * 256 + nl * 8 + kl;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const double sg = (a == 3) ? -1.0 : 1.0;     // the kernels form patch row 3 of B^T d B with the opposite sign
-            o[(a * 4 + 0) * 256] = (float)(sg * t[a][0]);
-            o[(a * 4 + 1) * 256] = (float)(sg * 0.5 * (t[a][0] + t[a][1] + t[a][2]));
-            o[(a * 4 + 2) * 256] = (float)(sg * 0.5 * (t[a][0] - t[a][1] + t[a][2]));
-            o[(a * 4 + 3) * 256] = (float)(sg * t[a][2]);
-        }
+        fd_wino_pack_one(w, scale, out, N, K, mode, n, k);
     }
 }
 

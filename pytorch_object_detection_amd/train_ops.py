@@ -167,31 +167,45 @@ class _PackCache:
         self.table = None           # (signature, device tensor of fd_pack_job, max_elems)
 
     @staticmethod
-    def _key(w, scale, dgrad):
-        return (w.data_ptr(), tuple(w.shape), bool(dgrad), scale.data_ptr() if (scale is not None and dgrad) else 0)
+    def _key(w, scale, dgrad, wino=False):
+        return (w.data_ptr(), tuple(w.shape), bool(dgrad), scale.data_ptr() if (scale is not None and dgrad) else 0, bool(wino))
 
-    def get(self, w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False) -> torch.Tensor:
+    @staticmethod
+    def _pack_now(w, scale, dgrad, wino):
+        if not wino:
+            return ops.pack_conv_weight_hip(w, scale, dgrad)
+        out = ops.pack_conv_weight_wino(w, scale, dgrad)
+        out._fd_wino = (w.shape[1] if dgrad else w.shape[0])       # marks the Winograd packing for _conv_launch (value = output channels)
+        return out
+
+    def get(self, w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False, wino: bool = False) -> torch.Tensor:
+        """Packed weights for the conv kernel: the direct kernel's layout, or (wino=True, 3x3 stride-1 'same' layers) the Winograd
+        F(2x2, 3x3) packing of fd_conv_wino.hip; dgrad=True = the flipped / transposed / BN-scaled weights of the data gradient."""
         import weakref
         if isinstance(w, nn.Parameter) and w.is_contiguous():
             self.params[w.data_ptr()] = weakref.ref(w)
         ref = self.params.get(w.data_ptr())
         owner = ref() if ref is not None else None
         if owner is None or owner.data_ptr() != w.data_ptr() or owner.shape != w.shape or not w.is_contiguous():
-            return ops.pack_conv_weight_hip(w, scale, dgrad)             # a temporary (merged / padded weights): pack now
-        key = self._key(w, scale, dgrad)
+            return self._pack_now(w, scale, dgrad, wino)                  # a temporary (merged / padded weights): pack now
+        key = self._key(w, scale, dgrad, wino)
         e = self.entries.get(key)
         if e is not None and e[0]() is not owner:       # the address was recycled by another parameter: drop the old entry
             e = None
         if e is None:
-            out = ops.pack_conv_weight_hip(w, scale, dgrad)
+            out = self._pack_now(w, scale, dgrad, wino)
             self.entries[key] = [ref, scale, dgrad, out, w._version]
             self.table = None
             return out
         if e[4] != w._version:                                            # changed since the last refresh: re-pack in place
             co, ci, kh, kw = w.shape
-            ops.check(_lib.lib().fd_pack_conv_weight_f32(w.data_ptr(), scale.data_ptr() if (scale is not None and dgrad) else None,
-                                                         e[3].data_ptr(), co, ci, kh, kw, 1 if dgrad else 0, ops._stream()),
-                      "fd_pack_conv_weight_f32")
+            sp = scale.data_ptr() if (scale is not None and dgrad) else None
+            if wino:
+                ops.check(_lib.lib().fd_wino_pack_weights_f32(w.data_ptr(), sp, e[3].data_ptr(), co, ci, 1 if dgrad else 0, ops._stream()),
+                          "fd_wino_pack_weights_f32")
+            else:
+                ops.check(_lib.lib().fd_pack_conv_weight_f32(w.data_ptr(), sp, e[3].data_ptr(), co, ci, kh, kw, 1 if dgrad else 0,
+                                                             ops._stream()), "fd_pack_conv_weight_f32")
             e[4] = w._version
         return e[3]
 
@@ -201,10 +215,10 @@ class _PackCache:
         newest: dict = {}        # (param address, shape) -> newest data-gradient entry: a re-folded frozen BN (load_state_dict) makes
         for key, e in self.entries.items():      # a new scale tensor and a new entry; the superseded one is dropped here
             if key[2]:
-                newest[key[:2]] = key
+                newest[(key[0], key[1], key[4])] = key
         for key, e in self.entries.items():
             p = e[0]()
-            if p is not None and p.data_ptr() == key[0] and tuple(p.shape) == key[1] and (not key[2] or newest[key[:2]] == key):
+            if p is not None and p.data_ptr() == key[0] and tuple(p.shape) == key[1] and (not key[2] or newest[(key[0], key[1], key[4])] == key):
                 live[key] = e
         self.params = {a: r for a, r in self.params.items() if r() is not None}
         if len(live) != len(self.entries):
@@ -218,7 +232,7 @@ class _PackCache:
             for j, (key, e) in zip(jobs, live.items()):
                 co, ci, kh, kw = key[1]
                 j.w, j.scale, j.out = key[0], (e[1].data_ptr() if (e[1] is not None and e[2]) else None), e[3].data_ptr()
-                j.Cout, j.Cin, j.KH, j.KW, j.mode = co, ci, kh, kw, 1 if e[2] else 0
+                j.Cout, j.Cin, j.KH, j.KW, j.mode = co, ci, kh, kw, (2 if key[4] else 0) + (1 if e[2] else 0)
                 mx = max(mx, co * ci * kh * kw)
             raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).clone()
             dev = next(iter(live.values()))[3].device
@@ -231,6 +245,13 @@ class _PackCache:
 
 PACKS = _PackCache()
 
+
+def _wino(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bool:
+    """3x3 stride-1 'same' layers run on the Winograd kernel -- forward (Cin -> Cout) and, with the channel roles swapped, data
+    gradient -- unless FD_WINOGRAD=0 (the switch of the inference plans)."""
+    from . import engine
+    return engine.WINOGRAD and ops.wino_ok(Cin, Cout, k, stride, pad, dil)
+
 _TILE_CACHE: dict = {}
 
 
@@ -239,6 +260,11 @@ def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.T
     """y = act(conv(x, w) * scale + shift + res) on contiguous rows buffers; w_packed from ops.pack_conv_weight_hip.
     The block tile comes from the same table / heuristic / FD_AUTOTUNE timing as the inference plans (ops.autotune_conv),
     remembered per shape for the process."""
+    wino_cout = getattr(w_packed, "_fd_wino", 0)
+    if wino_cout:        # the Winograd packing (PACKS.get(..., wino=True)): fd_conv_wino.hip, no tile choice
+        ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=x.shape[1], Cout=wino_cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
+                      shift=shift, res=_r(res) if res is not None else None, act=act, res_mask=res_mask, tile=_lib.WINO_TILE)()
+        return
     Cin, Cout = x.shape[1], w_packed.shape[0]
     out_rows = y.shape[0]
     KT = (Cin // 32) * k * k
@@ -291,8 +317,8 @@ class _ConvRows(torch.autograd.Function):
         Cout, _, k, _ = weight.shape
         so = ops.conv_out_segs(segs, k, stride, pad, dil)
         y = torch.empty(so.rows, Cout, dtype=torch.float32, device=x.device)
-        _conv_launch(x, segs, PACKS.get(weight), y, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
-                     shift=shift.detach().contiguous() if shift is not None else None,
+        _conv_launch(x, segs, PACKS.get(weight, wino=_wino(x.shape[1], Cout, k, stride, pad, dil)), y, k=k, stride=stride, pad=pad,
+                     dil=dil, scale=scale, shift=shift.detach().contiguous() if shift is not None else None,
                      res=residual.contiguous() if residual is not None else None, act=act)
         ctx.save_for_backward(x, weight, scale, y if act == ACT_RELU else None)
         ctx.geom = (segs, so, stride, pad, dil, act)
@@ -314,8 +340,8 @@ class _ConvRows(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if stride == 1 and Cout % 32 == 0:
                 gx = torch.empty_like(x)
-                _conv_launch(g, so, PACKS.get(weight, scale, dgrad=True), gx, k=k, stride=1,
-                             pad=dil * (k - 1) - pad, dil=dil)
+                _conv_launch(g, so, PACKS.get(weight, scale, dgrad=True, wino=_wino(Cout, Cin, k, stride, dil * (k - 1) - pad, dil)), gx,
+                             k=k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
             elif segs.nseg == 1 and stride > 1 and dil == 1 and (gx := _strided_dgrad(g, weight, scale, segs, k, stride, pad)) is not None:
                 pass                                   # strided layer: one exact-FLOP launch per parity class (ops.conv_dgrad_strided)
             elif segs.nseg == 1:  # what is left (narrow Cout, dilated + strided): stock op for the data gradient
@@ -384,7 +410,7 @@ class _BottleneckRows(torch.autograd.Function):
         y2 = torch.empty(so.rows, P, dtype=torch.float32, device=dev)
         out = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
         _conv_launch(x, segs, PACKS.get(w1), y1, k=1, stride=1, pad=0, dil=1, scale=c1[0], shift=c1[1], act=ACT_RELU)
-        _conv_launch(y1, segs, PACKS.get(w2), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0], shift=c2[1],
+        _conv_launch(y1, segs, PACKS.get(w2, wino=_wino(P, P, 3, stride, 1, 1)), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0], shift=c2[1],
                      act=ACT_RELU)
         if wd is not None:
             idt = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
@@ -416,7 +442,8 @@ class _BottleneckRows(torch.autograd.Function):
             gw2 = wg(y1, g2, segs, P, P, 3, stride, 1, s2)
         if stride == 1:
             g1 = torch.empty_like(y1)
-            _conv_launch(g2, so, PACKS.get(w2, s2, dgrad=True), g1, k=3, stride=1, pad=1, dil=1, res=y1, res_mask=True)
+            _conv_launch(g2, so, PACKS.get(w2, s2, dgrad=True, wino=_wino(w2.shape[0], w2.shape[1], 3, 1, 1, 1)), g1, k=3, stride=1, pad=1, dil=1,
+                         res=y1, res_mask=True)
         elif (g1 := _strided_dgrad(g2, w2, s2, segs, 3, stride, 1, res=y1, res_mask=True)) is not None:
             pass    # strided 3x3: four parity-class launches on the conv kernel, ReLU mask of y1 applied in their epilogues
         else:   # strided 3x3: stock data gradient, masked separately

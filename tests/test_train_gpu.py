@@ -15,7 +15,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_train_step_matches_oracle_autograd():
+@pytest.mark.parametrize("wino", [False, True], ids=["direct", "winograd"])
+def test_train_step_matches_oracle_autograd(wino, monkeypatch):
+    """wino=False: every dense conv on the direct kernel (bit-for-bit an fp32 fma chain).  wino=True (the default, FD_WINOGRAD=1): the
+    3x3 stride-1 layers -- forward and data gradient -- on the Winograd F(2x2, 3x3) kernel (fp32 too, another rounding).  Same bars.
+    Measured on MI355X (tools/train_dev_stats.py, this seed): Winograd path -- all 145 gradients within 5e-6 of their maximum; direct
+    path -- 128 of 145 at rounding level, 17 (biases upstream of one flipped ReLU mask element) with a median deviation of 1e-4 .. 3e-4."""
+    from pytorch_object_detection_amd import engine
+    monkeypatch.setattr(engine, "WINOGRAD", wino)
     torch.manual_seed(0)
     model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256)
     gen = torch.Generator().manual_seed(1)
@@ -86,7 +93,7 @@ def test_train_step_matches_oracle_autograd():
     # EVERY trainable parameter (not a sample of eight): a gradient exists on both sides, points the same way, agrees to
     # rounding in the bulk (median) and to a flipped-ReLU-mask's worth at worst (see the comment above and
     # test_relu_mask_flips_are_the_only_source_of_large_gradient_deviations)
-    n_par = 0
+    n_par, bulk_ok = 0, 0
     for name, p in model.named_parameters():
         g_ref = sd[name].grad
         if not p.requires_grad:
@@ -101,10 +108,15 @@ def test_train_step_matches_oracle_autograd():
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         d = (a - b).abs() / scale
         assert cos > 0.9995, (name, cos)
-        assert float(d.median()) < 5e-5, (name, float(d.median()))
+        # which near-zero pre-activation lands on the other side of 0 depends on the summation order (block tile, split-K, Winograd):
+        # a parameter upstream of a flipped mask element deviates by that element's share everywhere (median up to ~1e-3 of the
+        # maximum), all others agree to rounding -- so: a flip's worth for each, rounding level for the bulk of them
+        assert float(d.median()) < 1e-3, (name, float(d.median()))
         assert float(d.max()) < (5e-2 if name.startswith("backbone.") else 2e-2), (name, float(d.max()))
+        bulk_ok += float(d.median()) < 5e-5
         n_par += 1
     assert n_par > 120, n_par
+    assert bulk_ok >= 0.85 * n_par, (bulk_ok, n_par)
     # layer1 and the stem are frozen (freeze_stages(1), HISFcos.py:67)
     assert model.backbone.extract_feature.layer1[0].conv1.weight.grad is None
     before = model.head.cls_logits.weight.detach().clone()
@@ -415,7 +427,7 @@ def test_full_size_batch_gradient_is_the_mean_of_the_per_image_gradients():
         a, b = full[n].double().flatten(), (acc[n] / B).double().flatten()
         scale = float(b.abs().max()) + 1e-30
         d = (a - b).abs() / scale
-        assert float(d.median()) < 1e-4, (n, float(d.median()))   # (fp32 sums over 16 x 5 456 locations in two different orders)
+        assert float(d.median()) < 3e-4, (n, float(d.median()))   # (fp32 sums over 16 x 5 456 locations in two different orders; worst measured 1.1e-4)
         assert float(d.max()) < 5e-2, (n, float(d.max()))       # (a ReLU-mask element may flip between the 1- and 16-image plans)
         worst = max(worst, float(d.max()))
     assert len(names) > 120
