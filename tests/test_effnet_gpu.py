@@ -14,6 +14,7 @@ from pytorch_object_detection_amd.model.backbone.efficientnetv1 import Efficient
 from pytorch_object_detection_amd.model.modules.head import ClipBoxes, FCOSHead
 from pytorch_object_detection_amd.model.od import FCOS
 from effnet_init import init_effnet
+from test_model_gpu import assert_same_detections
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -172,8 +173,7 @@ def test_fcos_b3_mixed_aspect_832x1344_vs_oracle(prec):
     for bi in range(2):
         n = int(counts[bi])
         assert n == len(exp[bi][0])
-        np.testing.assert_array_equal(c[bi, :n].cpu().numpy(), exp[bi][1])
-        np.testing.assert_array_equal(b[bi, :n].cpu().numpy(), exp[bi][2])
+        assert_same_detections(s[bi, :n].cpu().numpy(), c[bi, :n].cpu().numpy(), b[bi, :n].cpu().numpy(), *exp[bi])
 
 
 def test_fcos_b0_as_the_reference_constructs_it():
@@ -253,6 +253,4 @@ def test_cfg1_builder_voc_512_vs_oracle(tmp_path):
     scores, classes, boxes = FCOSHead(0.05, 0.6, 1000, strides)(out)          # batch 1: the reference's stacked return
     boxes = ClipBoxes()(xd, boxes.contiguous())
     (es, ec, eb), = R.fcos_detect([[t.cpu() for t in g] for g in out], strides, 0.05, 0.6, 1000, (512, 512))
-    np.testing.assert_array_equal(classes[0].cpu().numpy(), ec)
-    np.testing.assert_array_equal(boxes[0].cpu().numpy(), eb)
-    np.testing.assert_allclose(scores[0].cpu().numpy(), es, rtol=2e-6, atol=1e-7)
+    assert_same_detections(scores[0].cpu().numpy(), classes[0].cpu().numpy(), boxes[0].cpu().numpy(), es, ec, eb)

@@ -31,6 +31,25 @@ def randomize_norms(model, seed):
             m.weight.data.copy_(torch.rand(m.num_channels, generator=gen) + 0.5)
             m.bias.data.copy_(torch.randn(m.num_channels, generator=gen) * 0.1)
 
+def assert_same_detections(s, c, b, es, ec, eb):
+    """HIP detections of one image against the oracle post-process of the SAME head outputs.  Boxes and classes are exact; the
+    device's sigmoid / sqrt (expf, IEEE divide) and the host libm round a score differently in the last bit now and then (~2 % of
+    the candidates, 1 ulp), so two candidates whose scores are an ulp apart may come out in either order: the comparison is made on
+    the detections sorted by (class, box) -- identical sets, scores within 2 ulp -- plus 'scores descend' on the device's order."""
+    s, c, b = np.asarray(s), np.asarray(c), np.asarray(b)
+    assert len(s) == len(es) == len(c) == len(ec)
+    assert (np.diff(s) <= 0).all(), "device scores are not in descending order"
+
+    def canon(cc, bb):
+        return np.lexsort((bb[:, 3], bb[:, 2], bb[:, 1], bb[:, 0], cc))
+    i, j = canon(c, b), canon(np.asarray(ec), np.asarray(eb))
+    np.testing.assert_array_equal(c[i], np.asarray(ec)[j])
+    np.testing.assert_array_equal(b[i], np.asarray(eb)[j])
+    np.testing.assert_allclose(s[i], np.asarray(es)[j], rtol=2e-6, atol=1e-7)
+    moved = int((i != j).sum())
+    assert moved <= max(4, len(s) // 50), f"{moved} detections out of the oracle's order"     # (only neighbours an ulp apart may swap)
+
+
 
 def test_tiny_hisfcos_fpn_head_golden(golden):
     g = golden("g8_tiny_hisfcos")
@@ -97,9 +116,7 @@ def test_full_hisfcos_vs_oracle(shape, prec):
     for bi in range(B):
         n = int(counts[bi])
         assert n == len(exp[bi][0])
-        np.testing.assert_array_equal(c[bi, :n].cpu().numpy(), exp[bi][1])
-        np.testing.assert_array_equal(b[bi, :n].cpu().numpy(), exp[bi][2])
-        np.testing.assert_allclose(s[bi, :n].cpu().numpy(), exp[bi][0], rtol=2e-6, atol=1e-7)
+        assert_same_detections(s[bi, :n].cpu().numpy(), c[bi, :n].cpu().numpy(), b[bi, :n].cpu().numpy(), *exp[bi])
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
@@ -165,8 +182,7 @@ def test_baseline_config_640_batch2_vs_oracle(prec):
     for bi in range(2):
         n = int(counts[bi])
         assert n == len(exp[bi][0])
-        np.testing.assert_array_equal(c[bi, :n].cpu().numpy(), exp[bi][1])
-        np.testing.assert_array_equal(b[bi, :n].cpu().numpy(), exp[bi][2])
+        assert_same_detections(s[bi, :n].cpu().numpy(), c[bi, :n].cpu().numpy(), b[bi, :n].cpu().numpy(), *exp[bi])
 
 
 def test_mixed_aspect_832x1344_pyramid():
@@ -195,8 +211,7 @@ def test_mixed_aspect_832x1344_pyramid():
     exp = R.fcos_detect([[t.cpu() for t in grp] for grp in out], [8, 16, 32, 64, 128], 0.05, 0.6, 1000)
     n = int(counts[0])
     assert n == len(exp[0][0])
-    np.testing.assert_array_equal(c[0, :n].cpu().numpy(), exp[0][1])
-    np.testing.assert_array_equal(b[0, :n].cpu().numpy(), exp[0][2])
+    assert_same_detections(s[0, :n].cpu().numpy(), c[0, :n].cpu().numpy(), b[0, :n].cpu().numpy(), *exp[0])
 
 
 def test_uint8_input_matches_normalised_float_input():
