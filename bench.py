@@ -33,6 +33,9 @@ def build_model(num_classes: int, seed: int, name: str = "HISFCOS"):
     torch.manual_seed(seed)
     if name == "FCOS":   # the baseline detector behind the same API; diagnostic, not the headline
         model = FCOS([2048, 1024, 512], num_classes, 256).eval()
+    elif name == "MNFCOS":   # the detector the reference's config/main.yaml selects; diagnostic, not the headline
+        from pytorch_object_detection_amd.model.od import MNFCOS
+        model = MNFCOS([2048, 1024, 512], num_classes, 256).eval()
     elif name == "FCOS-B3":   # BASELINE configs[4]: EfficientNet-B3 trunk; diagnostic, not the headline
         model = FCOS([384, 136, 48], num_classes, 256, efficientnet=True, backbone_number=3).eval()
         gen = torch.Generator().manual_seed(seed + 2)
@@ -443,7 +446,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", default="640", help="input size: S (square) or HxW, multiples of 32 (Cfg5: 832x1344)")
     ap.add_argument("--classes", type=int, default=80)
-    ap.add_argument("--model", default="HISFCOS", choices=["HISFCOS", "FCOS", "FCOS-B3"],
+    ap.add_argument("--model", default="HISFCOS", choices=["HISFCOS", "FCOS", "FCOS-B3", "MNFCOS"],
                     help="FCOS / FCOS-B3 = diagnostic runs of the baseline detector on ResNet-50 / EfficientNet-B3 (Cfg5)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = diagnostic: the Cfg4 training step (DDP over RCCL for N > 1)")
     ap.add_argument("--inflight", type=int, default=2, choices=[1, 2],

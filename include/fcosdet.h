@@ -242,6 +242,14 @@ int32_t fd_dwconv3x3_bwd_weight_nhwc(const float* x, int32_t x_cs, int32_t x_co,
                                      int32_t dy_co, float* dw, int32_t C, const float* scale, int32_t layout,
                                      const fd_segs* segs, void* workspace, fd_stream_t stream);
 
+/* Dilated depthwise k x k convolution, stride 1, 'same' zero padding (pad = dil * (k - 1) / 2), y = act(dw(x) * scale + shift), over any
+ * pyramid: MNBlock.DilatedDepthWiseConv + BN of the reference's model/modules/modules.py:195-216 (MNFCOS: model/od/MNFcos.py:222-297;
+ * as shipped MNBlock pads with `dilation`, which keeps the size only for k = 3 -- its residual add raises for k = 5 / 7 -- the
+ * 'same' padding is the repaired behaviour).  k in {3, 5, 7}; w packed [K*K][C] (tap major); C % 4 == 0. */
+int32_t fd_dwconv_dilated_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w, const float* scale, const float* shift,
+                               float* y, int32_t y_cs, int32_t y_co, int32_t C, int32_t K, int32_t dil, int32_t act,
+                               const fd_segs* segs, fd_stream_t stream);
+
 /* Depthwise k x k convolution with stride and asymmetric zero padding, y = act(dw(x)*scale + shift): the depthwise
  * stage of an EfficientNet MBConv block (efficientnet_pytorch 0.7.1 MBConvBlock._depthwise_conv + _bn1 + swish, wrapped by
  * the reference's model/backbone/efficientnetv1.py:11-26; Conv2dStaticSamePadding pads (pad//2, pad - pad//2), i.e. more at

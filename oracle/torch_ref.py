@@ -173,6 +173,56 @@ def fcos_forward(sd: SD, x: torch.Tensor):
 
 
 # ----------------------------------------------------------------------------------------------
+# MNFCOS (reference model/od/MNFcos.py:11-36,222-297; model/modules/modules.py:195-216) — what config/main.yaml:2 selects
+# ----------------------------------------------------------------------------------------------
+def mn_block(sd: SD, p: str, x: torch.Tensor, k: int, dil: int) -> torch.Tensor:
+    """MNBlock.forward, modules.py:209-216: x + PW2(SiLU(PW1(BN(dilated depthwise(x))))).
+    As shipped the depthwise conv is padded with `dilation` (modules.py:203), which keeps the size only for k = 3; for the k = 5 / 7
+    blocks of the light-weight FPN the residual add raises (pinned as `fpn_raises` in g10_mnfcos_parts.npz).  Restated with the 'same'
+    padding dil * (k - 1) / 2 -- identical to the reference for k = 3 (pinned by g10), the repaired behaviour for k = 5 / 7
+    (parity unpinned: there is no reference output)."""
+    c = x.shape[1]
+    y = _conv(sd, p + "DilatedDepthWiseConv", x, 1, dil * (k - 1) // 2, dil, c)
+    y = _bn(sd, p + "BN", y)
+    y = F.silu(_conv(sd, p + "PW1", y))
+    return x + _conv(sd, p + "PW2", y)
+
+
+MN_FPN_BLOCKS = {"MNB3": (3, 1), "MNB4": (3, 2), "MNB5": (5, 2), "MNB6": (5, 1), "MNB7": (7, 1)}    # MNFcos.py:230-236 (kernel, dilation)
+
+
+def mn_fpn(sd: SD, feats: Sequence[torch.Tensor], p: str = "FeaturePyramidNetwork."):
+    """LieghtWeightFeaturePyramid_old.forward, MNFcos.py:239-256 (1x1 laterals with bias, nearest x2 upsample + add, 2x2 max-pool)."""
+    c3, c4, c5 = feats
+    up = lambda t: F.interpolate(t, scale_factor=2.0, mode="nearest")  # noqa: E731
+    blk = lambda n, t: mn_block(sd, p + n + ".", t, *MN_FPN_BLOCKS[n])  # noqa: E731
+    p5 = blk("MNB5", _conv(sd, p + "C5PW", c5))
+    p4 = blk("MNB4", up(p5) + _conv(sd, p + "C4PW", c4))
+    p3 = blk("MNB3", up(p4) + _conv(sd, p + "C3PW", c3))
+    p6 = blk("MNB6", F.max_pool2d(p5, 2, 2))
+    p7 = blk("MNB7", F.max_pool2d(p6, 2, 2))
+    return p3, p4, p5, p6, p7
+
+
+def mn_head(sd: SD, feats: Sequence[torch.Tensor], p: str = "head."):
+    """MNHeadFCOS.forward, MNFcos.py:285-297: two MNBlock(f, f, 3, 2, 2), 3x3 + GroupNorm(32) + SiLU towers, 1x1 predictors, ScaleExp."""
+    cls_l, cnt_l, reg_l = [], [], []
+    for i, f in enumerate(feats):
+        f = mn_block(sd, p + "block2.", mn_block(sd, p + "block1.", f, 3, 2), 3, 2)
+        c = F.silu(_gn(sd, p + "cls_conv.1", _conv(sd, p + "cls_conv.0", f, 1, 1)))
+        r = F.silu(_gn(sd, p + "reg_conv.1", _conv(sd, p + "reg_conv.0", f, 1, 1)))
+        cls_l.append(_conv(sd, p + "cls_logits", c))
+        cnt_l.append(_conv(sd, p + "cnt_logits", r))
+        reg_l.append(torch.exp(_conv(sd, p + "reg_pred", r) * sd[p + f"scale_exp.{i}.scale"]))
+    return cls_l, cnt_l, reg_l
+
+
+def mnfcos_forward(sd: SD, x: torch.Tensor):
+    """MNFCOS.forward, MNFcos.py:32-36 (backbone ResNet50v2: keys backbone.extract_feature.*)."""
+    return mn_head(sd, mn_fpn(sd, resnet50_c345(sd, x)))
+
+
+# ----------------------------------------------------------------------------------------------
 # post-processing (reference model/modules/head.py, utill/utills.py) — C restatement via ctypes
 # ----------------------------------------------------------------------------------------------
 _HERE = os.path.dirname(os.path.abspath(__file__))

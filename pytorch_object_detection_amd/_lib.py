@@ -98,6 +98,7 @@ _SIGS = {
     "fd_upsample2x_add_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fd_dwconv3x3_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(Segs), _P]),
     "fd_dwconv2d_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fd_dwconv_dilated_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(Segs), _P]),
     "fd_stem_conv_nhwc4": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fd_collate_u8_nhwc4": (_I, [_P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
     "fd_dwconv3x3_wgrad_workspace_bytes": (_L, [C.POINTER(Segs), _I]),

@@ -16,7 +16,7 @@ from .utill.utills import load_config  # noqa: F401  (re-exported: `from bulider
 
 def _detectors() -> Dict[str, Callable[..., nn.Module]]:
     from .model import od
-    return {"FCOS": od.Fcos.FCOS, "HISFCOS": od.HISFcos.HalfInvertedStageFCOS}
+    return {"FCOS": od.Fcos.FCOS, "HISFCOS": od.HISFcos.HalfInvertedStageFCOS, "MNFCOS": od.MNFcos.MNFCOS}
 
 
 _OPTIMIZERS: Dict[str, Callable[..., torch.optim.Optimizer]] = {
@@ -44,7 +44,7 @@ class Builder:
         block = self._block()
         ctor = _detectors().get(self.model)
         if ctor is None:
-            raise NotImplementedError(f"model '{self.model}' is outside the MI355X hot path (FCOS, HISFCOS)")
+            raise NotImplementedError(f"model '{self.model}' is outside the MI355X hot path (FCOS, HISFCOS, MNFCOS)")
         return ctor(block["CannelofBackbone"], self.config["dataset_setting"]["class_num"], block["channel"])
 
     def opt_build(self, model: nn.Module) -> torch.optim.Optimizer:

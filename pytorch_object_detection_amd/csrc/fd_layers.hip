@@ -456,6 +456,62 @@ extern "C" int32_t fd_dwconv3x3_nhwc(const float* x, int32_t x_cs, int32_t x_co,
     return FD_OK;
 }
 
+// ---- dilated depthwise k x k, stride 1, 'same' padding (pad = dil * (k - 1) / 2), any pyramid: the DilatedDepthWiseConv of the
+// reference's MNBlock (model/modules/modules.py:195-216, used by MNFCOS's light-weight FPN / head, model/od/MNFcos.py:222-297) with its
+// BatchNorm folded in.  One thread = one pixel x 4 channels (MNFCOS maps are 128-256 channels on <= 80 x 80: a launch-latency-sized op).
+__global__ __launch_bounds__(256) void dwconv_dilated_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ wt,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float* __restrict__ y, int y_cs, int y_co, int C, int K, int dil, int act,
+                                                              SegTab tab, long total) {
+    const int C4 = C >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const long m = i / C4;
+        int H, W, h, w;
+        long row0;
+        seg_decode(tab.s, m, H, W, row0, h, w);
+        const int half = (K - 1) / 2;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < K; ++r) {
+            const int hi = h + (r - half) * dil;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int c = 0; c < K; ++c) {
+                const int wi = w + (c - half) * dil;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + (row0 + (long)hi * W + wi) * x_cs + x_co + 4 * q);
+                const float4 k = *reinterpret_cast<const float4*>(wt + (r * K + c) * C + 4 * q);
+                acc.x = fmaf(v.x, k.x, acc.x); acc.y = fmaf(v.y, k.y, acc.y);
+                acc.z = fmaf(v.z, k.z, acc.z); acc.w = fmaf(v.w, k.w, acc.w);
+            }
+        }
+        if (scale) {
+            const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * q);
+            acc.x *= sc.x; acc.y *= sc.y; acc.z *= sc.z; acc.w *= sc.w;
+        }
+        if (shift) {
+            const float4 sf = *reinterpret_cast<const float4*>(shift + 4 * q);
+            acc.x += sf.x; acc.y += sf.y; acc.z += sf.z; acc.w += sf.w;
+        }
+        acc.x = fd_act(acc.x, act, 0.f); acc.y = fd_act(acc.y, act, 0.f); acc.z = fd_act(acc.z, act, 0.f); acc.w = fd_act(acc.w, act, 0.f);
+        *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) = acc;
+    }
+}
+
+extern "C" int32_t fd_dwconv_dilated_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w, const float* scale,
+                                          const float* shift, float* y, int32_t y_cs, int32_t y_co, int32_t C, int32_t K, int32_t dil,
+                                          int32_t act, const fd_segs* segs, fd_stream_t stream) {
+    FD_REQUIRE(fd_segs_ok(segs), FD_E_INVAL, "fd_dwconv_dilated: bad segment table");
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C) && w && ((uintptr_t)w & 15) == 0, FD_E_INVAL,
+               "fd_dwconv_dilated: channel views must be 4-aligned (C=%d)", C);
+    FD_REQUIRE((K == 3 || K == 5 || K == 7) && dil >= 1 && dil <= 8, FD_E_UNSUPPORTED, "fd_dwconv_dilated: k in {3, 5, 7}, 1 <= dilation <= 8 (k=%d dil=%d)", K, dil);
+    SegTab tab; tab.s = *segs;
+    const long total = (long)segs->m_start[segs->nseg] * (C / 4);
+    hipLaunchKernelGGL(dwconv_dilated_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, w, scale, shift,
+                       y, y_cs, y_co, C, K, dil, act, tab, total);
+    FD_CHECK_LAUNCH("fd_dwconv_dilated_nhwc");
+    return FD_OK;
+}
+
 // ---- depthwise 3x3 weight gradient: dw[t][c] = sum_m x[pix(m, t)][c] * dy[m][c]  (HBM-bound; x and dy read once)
 // pass 1: one workgroup per row chunk; a thread owns one channel quad and every R-th row of the chunk, keeps the
 //         9 tap sums in registers, lanes are combined through LDS in lane order -> partial[chunk][9][C]

@@ -579,6 +579,88 @@ def build_fcos_head(plan: Plan, head, pyr: Rows, segs: Segs):
     return _out_convs(plan, head, cur, segs, F, ncls)
 
 
+# ------------------------------------------------------------------------------------------------ MNFCOS
+def add_mn_block(plan: Plan, name: str, blk, x: Rows, segs: Segs, out: Rows) -> None:
+    """MNBlock.forward (modules.py:209-216): out = x + PW2(SiLU(PW1(BN(dilated depthwise k x k (x))))) -- the depthwise conv with its
+    frozen BatchNorm folded in (fd_dwconv_dilated_nhwc, 'same' padding: the repaired behaviour for k = 5 / 7), the two 1x1 convs on
+    the MFMA kernel with SiLU and the residual add in their epilogues.  Works on one level or a whole pyramid (shared weights)."""
+    dev, pool = plan.device, plan.pool
+    dw = blk.DilatedDepthWiseConv
+    C, K, dil = dw.weight.shape[0], dw.kernel_size[0], dw.dilation[0]
+    wd = ops.pack_dwk_weight(_dev(dw.weight, dev))
+    sc, sf = ops.fold_bn(_dev(blk.BN.weight, dev), _dev(blk.BN.bias, dev), _dev(blk.BN.running_mean, dev), _dev(blk.BN.running_var, dev),
+                         blk.BN.eps)
+    plan.keep += [wd, sc, sf]
+    t = pool.get(segs.rows, C)
+    plan.add(name + ".DilatedDepthWiseConv", lambda: ops.dwconv_dilated(x, wd, t, segs, K, dil, sc, sf, ACT_NONE))
+    h = pool.get(segs.rows, blk.PW1.weight.shape[0])
+    add_conv(plan, name + ".PW1", t, segs, blk.PW1, h, act=ACT_SILU)
+    pool.put(t)
+    add_conv(plan, name + ".PW2", h, segs, blk.PW2, out, res=x)
+    pool.put(h)
+
+
+def build_mn_fpn(plan: Plan, fpn, feats):
+    """LieghtWeightFeaturePyramid_old.forward (MNFcos.py:239-256): 1x1 laterals (+bias), MNBlocks, nearest x2 upsample + add, 2x2 max-pool."""
+    pool = plan.pool
+    (c3, s3), (c4, s4), (c5, s5) = feats
+    B = s3.batch
+    F = fpn.C5PW.weight.shape[0]
+    h5, w5 = s5.H[0], s5.W[0]
+    hw = [(s3.H[0], s3.W[0]), (s4.H[0], s4.W[0]), (h5, w5), (h5 // 2, w5 // 2), (h5 // 4, w5 // 4)]
+    if hw[1] != (2 * h5, 2 * w5) or hw[0] != (4 * h5, 4 * w5) or hw[4][0] < 1 or hw[4][1] < 1:
+        raise FdError("MNFCOS FPN: H and W must be multiples of 32 and at least 128")
+    pyr_segs = Segs.make(B, hw)
+    pyr = pool.get(pyr_segs.rows, F)
+    lv = [Rows(pyr.buf[pyr_segs.m_start[i]:pyr_segs.m_start[i + 1]]) for i in range(5)]
+    seg = [Segs.make(B, [hw[i]]) for i in range(5)]
+    l5 = pool.get(s5.rows, F)
+    add_conv(plan, "FeaturePyramidNetwork.C5PW", c5, s5, fpn.C5PW, l5)
+    add_mn_block(plan, "FeaturePyramidNetwork.MNB5", fpn.MNB5, l5, seg[2], lv[2])
+    pool.put(l5)
+    l4 = pool.get(s4.rows, F)
+    add_conv(plan, "FeaturePyramidNetwork.C4PW", c4, s4, fpn.C4PW, l4)
+    plan.add("FeaturePyramidNetwork.up1_add", lambda: ops.upsample2x_add(lv[2], l4, l4, B, hw[2][0], hw[2][1]))
+    add_mn_block(plan, "FeaturePyramidNetwork.MNB4", fpn.MNB4, l4, seg[1], lv[1])
+    pool.put(l4)
+    l3 = pool.get(s3.rows, F)
+    add_conv(plan, "FeaturePyramidNetwork.C3PW", c3, s3, fpn.C3PW, l3)
+    plan.add("FeaturePyramidNetwork.up2_add", lambda: ops.upsample2x_add(lv[1], l3, l3, B, hw[1][0], hw[1][1]))
+    add_mn_block(plan, "FeaturePyramidNetwork.MNB3", fpn.MNB3, l3, seg[0], lv[0])
+    pool.put(l3)
+    d6 = pool.get(seg[3].rows, F)
+    plan.add("FeaturePyramidNetwork.DownSample_1", lambda: ops.maxpool(lv[2], d6, B, hw[2][0], hw[2][1], 2, 2, 0))
+    add_mn_block(plan, "FeaturePyramidNetwork.MNB6", fpn.MNB6, d6, seg[3], lv[3])
+    pool.put(d6)
+    d7 = pool.get(seg[4].rows, F)
+    plan.add("FeaturePyramidNetwork.DownSample_2", lambda: ops.maxpool(lv[3], d7, B, hw[3][0], hw[3][1], 2, 2, 0))
+    add_mn_block(plan, "FeaturePyramidNetwork.MNB7", fpn.MNB7, d7, seg[4], lv[4])
+    pool.put(d7)
+    return pyr, pyr_segs
+
+
+def build_mn_head(plan: Plan, head, pyr: Rows, segs: Segs):
+    """MNHeadFCOS.forward (MNFcos.py:285-297) over the whole pyramid per launch (the weights are shared over levels): two MNBlocks, the
+    cls / reg 3x3 convs as one 2F-wide conv + one GroupNorm(64, 2F) + SiLU, the 1x1 predictors (cnt + reg merged, ScaleExp fused)."""
+    pool = plan.pool
+    M = segs.rows
+    F = head.cls_logits.weight.shape[1]
+    ncls = head.cls_logits.weight.shape[0]
+    b1 = pool.get(M, F)
+    add_mn_block(plan, "head.block1", head.block1, pyr, segs, b1)
+    b2 = pool.get(M, F)
+    add_mn_block(plan, "head.block2", head.block2, b1, segs, b2)
+    pool.put(b1)
+    tower = pool.get(M, 2 * F)
+    w = torch.cat([head.cls_conv[0].weight.detach(), head.reg_conv[0].weight.detach()], 0)
+    mark = len(plan.steps)
+    add_conv(plan, "head.tower3x3", b2, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F, tag=1)
+    plan.marks["head.tower3x3"] = (mark, len(plan.steps))
+    _fused_gn(plan, "head.tower_gn", tower, segs, [head.cls_conv[1], head.reg_conv[1]], ACT_SILU)
+    pool.put(b2)
+    return _out_convs(plan, head, tower, segs, F, ncls)
+
+
 # ------------------------------------------------------------------------------------------------ views
 def level_views(rows: Rows, segs: Segs) -> List[torch.Tensor]:
     """Per-level NCHW-shaped tensors (channels-last memory: zero-copy views of the pyramid rows buffer)."""

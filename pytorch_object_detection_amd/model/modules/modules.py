@@ -92,6 +92,39 @@ class ScaleExp(nn.Module):
         return T.from_rows(y, B, H, W)
 
 
+class MNBlock(nn.Module):
+    """x + PW2(SiLU(PW1(BN(dilated depthwise k x k (x))))) -- reference model/modules/modules.py:195-216, the block MNFCOS is built from
+    (model/od/MNFcos.py:222-297).  As shipped the reference pads the depthwise conv with `dilated`, which keeps the map size only for
+    k = 3, so its own residual add raises for the k = 5 / 7 blocks; here the padding is 'same' (dilated * (kernel - 1) / 2): identical
+    for k = 3, the evident intent for 5 / 7.  Inside a detector plan the block is three HIP launches (engine.add_mn_block); called on
+    its own (eval, no gradient) it runs the same launches."""
+
+    def __init__(self, in_ch: int, out_ch: int, kernel: int, dilated: int, alpha: int = 1):
+        super().__init__()
+        self.DilatedDepthWiseConv = nn.Conv2d(in_ch, in_ch, kernel, 1, dilated * (kernel - 1) // 2, dilated, in_ch, False)
+        self.BN = nn.BatchNorm2d(in_ch)
+        self.PW1 = nn.Conv2d(in_ch, in_ch * alpha, 1, 1, 0, 1, 1, True)
+        self.ACT1 = nn.SiLU(True)
+        self.PW2 = nn.Conv2d(in_ch * alpha, out_ch, 1, 1, 0, 1, 1, True)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        from ... import engine, train_ops as T
+        from ..._lib import Segs
+        T._need_cuda(x)
+        if self.training or (torch.is_grad_enabled() and (x.requires_grad or self.PW1.weight.requires_grad)):
+            raise FdError("MNBlock has a HIP forward only (MNFCOS is inference-only on the HIP path): call .eval() and run it under torch.no_grad()")
+        if x.dtype != torch.float32 or x.shape[1] % 4 or self.PW2.weight.shape[0] != x.shape[1]:
+            raise FdError("MNBlock: fp32 input with C % 4 == 0 and out_ch == in_ch (the residual add) expected")
+        B, C, H, W = x.shape
+        plan = engine.Plan(x.device)
+        segs = Segs.make(B, [(H, W)])
+        xin, out = plan.pool.get(B * H * W, C), plan.pool.get(B * H * W, C)
+        engine.add_mn_block(plan, "MNBlock", self, xin, segs, out)
+        xin.tensor().view(B, H, W, C).copy_(x.permute(0, 2, 3, 1))
+        plan.run()
+        return out.tensor().view(B, H, W, C).permute(0, 3, 1, 2).clone()
+
+
 def init_conv_random_normal(module: nn.Module, std: float = 0.01):
     if isinstance(module, nn.Conv2d):
         nn.init.normal_(module.weight, std=std)

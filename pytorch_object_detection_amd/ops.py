@@ -480,6 +480,14 @@ def dwconv2d(x: Rows, wkc: torch.Tensor, y: Rows, N: int, H: int, W: int, K: int
                                       pad_top, pad_left, Ho, Wo, act, _stream()), "fd_dwconv2d_nhwc")
 
 
+def dwconv_dilated(x: Rows, wkc: torch.Tensor, y: Rows, segs: Segs, K: int, dil: int, scale=None, shift=None, act: int = ACT_NONE) -> None:
+    """Dilated depthwise K x K, stride 1, 'same' padding, over a pyramid (MNBlock.DilatedDepthWiseConv + folded BN); w [K*K][C]."""
+    _need_gpu(wkc, scale, shift)
+    check(_lib.lib().fd_dwconv_dilated_nhwc(x.ptr, x.cs, x.co, wkc.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                            shift.data_ptr() if shift is not None else None, y.ptr, y.cs, y.co, x.C, K, dil, act,
+                                            C.byref(segs), _stream()), "fd_dwconv_dilated_nhwc")
+
+
 def stem_conv3(x4: torch.Tensor, w: torch.Tensor, y: Rows, N: int, H: int, W: int, K: int, stride: int, pad_top: int,
                pad_left: int, Ho: int, Wo: int, scale=None, shift=None, act: int = ACT_NONE) -> None:
     """3-channel stem conv on the [N*H*W, 4] image layout (w from pack_stem3_weight)."""

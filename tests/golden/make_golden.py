@@ -392,5 +392,51 @@ def g9():
     save("g9_full_width", **out)
 
 
+# ------------------------------------------------------------------ G10 MNFCOS pieces that run as shipped
+def g10():
+    """MNFCOS (model/od/MNFcos.py:11-36, what config/main.yaml:2 selects): the parts of it whose forward runs as shipped --
+    MNHeadFCOS (two MNBlock(f, f, 3, 2, 2) + 3x3 / GroupNorm / SiLU towers + 1x1 predictors + ScaleExp, MNFcos.py:259-297) on a tiny
+    pyramid, and MNBlock with k = 3 at dilation 1 and 2 (modules.py:195-216).  MNBlock pads its dilated depthwise conv with `dilation`,
+    which keeps the map size only for k = 3: the k = 5 / 7 blocks of LieghtWeightFeaturePyramid_old (MNFcos.py:233-235) make
+    `torch.add(x, x1)` (modules.py:215) raise, recorded here as `fpn_raises` -- there is no reference output to store for them."""
+    from model.modules import modules as ref_mod
+    from model.od import MNFcos as ref_mn
+    gen = torch.Generator().manual_seed(10)
+    torch.manual_seed(10)
+    head = ref_mn.MNHeadFCOS(32, 20, 0.01).eval()
+    randomize_bn(head, gen)
+    with torch.no_grad():
+        for i, s in enumerate(head.scale_exp):
+            s.scale.fill_(0.8 + 0.1 * i)
+    feats = [torch.randn(2, 32, h, h, generator=gen) for h in (16, 8, 4, 2, 1)]
+    with torch.no_grad():
+        cls, cnt, reg = head(feats)
+    out = {}
+    for k, v in sd_np(head).items():
+        out["sd.head." + k] = v
+    for i in range(5):
+        out[f"f{i}"] = feats[i].numpy(); out[f"cls{i}"] = cls[i].numpy(); out[f"cnt{i}"] = cnt[i].numpy(); out[f"reg{i}"] = reg[i].numpy()
+    for name, k, d in (("mnb_k3d1", 3, 1), ("mnb_k3d2", 3, 2)):
+        blk = ref_mod.MNBlock(32, 32, k, d, 2).eval()
+        randomize_bn(blk, gen)
+        x = torch.randn(2, 32, 9, 7, generator=gen)
+        with torch.no_grad():
+            y = blk(x)
+        out[name + ".x"] = x.numpy(); out[name + ".y"] = y.numpy()
+        for kk, v in sd_np(blk).items():
+            out[name + ".sd." + kk] = v
+    raises = 0
+    try:
+        fpn = ref_mn.LieghtWeightFeaturePyramid_old([128, 64, 32], 32).eval()
+        with torch.no_grad():
+            fpn((torch.randn(1, 32, 16, 16), torch.randn(1, 64, 8, 8), torch.randn(1, 128, 4, 4)))
+    except RuntimeError:
+        raises = 1
+    out["fpn_raises"] = np.array([raises])
+    save("g10_mnfcos_parts", **out)
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g3b(); g4(); g5(); g67(); g8(); g9()
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3b", "g4", "g5", "g67", "g8", "g9", "g10"]
+    for name in which:
+        globals()[name]()

@@ -138,6 +138,34 @@ def test_g8_tiny_fcos(golden):
         np.testing.assert_allclose(reg[i].numpy(), g[f"reg{i}"], rtol=1e-5, atol=1e-5)
 
 
+def test_g10_mnfcos_parts(golden):
+    """MNFCOS pieces that run as shipped in the reference (MNHeadFCOS, MNBlock k = 3 at dilation 1 / 2) pin the oracle's restatement;
+    the fixture also records that the reference's light-weight FPN raises (k = 5 / 7 MNBlocks), which the oracle repairs."""
+    g = golden("g10_mnfcos_parts")
+    assert int(g["fpn_raises"][0]) == 1
+    sd = _sd(g)
+    feats = [torch.from_numpy(g[f"f{i}"]) for i in range(5)]
+    with torch.no_grad():
+        cls, cnt, reg = R.mn_head(sd, feats)
+    for i in range(5):
+        np.testing.assert_allclose(cls[i].numpy(), g[f"cls{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(cnt[i].numpy(), g[f"cnt{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(reg[i].numpy(), g[f"reg{i}"], rtol=1e-5, atol=1e-5)
+    for name, k, d in (("mnb_k3d1", 3, 1), ("mnb_k3d2", 3, 2)):
+        bsd = {kk[len(name) + 4:]: torch.from_numpy(g[kk]) for kk in g.files if kk.startswith(name + ".sd.")}
+        with torch.no_grad():
+            y = R.mn_block(bsd, "", torch.from_numpy(g[name + ".x"]), k, d)
+        np.testing.assert_allclose(y.numpy(), g[name + ".y"], rtol=1e-5, atol=1e-5)
+    # the repaired k = 5 / 7 blocks keep the map size (what the residual add needs)
+    gen = torch.Generator().manual_seed(1)
+    for k, d in ((5, 2), (5, 1), (7, 1)):
+        bsd = {"DilatedDepthWiseConv.weight": torch.randn(8, 1, k, k, generator=gen), "BN.weight": torch.ones(8), "BN.bias": torch.zeros(8),
+               "BN.running_mean": torch.zeros(8), "BN.running_var": torch.ones(8), "PW1.weight": torch.randn(16, 8, 1, 1, generator=gen),
+               "PW1.bias": torch.zeros(16), "PW2.weight": torch.randn(8, 16, 1, 1, generator=gen), "PW2.bias": torch.zeros(8)}
+        x = torch.randn(1, 8, 6, 5, generator=gen)
+        assert R.mn_block(bsd, "", x, k, d).shape == x.shape
+
+
 def test_normalize_and_box_rescale_against_numpy():
     """Pipeline-tail restatements against their one-line numpy / torch definitions."""
     rng = np.random.default_rng(0)
