@@ -8,7 +8,8 @@
 // with 2.25x fewer MFMAs.  Everything stays fp32 (the transforms only add, subtract and halve): the result differs from the fma
 // chain of the direct kernel by rounding, ~1e-6 relative, inside the 1e-4 parity bar, and is the same on every run.
 //
-// One workgroup (4 waves) = 32 tiles (128 output pixels) x 64 output channels x all 16 frequencies:
+// One workgroup (4 waves; 8 waves x 128 channels for wide layers, see NCH below) = 32 tiles (128 output pixels) x 64 output channels x
+// all 16 frequencies:
 //   * tiles are enumerated over (level, image, dilation parity class, tile row, tile column): a dilated conv is a plain one on
 //     each of the dil^2 sub-lattices (h % dil, w % dil), so dilation only changes the address arithmetic;
 //   * per 8-channel chunk every thread loads ONE row of one tile's 4x4 patch (4 x 16 B raw buffer loads, zero outside the
@@ -38,7 +39,7 @@ struct WinoArgs {
 };
 
 #define WINO_TB 32     // tiles per workgroup
-#define WINO_NB 64     // output channels per workgroup
+#define WINO_NB 64     // output channels per workgroup (NCH = 2 waves-pairs; 128 with NCH = 4)
 #define WINO_KC 8      // channels per chunk
 
 struct TilePos { int s, n, h0, w0; bool ok; };
@@ -68,8 +69,11 @@ __device__ __forceinline__ float dpp_quad_2211(float v) {   // lane i of a quad 
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
 }
 
-template <int TAG>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
+// NCH = output-channel blocks of 32 per workgroup: 2 (4 waves, 64 channels, two workgroups per CU) or 4 (8 waves, 128 channels, one
+// workgroup per CU: the V tile -- patch loads, transform, LDS writes, done by waves 0..3 -- is shared by twice as many MFMAs and the
+// input is streamed half as many times; waves 4..7 only run MFMAs, and each SIMD hosts one wave of either kind).
+template <int TAG, int NCH>
+__global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Vs = reinterpret_cast<float*>(smem);          // [2 stages][16 f][32 tiles][8 c]; the epilogue reuses all 64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -83,14 +87,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     const int cnt = min(a.mtiles - mt_lo, a.mt_per);
     if (cnt <= 0 || idx >= cnt * a.ntiles) return;
     const int nt = idx / cnt, mt = mt_lo + (idx - nt * cnt);
-    const int tile0 = mt * WINO_TB, n0 = nt * WINO_NB;
+    const int tile0 = mt * WINO_TB, n0 = nt * (32 * NCH);
+    const bool loader = wave < 4;                        // (wave-uniform)
 
     constexpr unsigned OOB = 0xC0000000u;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, (int)a.u_bytes, 0x00020000);
 
     // ---- loader role: thread = (tile lt, channel quad q, patch row pi) ----
-    const int pi = tid & 3, q = (tid >> 2) & 1, lt = tid >> 3;
+    const int pi = tid & 3, q = (tid >> 2) & 1, lt = (tid >> 3) & 31;
     unsigned a_off[4];
     {
         const TilePos p = wino_decode(a, tile0 + lt);
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         const int cn1_ = min(cc_ + 1, a.NC - 1), cn2_ = min(cc_ + 2, a.NC - 1);                                                    \
         const float* Vb = Vs + (SLOT) * STAGE + v_rd;                                                                              \
         float4 fa[8];                                                                                                              \
-        WINO_LOAD_PATCH(SLOT, cn2_);                                                                                               \
+        if (loader) { WINO_LOAD_PATCH(SLOT, cn2_); }                                                                               \
         fa[0] = read_v(Vb, 0);                                                                                                     \
         fa[1] = read_v(Vb, 1);                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
@@ -196,22 +201,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
             acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fi].w, fb.w, acc[fi], 0, 0, 0);                                      \
             load_u(cn1_, fi);                                                                                                      \
             if (fi + 2 < 8) fa[fi + 2] = read_v(Vb, fi + 2);                                                                       \
-            if (fi == 2) WINO_ROW_PASS((SLOT) ^ 1);                                                                                \
-            if (fi >= 3 && fi <= 6) col_store((SLOT) ^ 1, fi - 3);                                                                 \
+            if (loader) {                                                                                                          \
+                if (fi == 2) WINO_ROW_PASS((SLOT) ^ 1);                                                                            \
+                if (fi >= 3 && fi <= 6) col_store((SLOT) ^ 1, fi - 3);                                                             \
+            }                                                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                                                     \
         }                                                                                                                          \
         __builtin_amdgcn_s_setprio(0);                                                                                             \
         __syncthreads();                                                                                                           \
     } while (0)
 
-    WINO_LOAD_PATCH(0, 0);
-    WINO_LOAD_PATCH(1, min(1, a.NC - 1));
+    if (loader) {
+        WINO_LOAD_PATCH(0, 0);
+        WINO_LOAD_PATCH(1, min(1, a.NC - 1));
+    }
 #pragma unroll
     for (int fi = 0; fi < 8; ++fi) load_u(0, fi);
-    WINO_ROW_PASS(0);
-    asm volatile("s_nop 4");      // (VALU write -> DPP read of the same VGPR needs 2 wait states; the hazard recogniser does not see into asm)
+    if (loader) {
+        WINO_ROW_PASS(0);
+        asm volatile("s_nop 4");      // (VALU write -> DPP read of the same VGPR needs 2 wait states; the hazard recogniser does not see into asm)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) col_store(0, j);
+        for (int j = 0; j < 4; ++j) col_store(0, j);
+    }
     __syncthreads();
     for (int cc = 0; cc < a.NC; cc += 2) {
         WINO_ITER(0, cc);
@@ -256,13 +267,13 @@ extern "C" int32_t fd_wino_pack_weights_f32(const float* w, const float* scale, 
     return FD_OK;
 }
 
-template <int TAG>
+template <int TAG, int NCH>
 static int launch_wino(const WinoArgs& a, hipStream_t stream) {
-    constexpr int lds = 64 * 1024;
-    auto kern = conv3x3_wino_kernel<TAG>;
+    constexpr int lds = NCH * 32 * 1024;      // the epilogue's pair stages: 32 KB per 32-channel block (the main loop needs 32 KB)
+    auto kern = conv3x3_wino_kernel<TAG, NCH>;
     static std::atomic<unsigned> attr_mask{0};
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
-    hipLaunchKernelGGL(kern, dim3(8 * a.mt_per * a.ntiles), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(8 * a.mt_per * a.ntiles), dim3(NCH * 128), lds, stream, a);
     FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (winograd)");
     return FD_OK;
 }
@@ -308,7 +319,11 @@ int fd_launch_conv_wino(const fd_conv_params* p, hipStream_t stream) {
     FD_REQUIRE(xb < 0xC0000000L - 65536 && ub < 0xC0000000L, FD_E_UNSUPPORTED, "fd_conv2d: input / weight buffer exceeds 3 GiB");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub;
     a.mtiles = (a.T + WINO_TB - 1) / WINO_TB;
-    a.ntiles = (p->Cout + WINO_NB - 1) / WINO_NB;
+    // 128-channel workgroups (8 waves) for wide layers with enough work to go round: measured on MI355X 5-7 % faster on the towers and the
+    // trunk's 256- / 512-wide conv2, slower at Cout = 128 and on maps with < 200 workgroups (HisBlock1 conv4: 100)
+    const int nch = (p->Cout % 128 == 0 && p->Cout >= 256 && (long)a.mtiles * (p->Cout / 128) >= 192) ? 4 : 2;
+    a.ntiles = (p->Cout + 32 * nch - 1) / (32 * nch);
     a.mt_per = (a.mtiles + 7) / 8;
-    return p->tag == 1 ? launch_wino<1>(a, stream) : launch_wino<0>(a, stream);
+    if (nch == 4) return p->tag == 1 ? launch_wino<1, 4>(a, stream) : launch_wino<0, 4>(a, stream);
+    return p->tag == 1 ? launch_wino<1, 2>(a, stream) : launch_wino<0, 2>(a, stream);
 }
