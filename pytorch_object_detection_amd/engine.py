@@ -29,7 +29,8 @@ import os as _os
 CONV_PRECISION = _os.environ.get("FD_CONV_PRECISION", "f32")
 AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see ops.autotune_conv, FD_AUTOTUNE)
 # FD_WINOGRAD: "1" (default) = 3x3 stride-1 'same' convs (dilation 1 / 2, Cin % 8 == 0) of an exact-fp32 plan run on the Winograd
-# F(2x2, 3x3) kernel (fd_conv_wino.hip: 2.25x fewer MFMAs, still fp32 arithmetic); "0" = every conv on the direct implicit-GEMM kernel
+# F(2x2, 3x3) kernel (fd_conv_wino.hip: 2.25x fewer MFMAs, still fp32 arithmetic) where the map is large enough for it to win
+# (ops.wino_preferred: it has no split-K); "force" = wherever it applies; "0" = every conv on the direct implicit-GEMM kernel
 WINOGRAD = _os.environ.get("FD_WINOGRAD", "1") != "0"
 
 
@@ -149,7 +150,7 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         Cin = x.C
     split = plan.precision == "f16x3"
     wino = (plan.winograd and ops.wino_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0 and
-            (res is None or (res.cs % 4 == 0 and res.co % 4 == 0)))
+            (res is None or (res.cs % 4 == 0 and res.co % 4 == 0)) and (tag == 1 or ops.wino_preferred(segs, Cin, co, dil)))
     if wino:
         wp = ops.pack_conv_weight_wino(_dev(w, dev))
     else:
@@ -461,7 +462,7 @@ def _out_convs(plan: Plan, head, tower: Rows, segs: Segs, F: int, ncls: int):
     scales = [float(s.scale.detach().reshape(-1)[0]) for s in head.scale_exp][:segs.nseg]
     rp = head.reg_pred
     rp_pad = rp.dilation[0] * (rp.kernel_size[0] - 1) // 2 if isinstance(rp.padding, str) else rp.padding[0]
-    if plan.winograd and ops.wino_ok(F, 8, rp.kernel_size[0], rp.stride[0], rp_pad, rp.dilation[0]):
+    if plan.winograd and ops.wino_ok(F, 8, rp.kernel_size[0], rp.stride[0], rp_pad, rp.dilation[0]) and ops.wino_preferred(segs, F, 8, rp.dilation[0]):
         # the Winograd kernel writes whole float4s: three zero filters fill the 8-wide buffer (channels 5..7 hold exp(0) = 1, never read);
         # 0.27 -> 0.17 ms against the direct kernel's 128 x 32 tile at Cout = 5
         w = torch.cat([w, torch.zeros(3, *w.shape[1:], dtype=w.dtype, device=w.device)], 0)

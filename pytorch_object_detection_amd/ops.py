@@ -373,6 +373,36 @@ def wino_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> boo
     return k == 3 and stride == 1 and pad == dil and dil in (1, 2) and Cin % 8 == 0 and Cout % 4 == 0
 
 
+def wino_tiles(segs: Segs, dil: int) -> int:
+    """2x2 output tiles the Winograd kernel enumerates: per level, image and dilation parity class ceil(ceil(H/dil)/2) x ceil(ceil(W/dil)/2)."""
+    return sum(segs.batch * dil * dil * ((-(-h // dil) + 1) // 2) * ((-(-w // dil) + 1) // 2) for h, w in segs.level_hw())
+
+
+# FD_WINOGRAD=force: every layer the Winograd kernel covers runs on it, whatever its size (tests exercise the kernel on small maps this way)
+WINO_FORCE = os.environ.get("FD_WINOGRAD", "1") == "force"
+
+
+def wino_preferred(segs: Segs, Cin: int, Cout: int, dil: int) -> bool:
+    """Winograd or direct kernel for a 3x3 stride-1 layer both cover?  The Winograd kernel has no split-K: one workgroup walks all Cin
+    (1.5 us per 8 channels), so a map with few tiles is latency-bound on it while the direct kernel splits K over workgroups
+    (floor ~21 us, two launches); wide maps are throughput-bound and Winograd's 2.25x fewer MFMAs win.  A small cost model fitted to
+    MI355X measurements (batch 1 .. 16 at 512^2 / 640^2, profiles/r02z_layer_times.tsv, gpurun_out/layers_b1_*.tsv):
+      t_wino   = (1.5 * Cin/8 + 3) us * max(1, workgroups / (0.55 * resident slots))
+      t_direct = max(21 us [narrow Cout <= 96: no split-K, 1.9 us per K-tile], FLOPs / 95 TFLOP/s)"""
+    if WINO_FORCE:
+        return True
+    T = wino_tiles(segs, dil)
+    mt = -(-T // 32)
+    nch = 4 if (Cout % 128 == 0 and Cout >= 256 and mt * (Cout // 128) >= 192) else 2      # as fd_launch_conv_wino chooses
+    wgs = mt * -(-Cout // (32 * nch))
+    slots = 256 * (2 if nch == 2 else 1)
+    t_w = (1.5 * (Cin // 8) + 3.0) * max(1.0, wgs / (0.55 * slots))
+    flops = 2.0 * segs.rows * max(Cout, 32) * Cin * 9
+    floor = 1.9 * (-(-Cin // 32) * 9) if Cout <= 96 else 21.0
+    t_d = max(floor, flops / 95e12 * 1e6)
+    return t_w < t_d
+
+
 def strided_dgrad_classes(k: int, stride: int, pad: int):
     """Parity classes of the data gradient of a k x k conv with `stride`: for input rows h = stride*i + a only the taps
     r = r0 + stride*t contribute, and dY row = i + c - t.  Returns per class a: (r0, T taps, c) with r0 = (a + pad) % stride,

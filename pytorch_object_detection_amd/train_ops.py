@@ -246,11 +246,12 @@ class _PackCache:
 PACKS = _PackCache()
 
 
-def _wino(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bool:
+def _wino(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int, segs: Segs) -> bool:
     """3x3 stride-1 'same' layers run on the Winograd kernel -- forward (Cin -> Cout) and, with the channel roles swapped, data
-    gradient -- unless FD_WINOGRAD=0 (the switch of the inference plans)."""
+    gradient -- unless FD_WINOGRAD=0 (the switch of the inference plans) or the map is so small that the direct kernel's split-K
+    wins (ops.wino_preferred, the rule of the inference plans)."""
     from . import engine
-    return engine.WINOGRAD and ops.wino_ok(Cin, Cout, k, stride, pad, dil)
+    return engine.WINOGRAD and ops.wino_ok(Cin, Cout, k, stride, pad, dil) and ops.wino_preferred(segs, Cin, Cout, dil)
 
 _TILE_CACHE: dict = {}
 
@@ -317,7 +318,7 @@ class _ConvRows(torch.autograd.Function):
         Cout, _, k, _ = weight.shape
         so = ops.conv_out_segs(segs, k, stride, pad, dil)
         y = torch.empty(so.rows, Cout, dtype=torch.float32, device=x.device)
-        _conv_launch(x, segs, PACKS.get(weight, wino=_wino(x.shape[1], Cout, k, stride, pad, dil)), y, k=k, stride=stride, pad=pad,
+        _conv_launch(x, segs, PACKS.get(weight, wino=_wino(x.shape[1], Cout, k, stride, pad, dil, segs)), y, k=k, stride=stride, pad=pad,
                      dil=dil, scale=scale, shift=shift.detach().contiguous() if shift is not None else None,
                      res=residual.contiguous() if residual is not None else None, act=act)
         ctx.save_for_backward(x, weight, scale, y if act == ACT_RELU else None)
@@ -340,7 +341,7 @@ class _ConvRows(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if stride == 1 and Cout % 32 == 0:
                 gx = torch.empty_like(x)
-                _conv_launch(g, so, PACKS.get(weight, scale, dgrad=True, wino=_wino(Cout, Cin, k, stride, dil * (k - 1) - pad, dil)), gx,
+                _conv_launch(g, so, PACKS.get(weight, scale, dgrad=True, wino=_wino(Cout, Cin, k, stride, dil * (k - 1) - pad, dil, so)), gx,
                              k=k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
             elif segs.nseg == 1 and stride > 1 and dil == 1 and (gx := _strided_dgrad(g, weight, scale, segs, k, stride, pad)) is not None:
                 pass                                   # strided layer: one exact-FLOP launch per parity class (ops.conv_dgrad_strided)
@@ -410,7 +411,7 @@ class _BottleneckRows(torch.autograd.Function):
         y2 = torch.empty(so.rows, P, dtype=torch.float32, device=dev)
         out = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
         _conv_launch(x, segs, PACKS.get(w1), y1, k=1, stride=1, pad=0, dil=1, scale=c1[0], shift=c1[1], act=ACT_RELU)
-        _conv_launch(y1, segs, PACKS.get(w2, wino=_wino(P, P, 3, stride, 1, 1)), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0], shift=c2[1],
+        _conv_launch(y1, segs, PACKS.get(w2, wino=_wino(P, P, 3, stride, 1, 1, segs)), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0], shift=c2[1],
                      act=ACT_RELU)
         if wd is not None:
             idt = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
@@ -442,7 +443,7 @@ class _BottleneckRows(torch.autograd.Function):
             gw2 = wg(y1, g2, segs, P, P, 3, stride, 1, s2)
         if stride == 1:
             g1 = torch.empty_like(y1)
-            _conv_launch(g2, so, PACKS.get(w2, s2, dgrad=True, wino=_wino(w2.shape[0], w2.shape[1], 3, 1, 1, 1)), g1, k=3, stride=1, pad=1, dil=1,
+            _conv_launch(g2, so, PACKS.get(w2, s2, dgrad=True, wino=_wino(w2.shape[0], w2.shape[1], 3, 1, 1, 1, so)), g1, k=3, stride=1, pad=1, dil=1,
                          res=y1, res_mask=True)
         elif (g1 := _strided_dgrad(g2, w2, s2, segs, 3, stride, 1, res=y1, res_mask=True)) is not None:
             pass    # strided 3x3: four parity-class launches on the conv kernel, ReLU mask of y1 applied in their epilogues

@@ -718,6 +718,7 @@ WINO_CASES = [
     (8, 4, 1, [(7, 7), (4, 4)], ACT_NONE, False),
     (256, 128, 2, [(1, 1), (2, 3), (5, 7)], ACT_RELU, True), # dilation 2 on maps smaller than a tile
     (512, 512, 1, [(6, 6)], ACT_RELU, False),                # layer4 conv2: K = 512
+    (64, 256, 1, [(80, 80)], ACT_RELU, True),                # wide and large enough for the 8-wave / 128-channel workgroups
 ]
 
 

@@ -88,9 +88,13 @@ def test_tiny_fcos_fpn_head_golden(golden):
         np.testing.assert_allclose(reg[i].cpu().numpy(), g[f"reg{i}"], **TOL)
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("prec", ["f32", "f32-winograd-everywhere", "f16x3"])
 @pytest.mark.parametrize("shape", [(2, 128, 128), (1, 256, 192)])
-def test_full_hisfcos_vs_oracle(shape, prec):
+def test_full_hisfcos_vs_oracle(shape, prec, monkeypatch):
+    if prec == "f32-winograd-everywhere":      # small maps normally go to the direct kernel (ops.wino_preferred): force the Winograd
+        from pytorch_object_detection_amd import ops as _ops    # kernel onto every 3x3 stride-1 layer, tiny levels and all
+        monkeypatch.setattr(_ops, "WINO_FORCE", True)
+        prec = "f32"
     torch.manual_seed(0)
     B, H, W = shape
     model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).eval()

@@ -21,8 +21,9 @@ def test_train_step_matches_oracle_autograd(wino, monkeypatch):
     3x3 stride-1 layers -- forward and data gradient -- on the Winograd F(2x2, 3x3) kernel (fp32 too, another rounding).  Same bars.
     Measured on MI355X (tools/train_dev_stats.py, this seed): Winograd path -- all 145 gradients within 5e-6 of their maximum; direct
     path -- 128 of 145 at rounding level, 17 (biases upstream of one flipped ReLU mask element) with a median deviation of 1e-4 .. 3e-4."""
-    from pytorch_object_detection_amd import engine
+    from pytorch_object_detection_amd import engine, ops
     monkeypatch.setattr(engine, "WINOGRAD", wino)
+    monkeypatch.setattr(ops, "WINO_FORCE", wino)       # (at 128 x 128 the size rule would send every layer to the direct kernel)
     torch.manual_seed(0)
     model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256)
     gen = torch.Generator().manual_seed(1)
@@ -422,12 +423,16 @@ def test_full_size_batch_gradient_is_the_mean_of_the_per_image_gradients():
         gi = grads(slice(i, i + 1))
         acc = gi if acc is None else {n: acc[n] + gi[n] for n in acc}
     assert set(full) == set(acc) == set(names)
-    worst = 0.0
+    worst, bulk_ok = 0.0, 0
     for n in names:
         a, b = full[n].double().flatten(), (acc[n] / B).double().flatten()
         scale = float(b.abs().max()) + 1e-30
         d = (a - b).abs() / scale
-        assert float(d.median()) < 3e-4, (n, float(d.median()))   # (fp32 sums over 16 x 5 456 locations in two different orders; worst measured 1.1e-4)
+        # fp32 sums over 16 x 5 456 locations in two different orders, and the 1-image plans run their small maps on the direct kernel where
+        # the 16-image plan uses Winograd (ops.wino_preferred): rounding level for the bulk, a flipped ReLU-mask element's share at worst
+        assert float(d.median()) < 1e-3, (n, float(d.median()))
+        bulk_ok += float(d.median()) < 1e-4
         assert float(d.max()) < 5e-2, (n, float(d.max()))       # (a ReLU-mask element may flip between the 1- and 16-image plans)
         worst = max(worst, float(d.max()))
     assert len(names) > 120
+    assert bulk_ok >= 0.85 * len(names), (bulk_ok, len(names))
