@@ -18,7 +18,9 @@ timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/be
 timeout -k 10 300 python bench.py --model FCOS-B3 --size 832x1344 --steps 10 --warmup 3 --no-fast-mode --no-train-step > $O/bench_fcos_b3_832x1344.json 2> $O/bench_b3.err
 timeout -k 10 300 python bench.py --model FCOS-B3 --size 832x1344 --layer-times $O/layer_times_fcos_b3.tsv > /dev/null 2>&1
 timeout -k 10 300 python bench.py --model FCOS --no-fast-mode --no-train-step > $O/bench_fcos_r50.json 2> $O/bench_fcos.err
+timeout -k 10 300 python bench.py --model MNFCOS --no-fast-mode --no-train-step --no-cpu-baseline > $O/bench_mnfcos.json 2> $O/bench_mn.err
 timeout -k 10 300 python bench.py --mode train > $O/bench_train.json 2> $O/bench_train.err
+for b in 1 2; do timeout -k 10 200 python bench.py --batch $b --size 512 --inflight 1 --steps 50 --warmup 10 --no-fast-mode --no-train-step --no-cpu-baseline > $O/bench_latency_b${b}_512.json 2>/dev/null; done
 FD_WINOGRAD=0 timeout -k 10 300 python bench.py --no-fast-mode --no-train-step --no-cpu-baseline > $O/bench_direct_kernels_only.json 2> $O/bench_direct.err
 timeout -k 10 200 python tools/time_wino.py 2>&1 | grep -v amdgpu.ids > $O/time_wino.txt
 du -sh gpurun_out
