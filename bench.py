@@ -73,7 +73,7 @@ def tower_roofline(plan, tower_flops: int, tower_ms: float) -> dict:
     time; `frac` = achieved / the dense fp32-MFMA peak.  On the default Winograd F(2x2, 3x3) kernel the launch EXECUTES 1 / 2.25 of
     those FLOPs on the matrix pipe (16 multiplies per 2x2 output tile and channel pair instead of 36), so `frac` can exceed 1;
     `mfma_executed_*` state what the matrix pipe itself does (the number comparable with an MFMA-utilisation counter)."""
-    wino = plan.tiles.get("head.tower3x3", 0) == 14
+    wino = (plan.tiles.get("head.tower3x3", 0) & 0xFF) == 14
     achieved = tower_flops / (tower_ms * 1e-3) / 1e12
     r = {"bound": "mfma",
          "kernel": ("conv3x3_wino_kernel<TAG=1> head tower 3x3 (cls_conv+reg_conv fused, 5 levels): Winograd F(2x2,3x3), fp32"

@@ -101,8 +101,9 @@ const char* fd_last_error(void);
 #define FD_TILE_WINOGRAD 14 /* 3x3 stride-1 'same' convs (dilation 1 or 2), fp32: Winograd F(2x2, 3x3) on the fp32 MFMA -- 16 multiplies
                                per (cin, cout) and 2x2 output tile instead of 36 (fd_conv_wino.hip).  `w` must be the
                                fd_wino_pack_weights_f32 packing; Cin % 8 == 0, Cout % 4 == 0, 16-byte addressable y / res / scale /
-                               shift; same epilogue contract; the result differs from the direct kernel's fma chain by fp32
-                               rounding (~1e-6 relative), deterministically */
+                               shift; same epilogue contract incl. ksplit (chunk loop split over workgroups, combined in slice
+                               order); the result differs from the direct kernel's fma chain by fp32 rounding (~1e-5 relative),
+                               deterministically */
 #define FD_TILE_COUNT 14
 
 typedef struct fd_conv_params {

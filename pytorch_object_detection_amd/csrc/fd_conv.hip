@@ -276,6 +276,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, const fl
     }
 }
 
+int fd_launch_splitk_reduce(const ConvArgs& orig, const float* ws, int nslice, int ldw, long slab, hipStream_t stream) {
+    long g = ((long)orig.M * (ldw >> 2) + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, orig, ws, nslice, ldw, slab);
+    FD_CHECK_LAUNCH("fd_conv2d (split-K reduce)");
+    return FD_OK;
+}
+
 template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -408,12 +416,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
         a.scale = a.shift = a.res = nullptr; a.act = FD_ACT_NONE; a.vec_epi = 1; a.sc_on = 0;
         const int rc = dispatch_conv(p, a, stem, stream);
         if (rc != FD_OK) return rc;
-        const int nslice = (a.KT + a.kt_per - 1) / a.kt_per;
-        long g = ((long)orig.M * (ldw >> 2) + 255) / 256;
-        if (g > 16384) g = 16384;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, orig, (const float*)p->workspace, nslice, ldw, slab);
-        FD_CHECK_LAUNCH("fd_conv2d (split-K reduce)");
-        return FD_OK;
+        return fd_launch_splitk_reduce(orig, (const float*)p->workspace, (a.KT + a.kt_per - 1) / a.kt_per, ldw, slab, stream);
     }
     return dispatch_conv(p, a, stem, stream);
 }

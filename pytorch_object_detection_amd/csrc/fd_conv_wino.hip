@@ -35,6 +35,8 @@ struct WinoArgs {
     float seg_param[FD_MAX_SEG];
     int T;                        // tiles in all
     int mtiles, ntiles, mt_per;   // M tiles (32 tiles each), N tiles (64 cout), M tiles per XCD
+    int nc_per;                   // 8-channel chunks per split-K slice (blockIdx.y = slice; NC when split-K is off)
+    long slice_stride;            // elements between consecutive split-K slabs of the workspace y points to
     unsigned x_bytes, u_bytes;
 };
 
@@ -89,6 +91,8 @@ __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kern
     const int nt = idx / cnt, mt = mt_lo + (idx - nt * cnt);
     const int tile0 = mt * WINO_TB, n0 = nt * (32 * NCH);
     const bool loader = wave < 4;                        // (wave-uniform)
+    // split-K: slice blockIdx.y owns chunks [c0, c1) and writes raw partial outputs to its slab of the workspace (the host points y at it)
+    const int c0 = blockIdx.y * a.nc_per, c1 = min(a.NC, c0 + a.nc_per);
 
     constexpr unsigned OOB = 0xC0000000u;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kern
 #define WINO_ITER(SLOT, CC)                                                                                                        \
     do {                                                                                                                           \
         const int cc_ = (CC);                                                                                                      \
-        const int cn1_ = min(cc_ + 1, a.NC - 1), cn2_ = min(cc_ + 2, a.NC - 1);                                                    \
+        const int cn1_ = min(cc_ + 1, c1 - 1), cn2_ = min(cc_ + 2, c1 - 1);                                                        \
         const float* Vb = Vs + (SLOT) * STAGE + v_rd;                                                                              \
         float4 fa[8];                                                                                                              \
         if (loader) { WINO_LOAD_PATCH(SLOT, cn2_); }                                                                               \
@@ -212,11 +216,11 @@ __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kern
     } while (0)
 
     if (loader) {
-        WINO_LOAD_PATCH(0, 0);
-        WINO_LOAD_PATCH(1, min(1, a.NC - 1));
+        WINO_LOAD_PATCH(0, c0);
+        WINO_LOAD_PATCH(1, min(c0 + 1, c1 - 1));
     }
 #pragma unroll
-    for (int fi = 0; fi < 8; ++fi) load_u(0, fi);
+    for (int fi = 0; fi < 8; ++fi) load_u(c0, fi);
     if (loader) {
         WINO_ROW_PASS(0);
         asm volatile("s_nop 4");      // (VALU write -> DPP read of the same VGPR needs 2 wait states; the hazard recogniser does not see into asm)
@@ -224,10 +228,11 @@ __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kern
         for (int j = 0; j < 4; ++j) col_store(0, j);
     }
     __syncthreads();
-    for (int cc = 0; cc < a.NC; cc += 2) {
+    for (int cc = c0; cc < c1; cc += 2) {
         WINO_ITER(0, cc);
-        if (cc + 1 < a.NC) WINO_ITER(1, cc + 1);
+        if (cc + 1 < c1) WINO_ITER(1, cc + 1);
     }
+    float* const ybase = a.y + (size_t)blockIdx.y * a.slice_stride;
 #undef WINO_ITER
 #undef WINO_ROW_PASS
 #undef WINO_LOAD_PATCH
@@ -273,7 +278,7 @@ static int launch_wino(const WinoArgs& a, hipStream_t stream) {
     auto kern = conv3x3_wino_kernel<TAG, NCH>;
     static std::atomic<unsigned> attr_mask{0};
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
-    hipLaunchKernelGGL(kern, dim3(8 * a.mt_per * a.ntiles), dim3(NCH * 128), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(8 * a.mt_per * a.ntiles, (a.NC + a.nc_per - 1) / a.nc_per), dim3(NCH * 128), lds, stream, a);
     FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (winograd)");
     return FD_OK;
 }
@@ -281,8 +286,8 @@ static int launch_wino(const WinoArgs& a, hipStream_t stream) {
 // Called by fd_conv2d_nhwc_f32 for tile == FD_TILE_WINOGRAD (p->w = the fd_wino_pack_weights_f32 packing).
 int fd_launch_conv_wino(const fd_conv_params* p, hipStream_t stream) {
     FD_REQUIRE(p->mode == FD_CONV_GENERIC && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == p->dil &&
-                   (p->dil == 1 || p->dil == 2) && p->ksplit <= 1 && p->out_H <= 0 && p->sc_H <= 0 && p->precision == FD_PREC_F32,
-               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD needs an fp32 3x3 stride-1 'same' conv with dilation 1 or 2 (no split-K / scatter)");
+                   (p->dil == 1 || p->dil == 2) && p->out_H <= 0 && p->sc_H <= 0 && p->precision == FD_PREC_F32,
+               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD needs an fp32 3x3 stride-1 'same' conv with dilation 1 or 2 (no scatter)");
     FD_REQUIRE(p->Cin % 8 == 0 && p->Cout % 4 == 0, FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD needs Cin %% 8 == 0 and Cout %% 4 == 0 (Cin=%d Cout=%d)",
                p->Cin, p->Cout);
     FD_REQUIRE(p->y_cs % 4 == 0 && p->y_co % 4 == 0 && ((uintptr_t)p->y & 15) == 0 &&
@@ -324,6 +329,31 @@ int fd_launch_conv_wino(const fd_conv_params* p, hipStream_t stream) {
     const int nch = (p->Cout % 128 == 0 && p->Cout >= 256 && (long)a.mtiles * (p->Cout / 128) >= 192) ? 4 : 2;
     a.ntiles = (p->Cout + 32 * nch - 1) / (32 * nch);
     a.mt_per = (a.mtiles + 7) / 8;
+    a.nc_per = a.NC; a.slice_stride = 0;
+    const int ksplit = p->ksplit > 1 ? p->ksplit : 1;
+    if (ksplit > 1) {
+        // split-K: the chunk loop is divided over `ksplit` workgroups per tile, raw partial outputs (the output transform is linear) go to the
+        // workspace and the direct kernel's combine launch adds the slabs in slice order and applies the epilogue (deterministic)
+        FD_REQUIRE(ksplit <= 64 && a.NC >= 2 * ksplit, FD_E_INVAL, "fd_conv2d: ksplit=%d needs 1 < ksplit <= min(64, Cin / 16 = %d)", ksplit, a.NC / 2);
+        const int ldw = (p->Cout + 3) & ~3;
+        const long slab = rows * ldw;
+        FD_REQUIRE(p->workspace && ((uintptr_t)p->workspace & 15) == 0 && p->workspace_bytes >= (int64_t)ksplit * slab * 4, FD_E_INVAL,
+                   "fd_conv2d: split-K needs a 16-byte aligned workspace of fd_conv_workspace_bytes() bytes");
+        a.nc_per = (a.NC + ksplit - 1) / ksplit;
+        a.y = (float*)p->workspace; a.y_cs = ldw; a.y_co = 0; a.slice_stride = slab;
+        a.scale = a.shift = a.res = nullptr; a.act = FD_ACT_NONE; a.res_mask = 0;
+        const int rc = (nch == 4) ? launch_wino<0, 4>(a, stream) : launch_wino<0, 2>(a, stream);
+        if (rc != FD_OK) return rc;
+        ConvArgs o = {};
+        o.scale = p->scale; o.shift = p->shift; o.res = p->res; o.y = p->y;
+        o.res_cs = p->res_cs; o.res_co = p->res_co; o.y_cs = p->y_cs; o.y_co = p->y_co;
+        o.Cout = p->Cout; o.act = p->act; o.act_c0 = p->act_c0; o.M = (int)rows; o.nseg = p->in.nseg;
+        o.res_mask = (p->res && p->res_mode == 1) ? 1 : 0;
+        for (int sg = 0; sg <= FD_MAX_SEG; ++sg) o.m_out[sg] = p->in.m_start[sg < p->in.nseg ? sg : p->in.nseg];
+        for (int sg = 0; sg < FD_MAX_SEG; ++sg) { o.seg_param[sg] = p->seg_param[sg]; o.Ho[sg] = o.Wo[sg] = 1; }
+        o.sc_on = 0;
+        return fd_launch_splitk_reduce(o, (const float*)p->workspace, (a.NC + a.nc_per - 1) / a.nc_per, ldw, slab, stream);
+    }
     if (nch == 4) return p->tag == 1 ? launch_wino<1, 4>(a, stream) : launch_wino<0, 4>(a, stream);
     return p->tag == 1 ? launch_wino<1, 2>(a, stream) : launch_wino<0, 2>(a, stream);
 }

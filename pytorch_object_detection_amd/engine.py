@@ -149,8 +149,11 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         w = torch.nn.functional.pad(_dev(w, dev).detach(), (0, 0, 0, 0, 0, x.C - Cin))
         Cin = x.C
     split = plan.precision == "f16x3"
-    wino = (plan.winograd and ops.wino_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0 and
-            (res is None or (res.cs % 4 == 0 and res.co % 4 == 0)) and (tag == 1 or ops.wino_preferred(segs, Cin, co, dil)))
+    wino, wino_ks = False, 1
+    if (plan.winograd and ops.wino_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0 and
+            (res is None or (res.cs % 4 == 0 and res.co % 4 == 0))):
+        wino, wino_ks = ops.wino_choice(segs, Cin, co, dil)
+        wino = wino or tag == 1                   # (the head tower -- the roofline kernel -- always runs the Winograd kernel)
     if wino:
         wp = ops.pack_conv_weight_wino(_dev(w, dev))
     else:
@@ -167,16 +170,19 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     out = ops.conv_out_segs(segs, k, stride, pad, dil)
     # split-K scratch: taken from the pool and handed straight back (stream order makes the sharing safe)
     ws_rows = ops.KSPLIT_MAX * out.rows
-    ws = plan.pool.get(ws_rows, (co + 3) & ~3) if (plan.autotune and not wino and ws_rows * ((co + 3) & ~3) <= 64 * 1024 * 1024) else None
+    if wino:
+        ws = plan.pool.get(wino_ks * out.rows, (co + 3) & ~3) if wino_ks > 1 else None
+    else:
+        ws = plan.pool.get(ws_rows, (co + 3) & ~3) if (plan.autotune and ws_rows * ((co + 3) & ~3) <= 64 * 1024 * 1024) else None
     call = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                          shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param, tag=tag,
                          precision=1 if split else 0, workspace=ws.buf if ws is not None else None,
-                         tile=_lib.WINO_TILE if wino else 0)
+                         tile=_lib.WINO_TILE if wino else 0, ksplit=wino_ks if wino else 1)
     plan.add(name, call)
     if ws is not None:
         plan.pool.put(ws)
     if wino:
-        plan.tiles[name] = _lib.WINO_TILE
+        plan.tiles[name] = _lib.WINO_TILE | ((wino_ks if wino_ks > 1 else 0) << 8)
     elif plan.autotune:
         hw = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
         key = f"B{segs.batch}|{hw}|{Cin}>{co}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{x.cs}|ycs{y.cs}"
@@ -462,7 +468,7 @@ def _out_convs(plan: Plan, head, tower: Rows, segs: Segs, F: int, ncls: int):
     scales = [float(s.scale.detach().reshape(-1)[0]) for s in head.scale_exp][:segs.nseg]
     rp = head.reg_pred
     rp_pad = rp.dilation[0] * (rp.kernel_size[0] - 1) // 2 if isinstance(rp.padding, str) else rp.padding[0]
-    if plan.winograd and ops.wino_ok(F, 8, rp.kernel_size[0], rp.stride[0], rp_pad, rp.dilation[0]) and ops.wino_preferred(segs, F, 8, rp.dilation[0]):
+    if plan.winograd and ops.wino_ok(F, 8, rp.kernel_size[0], rp.stride[0], rp_pad, rp.dilation[0]) and ops.wino_choice(segs, F, 8, rp.dilation[0])[0]:
         # the Winograd kernel writes whole float4s: three zero filters fill the 8-wide buffer (channels 5..7 hold exp(0) = 1, never read);
         # 0.27 -> 0.17 ms against the direct kernel's 128 x 32 tile at Cout = 5
         w = torch.cat([w, torch.zeros(3, *w.shape[1:], dtype=w.dtype, device=w.device)], 0)

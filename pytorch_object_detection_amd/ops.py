@@ -382,25 +382,37 @@ def wino_tiles(segs: Segs, dil: int) -> int:
 WINO_FORCE = os.environ.get("FD_WINOGRAD", "1") == "force"
 
 
-def wino_preferred(segs: Segs, Cin: int, Cout: int, dil: int) -> bool:
-    """Winograd or direct kernel for a 3x3 stride-1 layer both cover?  The Winograd kernel has no split-K: one workgroup walks all Cin
-    (1.5 us per 8 channels), so a map with few tiles is latency-bound on it while the direct kernel splits K over workgroups
-    (floor ~21 us, two launches); wide maps are throughput-bound and Winograd's 2.25x fewer MFMAs win.  A small cost model fitted to
-    MI355X measurements (batch 1 .. 16 at 512^2 / 640^2, profiles/r02z_layer_times.tsv, gpurun_out/layers_b1_*.tsv):
-      t_wino   = (1.5 * Cin/8 + 3) us * max(1, workgroups / (0.55 * resident slots))
-      t_direct = max(21 us [narrow Cout <= 96: no split-K, 1.9 us per K-tile], FLOPs / 95 TFLOP/s)"""
+def wino_choice(segs: Segs, Cin: int, Cout: int, dil: int, allow_split: bool = True) -> Tuple[bool, int]:
+    """(use the Winograd kernel?, its split-K factor) for a 3x3 stride-1 layer both kernels cover.  Without split-K one Winograd
+    workgroup walks all Cin (1.5 us per 8 channels), so a map with few tiles is latency-bound on it while the direct kernel splits K over
+    workgroups (floor ~21 us, two launches); wide maps are throughput-bound and Winograd's 2.25x fewer MFMAs win.  A small cost model
+    fitted to MI355X measurements (batch 1 .. 16 at 512^2 / 640^2: profiles/r02z_layer_times.tsv, r02z_bench_latency_b*.json):
+      t_wino(ks) = (1.5 * Cin / 8 / ks + 3) us * max(1, ks * workgroups / (0.55 * resident slots))  [+ 7 us for the combine launch, ks > 1]
+      t_direct   = max(21 us [narrow Cout <= 96: no split-K there, 1.9 us per K-tile], FLOPs / 95 TFLOP/s)"""
     if WINO_FORCE:
-        return True
+        return True, 1
     T = wino_tiles(segs, dil)
     mt = -(-T // 32)
     nch = 4 if (Cout % 128 == 0 and Cout >= 256 and mt * (Cout // 128) >= 192) else 2      # as fd_launch_conv_wino chooses
     wgs = mt * -(-Cout // (32 * nch))
     slots = 256 * (2 if nch == 2 else 1)
-    t_w = (1.5 * (Cin // 8) + 3.0) * max(1.0, wgs / (0.55 * slots))
+    nc = Cin // 8
+    best_t, best_ks = None, 1
+    for ks in ((1, 2, 4, 8) if allow_split else (1,)):
+        if ks > 1 and nc < 4 * ks:
+            break
+        t = (1.5 * nc / ks + 3.0) * max(1.0, ks * wgs / (0.55 * slots)) + (7.0 if ks > 1 else 0.0)
+        if best_t is None or t < best_t * 0.9:          # (a split has to pay for its workspace traffic)
+            best_t, best_ks = t, ks
     flops = 2.0 * segs.rows * max(Cout, 32) * Cin * 9
     floor = 1.9 * (-(-Cin // 32) * 9) if Cout <= 96 else 21.0
     t_d = max(floor, flops / 95e12 * 1e6)
-    return t_w < t_d
+    return best_t < t_d, best_ks
+
+
+def wino_preferred(segs: Segs, Cin: int, Cout: int, dil: int) -> bool:
+    """wino_choice without split-K (callers that have no workspace: the training nodes)."""
+    return wino_choice(segs, Cin, Cout, dil, allow_split=False)[0]
 
 
 def strided_dgrad_classes(k: int, stride: int, pad: int):

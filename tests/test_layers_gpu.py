@@ -755,6 +755,21 @@ def test_conv3x3_winograd(case):
     for i, ((h, w), r) in enumerate(zip(hw, ref)):
         g = got[segs.m_start[i]:segs.m_start[i + 1]].reshape(B, h, w, Cout).permute(0, 3, 1, 2)
         np.testing.assert_allclose(g.numpy(), r.numpy(), atol=ATOL, rtol=1e-4, err_msg=f"level {i}")
+    if Cin >= 64:      # split-K: chunk loop divided over 2 / 4 workgroups per tile + the ordered combine launch (epilogue applied there)
+        for ks in (2, 4):
+            if Cin // 8 < 2 * ks:
+                continue
+            yb2 = torch.full((segs.rows, Cout + 8), float("nan"), device=DEV)
+            ws = torch.empty(ks * segs.rows * ((Cout + 3) & ~3), device=DEV)
+            run = ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(yb2, 4, Cout), Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, scale=sc.to(DEV),
+                                shift=sf.to(DEV), res=ops.Rows(rb) if use_res else None, act=act, tile=_lib.WINO_TILE, ksplit=ks, workspace=ws)
+            run()
+            g2 = yb2.cpu()
+            assert torch.isnan(g2[:, :4]).all() and torch.isnan(g2[:, 4 + Cout:]).all()
+            np.testing.assert_allclose(g2[:, 4:4 + Cout].numpy(), got.numpy(), atol=2e-5, rtol=1e-5, err_msg=f"ksplit {ks}")
+            first = g2.clone()
+            run()
+            assert torch.equal(yb2.cpu().nan_to_num(7.0), first.nan_to_num(7.0))          # bitwise reproducible
     with pytest.raises(Exception, match="WINOGRAD|multi-level"):     # not a stride-1 'same' 3x3: a clean error, no launch
         ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=0, dil=1, tile=_lib.WINO_TILE)()
 
