@@ -91,6 +91,46 @@ def test_state_dict_contract():
     assert "FPN.P6_c1.bias" in f.state_dict() and "head.cls_branch.9.weight" in f.state_dict()
 
 
+def test_mnfcos_containers_and_builder():
+    """MNFCOS (the detector the reference's config/main.yaml selects): the reference's state_dict names (pinned by fixture g10 for the
+    head), the 'same' padding repair of the k = 5 / 7 MNBlocks, the Builder entry."""
+    from pytorch_object_detection_amd.model.od import MNFCOS
+    from pytorch_object_detection_amd.model.modules.modules import MNBlock
+    m = MNFCOS([2048, 1024, 512], 20, 256)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_mnfcos_parts.npz"))
+    ref_head = {k[len("sd.head."):]: g[k].shape for k in g.files if k.startswith("sd.head.")}
+    assert set(ref_head) == set(m.head.state_dict())
+    for k in ("FeaturePyramidNetwork.C5PW.bias", "FeaturePyramidNetwork.MNB7.DilatedDepthWiseConv.weight", "FeaturePyramidNetwork.MNB1_P3.PW2.weight",
+              "head.block2.BN.running_var", "backbone.extract_feature.layer4.2.conv3.weight"):
+        assert k in m.state_dict(), k
+    assert m.FeaturePyramidNetwork.MNB7.DilatedDepthWiseConv.weight.shape == (256, 1, 7, 7)
+    for k, d in ((3, 1), (3, 2), (5, 1), (5, 2), (7, 1)):
+        assert MNBlock(8, 8, k, d, 2).DilatedDepthWiseConv.padding == (d * (k - 1) // 2,) * 2
+    cfg = load_config()
+    cfg["model"]["name"] = "MNFCOS"
+    assert isinstance(Builder(cfg).model_build(), MNFCOS) and cfg["MNFCOS"]["CannelofBackbone"] == [2048, 1024, 512]
+
+
+def test_winograd_tile_count_and_kernel_choice():
+    """Host logic of the Winograd path: the tile enumeration the kernel walks (tools/wino_emul.py proves the same formula against
+    F.conv2d) and the per-layer choice between the Winograd and the direct kernel (ops.wino_choice)."""
+    from pytorch_object_detection_amd import ops
+    seg = _lib.Segs.make(2, [(5, 5), (3, 4), (1, 1)])
+    assert ops.wino_tiles(seg, 1) == 2 * (9 + 4 + 1)                 # ceil(H/2) x ceil(W/2) per image and level
+    assert ops.wino_tiles(_lib.Segs.make(1, [(8, 7)]), 2) == 4 * 2 * 2  # dilation 2: four parity classes of a 4 x 4 sub-lattice
+    assert ops.wino_ok(256, 512, 3, 1, 1, 1) and ops.wino_ok(256, 256, 3, 1, 2, 2) and ops.wino_ok(256, 8, 3, 1, 1, 1)
+    assert not ops.wino_ok(256, 256, 3, 2, 1, 1) and not ops.wino_ok(256, 256, 1, 1, 0, 1) and not ops.wino_ok(12, 32, 3, 1, 1, 1)
+    pyr = [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
+    assert ops.wino_choice(_lib.Segs.make(16, pyr), 256, 512, 1) == (True, 1)         # the head tower at the bench shape
+    assert ops.wino_choice(_lib.Segs.make(16, [(160, 160)]), 64, 64, 1)[0]            # layer1 conv2
+    use, ks = ops.wino_choice(_lib.Segs.make(1, [(32, 32)]), 256, 256, 1)             # batch-1 layer3 conv2: few tiles -> split-K or direct
+    assert (not use) or ks > 1
+    use, ks = ops.wino_choice(_lib.Segs.make(16, [(5, 5)]), 256, 256, 2)              # the 5 x 5 pyramid level: 32 workgroups
+    assert (not use) or ks > 1
+    assert not ops.wino_choice(_lib.Segs.make(16, [(5, 5)]), 256, 256, 2, allow_split=False)[0]
+    assert ops.wino_preferred(_lib.Segs.make(16, pyr), 256, 512, 1)
+
+
 def test_weight_packing_and_bn_fold():
     w = torch.randn(8, 32, 3, 3)
     p = ops.pack_conv_weight(w)
