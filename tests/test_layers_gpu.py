@@ -800,3 +800,27 @@ def test_winograd_weight_pack_and_dgrad():
     wp = ops.pack_conv_weight_wino(w.to(DEV), scale.to(DEV), dgrad=True)
     ops.conv_call(to_rows(dy), segs, wp, dx, Cin=Cout, Cout=Cin, k=3, pad=1, dil=1, tile=_lib.WINO_TILE)()
     np.testing.assert_allclose(from_rows(dx, B, H, W).numpy(), x.grad.numpy(), atol=ATOL, rtol=1e-4)
+
+
+def test_winograd_vs_direct_kernel_at_the_bench_shapes():
+    """BASELINE configs[1] sizes (16 x 640 x 640): the head tower (256 -> 512 over the five-level pyramid, 8-wave workgroups) and the
+    dilation-2 HisBlock conv4 at 80 x 80 on the Winograd kernel against the direct kernel (bit-for-bit an fp32 fma chain, itself
+    oracle-tested above) -- the CPU oracle would take minutes at this size; size-independent check: same result from two algorithms,
+    bitwise identical from two launches."""
+    from pytorch_object_detection_amd import _lib
+    gen = torch.Generator().manual_seed(11)
+    for name, hw, Cin, Cout, dil in (("tower", [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)], 256, 512, 1), ("HisBlock3.conv4", [(80, 80)], 256, 256, 2)):
+        segs = Segs.make(16, hw)
+        x = ops.Rows(torch.randn(segs.rows, Cin, generator=gen).to(DEV))
+        w = (torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5).to(DEV)
+        sc, sf = (torch.rand(Cout, generator=gen) + 0.5).to(DEV), (torch.randn(Cout, generator=gen) * 0.1).to(DEV)
+        yd, yw, yw2 = (ops.new_rows(segs.rows, Cout, DEV) for _ in range(3))
+        kw = dict(Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, scale=sc, shift=sf, act=ACT_RELU)
+        ops.conv_call(x, segs, ops.pack_conv_weight(w), yd, tile=7, **kw)()
+        wp = ops.pack_conv_weight_wino(w)
+        ops.conv_call(x, segs, wp, yw, tile=_lib.WINO_TILE, **kw)()
+        ops.conv_call(x, segs, wp, yw2, tile=_lib.WINO_TILE, **kw)()
+        assert torch.equal(yw.tensor(), yw2.tensor()), name
+        d = (yw.tensor() - yd.tensor()).abs().max().item()
+        assert d < 5e-5, (name, d)            # (measured 1.3e-5 at unit-scale outputs; the parity bar vs the CPU path is 1e-4)
+        assert float(yd.tensor().abs().max()) > 1.0
