@@ -197,6 +197,13 @@ typedef struct fd_pack_job {
 } fd_pack_job;
 int32_t fd_pack_conv_weights_batch_f32(const fd_pack_job* jobs_dev, int32_t n_jobs, int64_t max_elems, fd_stream_t stream);
 
+/* The ResNet stem as its own kernel: y = act(conv7x7_s2_p3(x) * scale + shift), 3 -> 64 channels, on the [N][H][W][4] image layout
+ * (torchvision resnet50 conv1 + bn1 + relu behind the reference's model/backbone/resnet50.py:68-80).  The workgroup's input patch and
+ * the filter bank are staged once in LDS, K = 7 x 22 (5 % padding; FD_CONV_STEM of fd_conv2d_nhwc_f32 pads 147 to 224).
+ * w packed [7 filter rows][22][64]: k = 3 * (filter column) + (input channel), k = 21 zero.  Output [N][H/2][W/2] rows, 64 channels. */
+int32_t fd_stem7x7_nhwc4(const float* x4, const float* w, const float* scale, const float* shift, float* y, int32_t y_cs, int32_t y_co,
+                         int32_t N, int32_t H, int32_t W, int32_t act, fd_stream_t stream);
+
 /* [N][3][H][W] fp32 (NCHW, the reference's input layout, dataset/voc.py:141-173) -> [N][H][W][4] (c=3 zero) */
 int32_t fd_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, fd_stream_t stream);
 /* Input pipeline tail on the device: uint8 [N][H][W][3] images, already resized and zero padded on

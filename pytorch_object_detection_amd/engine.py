@@ -32,6 +32,7 @@ AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see 
 # F(2x2, 3x3) kernel (fd_conv_wino.hip: 2.25x fewer MFMAs, still fp32 arithmetic) where the map is large enough for it to win
 # (ops.wino_preferred: it has no split-K); "force" = wherever it applies; "0" = every conv on the direct implicit-GEMM kernel
 WINOGRAD = _os.environ.get("FD_WINOGRAD", "1") != "0"
+STEM_KERNEL = _os.environ.get("FD_STEM_KERNEL", "1") != "0"     # "0": the ResNet stem through the generic conv kernel's FD_CONV_STEM mode
 
 
 class PRows(Rows):
@@ -223,14 +224,18 @@ def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: Lis
     add_input(plan, x4, batch, H, W, image_ref)
     s_in = Segs.make(batch, [(H, W)])
     # stem 7x7 s2 + BN + ReLU
-    wp = ops.pack_stem_weight(_dev(trunk.conv1.weight, dev))
     sc, sf = ops.fold_bn(_dev(trunk.bn1.weight, dev), _dev(trunk.bn1.bias, dev), _dev(trunk.bn1.running_mean, dev),
                          _dev(trunk.bn1.running_var, dev), trunk.bn1.eps)
-    plan.keep += [wp, sc, sf]
     s1 = ops.conv_out_segs(s_in, 7, 2, 3, 1)
     y1 = pool.get(s1.rows, 64)
-    plan.add("backbone.conv1", ops.conv_call(x4, s_in, wp, y1, Cin=4, Cout=64, k=7, stride=2, pad=3, scale=sc, shift=sf,
-                                             act=ACT_RELU, stem=True))
+    if STEM_KERNEL and plan.precision == "f32" and tuple(trunk.conv1.weight.shape) == (64, 3, 7, 7):
+        wp = ops.pack_stem7_weight(_dev(trunk.conv1.weight, dev))      # the dedicated stem kernel (fd_stem.hip): patch + filters staged in LDS
+        plan.add("backbone.conv1", lambda: ops.stem7x7(x4, wp, y1, batch, H, W, sc, sf, ACT_RELU))
+    else:
+        wp = ops.pack_stem_weight(_dev(trunk.conv1.weight, dev))
+        plan.add("backbone.conv1", ops.conv_call(x4, s_in, wp, y1, Cin=4, Cout=64, k=7, stride=2, pad=3, scale=sc, shift=sf,
+                                                 act=ACT_RELU, stem=True))
+    plan.keep += [wp, sc, sf]
     plan.flops += 2 * s1.rows * 64 * 147
     plan.step_flops[len(plan.steps) - 1] = 2 * s1.rows * 64 * 147
     pool.put(x4)

@@ -96,6 +96,25 @@ def pack_stem_weight(w: torch.Tensor) -> torch.Tensor:
     return p.contiguous()
 
 
+def pack_stem7_weight(w: torch.Tensor) -> torch.Tensor:
+    """[64,3,7,7] -> [7 filter rows][22][64]: k = 3 * column + channel, k = 21 zero (fd_stem7x7_nhwc4)."""
+    if tuple(w.shape) != (64, 3, 7, 7):
+        raise FdError(f"the stem kernel takes a [64, 3, 7, 7] filter bank (got {tuple(w.shape)})")
+    p = torch.zeros(7, 22, 64, dtype=torch.float32, device=w.device)
+    p[:, :21, :] = w.detach().float().permute(2, 3, 1, 0).reshape(7, 21, 64)
+    return p.contiguous()
+
+
+def stem7x7(x4: Rows, w722: torch.Tensor, y: Rows, N: int, H: int, W: int, scale=None, shift=None, act: int = ACT_NONE) -> None:
+    """ResNet stem 7x7 s2 p3 (3 -> 64) + scale / shift + act on the [N][H][W][4] image rows: its own LDS-staged MFMA kernel."""
+    _need_gpu(w722, scale, shift)
+    if x4.cs != 4 or x4.co != 0 or y.C != 64:
+        raise FdError("stem7x7: input must be the [rows][4] image buffer, output a 64-channel view")
+    check(_lib.lib().fd_stem7x7_nhwc4(x4.ptr, w722.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                      shift.data_ptr() if shift is not None else None, y.ptr, y.cs, y.co, N, H, W, act, _stream()),
+          "fd_stem7x7_nhwc4")
+
+
 def pack_dw_weight(w: torch.Tensor) -> torch.Tensor:
     """[C,1,3,3] -> [9][C]."""
     return w.detach().reshape(w.shape[0], 9).t().contiguous().float()

@@ -806,8 +806,12 @@ def stem_frozen(trunk: nn.Module, x: torch.Tensor) -> torch.Tensor:
         s1 = ops.conv_out_segs(s_in, 7, 2, 3, 1)
         H1, W1 = s1.H[0], s1.W[0]
         y1 = torch.empty(s1.rows, 64, dtype=torch.float32, device=dev)
-        ops.conv_call(Rows(x4), s_in, ops.pack_stem_weight(trunk.conv1.weight), Rows(y1), Cin=4, Cout=64, k=7, stride=2,
-                      pad=3, scale=sc, shift=sf, act=ACT_RELU, stem=True)()
+        from . import engine
+        if engine.STEM_KERNEL:
+            ops.stem7x7(Rows(x4), ops.pack_stem7_weight(trunk.conv1.weight), Rows(y1), B, H, W, sc, sf, ACT_RELU)
+        else:
+            ops.conv_call(Rows(x4), s_in, ops.pack_stem_weight(trunk.conv1.weight), Rows(y1), Cin=4, Cout=64, k=7, stride=2,
+                          pad=3, scale=sc, shift=sf, act=ACT_RELU, stem=True)()
         H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         y2 = torch.empty(B * H2 * W2, 64, dtype=torch.float32, device=dev)
         ops.maxpool(Rows(y1), Rows(y2), B, H1, W1, 3, 2, 1)

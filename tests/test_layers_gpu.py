@@ -127,6 +127,26 @@ def test_conv_stem_7x7():
     np.testing.assert_allclose(from_rows(y, B, 32, 48).numpy(), ref.numpy(), atol=ATOL, rtol=RTOL)
 
 
+@pytest.mark.parametrize("hw", [(64, 96), (70, 50), (32, 32), (130, 258)])
+def test_stem7x7_kernel(hw):
+    """fd_stem7x7_nhwc4 (LDS-staged patch + filter bank, K = 7 x 22) against F.conv2d: full and partial 8 x 32 output tiles, BN + ReLU,
+    output written into a channel slice."""
+    gen = torch.Generator().manual_seed(hw[0] + hw[1])
+    B, (H, W) = 2, hw
+    x = torch.randn(B, 3, H, W, generator=gen)
+    w = torch.randn(64, 3, 7, 7, generator=gen) / np.sqrt(147)
+    scale, shift = torch.rand(64, generator=gen) + 0.5, torch.randn(64, generator=gen)
+    ref = F.relu(F.conv2d(x, w, None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    Ho, Wo = ref.shape[2:]
+    x4 = torch.empty(B * H * W, 4, device=DEV)
+    ops.nchw3_to_nhwc4(x.to(DEV), x4)
+    yb = torch.full((B * Ho * Wo, 72), float("nan"), device=DEV)
+    ops.stem7x7(ops.Rows(x4), ops.pack_stem7_weight(w.to(DEV)), ops.Rows(yb, 4, 64), B, H, W, scale.to(DEV), shift.to(DEV), ACT_RELU)
+    got = yb.cpu()
+    assert torch.isnan(got[:, :4]).all() and torch.isnan(got[:, 68:]).all()
+    np.testing.assert_allclose(got[:, 4:68].reshape(B, Ho, Wo, 64).permute(0, 3, 1, 2).numpy(), ref.numpy(), atol=ATOL, rtol=RTOL)
+
+
 def test_conv_pyramid_channel_views_and_exp():
     """5 levels in one launch, input read from a channel slice, output written into a channel slice,
     exp(scale_level * x) on channels >= 1 (the fused cnt_logits + reg_pred conv)."""
