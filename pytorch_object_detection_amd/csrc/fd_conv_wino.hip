@@ -72,8 +72,8 @@ __device__ __forceinline__ float dpp_quad_2211(float v) {   // lane i of a quad 
 }
 
 // NCH = output-channel blocks of 32 per workgroup: 2 (4 waves, 64 channels, two workgroups per CU) or 4 (8 waves, 128 channels, one
-// workgroup per CU: the V tile -- patch loads, transform, LDS writes, done by waves 0..3 -- is shared by twice as many MFMAs and the
-// input is streamed half as many times; waves 4..7 only run MFMAs, and each SIMD hosts one wave of either kind).
+// workgroup per CU: the V tile -- patch loads, transform, LDS writes -- is shared by twice as many MFMAs and the input is streamed half
+// as many times; the two groups of four waves stage alternate chunks).
 template <int TAG, int NCH>
 __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,7 +90,10 @@ __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kern
     if (cnt <= 0 || idx >= cnt * a.ntiles) return;
     const int nt = idx / cnt, mt = mt_lo + (idx - nt * cnt);
     const int tile0 = mt * WINO_TB, n0 = nt * (32 * NCH);
-    const bool loader = wave < 4;                        // (wave-uniform)
+    // who stages V: with 4 waves everyone, every chunk; with 8 waves the two wave groups take turns -- group g (waves 4g .. 4g + 3) loads,
+    // transforms and writes the chunks of parity g, so each wave carries half the loader work and only one patch slot is live per wave
+    const int grp = wave >> 2;                           // (wave-uniform)
+#define WINO_LD_ON(PAR) (NCH == 2 || grp == (PAR))
     // split-K: slice blockIdx.y owns chunks [c0, c1) and writes raw partial outputs to its slab of the workspace (the host points y at it)
     const int c0 = blockIdx.y * a.nc_per, c1 = min(a.NC, c0 + a.nc_per);
 
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kern
         const int cn1_ = min(cc_ + 1, c1 - 1), cn2_ = min(cc_ + 2, c1 - 1);                                                        \
         const float* Vb = Vs + (SLOT) * STAGE + v_rd;                                                                              \
         float4 fa[8];                                                                                                              \
-        if (loader) { WINO_LOAD_PATCH(SLOT, cn2_); }                                                                               \
+        if (WINO_LD_ON(SLOT)) { WINO_LOAD_PATCH(SLOT, cn2_); }                                                                     \
         fa[0] = read_v(Vb, 0);                                                                                                     \
         fa[1] = read_v(Vb, 1);                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kern
             acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fi].w, fb.w, acc[fi], 0, 0, 0);                                      \
             load_u(cn1_, fi);                                                                                                      \
             if (fi + 2 < 8) fa[fi + 2] = read_v(Vb, fi + 2);                                                                       \
-            if (loader) {                                                                                                          \
+            if (WINO_LD_ON((SLOT) ^ 1)) {                                                                                          \
                 if (fi == 2) WINO_ROW_PASS((SLOT) ^ 1);                                                                            \
                 if (fi >= 3 && fi <= 6) col_store((SLOT) ^ 1, fi - 3);                                                             \
             }                                                                                                                      \
@@ -215,13 +218,11 @@ __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kern
         __syncthreads();                                                                                                           \
     } while (0)
 
-    if (loader) {
-        WINO_LOAD_PATCH(0, c0);
-        WINO_LOAD_PATCH(1, min(c0 + 1, c1 - 1));
-    }
+    if (WINO_LD_ON(0)) { WINO_LOAD_PATCH(0, c0); }
+    if (WINO_LD_ON(1)) { WINO_LOAD_PATCH(1, min(c0 + 1, c1 - 1)); }
 #pragma unroll
     for (int fi = 0; fi < 8; ++fi) load_u(c0, fi);
-    if (loader) {
+    if (WINO_LD_ON(0)) {
         WINO_ROW_PASS(0);
         asm volatile("s_nop 4");      // (VALU write -> DPP read of the same VGPR needs 2 wait states; the hazard recogniser does not see into asm)
 #pragma unroll
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kern
     }
     float* const ybase = a.y + (size_t)blockIdx.y * a.slice_stride;
 #undef WINO_ITER
+#undef WINO_LD_ON
 #undef WINO_ROW_PASS
 #undef WINO_LOAD_PATCH
 
