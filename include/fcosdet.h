@@ -141,6 +141,14 @@ typedef struct fd_conv_params {
      *                     [N][sc_H][sc_W] map at y (and `res` is read there); y_cs / y_co / res_* describe that map. */
     int32_t out_H, out_W;
     int32_t sc_sy, sc_sx, sc_oy, sc_ox, sc_H, sc_W;
+    /* Per-(image, input channel) gate applied to the INPUT in the loader: y = act(conv(x * gate[n][c], w) * scale + shift + res).
+     * The squeeze-excitation gate of an MBConv block (efficientnet_pytorch MBConvBlock: x * sigmoid(se_expand(...)), then _project_conv)
+     * folded into the project conv: the scaling pass over the expanded map (a read and a write of it) disappears.  1x1 stride-1
+     * unpadded convs on a single level, FD_PREC_F32, no split-K; gate is [batch][gate_cs] floats, gate_cs >= Cin, 16-byte aligned rows.
+     * The library picks the block tile (tile / tag are ignored).  NULL = off. */
+    const float* gate;
+    int32_t gate_cs;
+    int32_t reserved0;
 } fd_conv_params;
 
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
@@ -310,6 +318,8 @@ int32_t fd_groupnorm_act_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, co
  * activation is the same swish): y = x * sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2).
  * w1 [Cr][C], w2 [C][Cr]; C % 4 == 0, C <= 4096, Cr <= 1024.  workspace: fd_se_workspace_bytes(N, HW, C).  x and y may alias. */
 int64_t fd_se_workspace_bytes(int32_t N, int32_t HW, int32_t C);
+/* (y == NULL: compute the gates only -- they are left as [N][C] floats at byte offset fd_se_workspace_bytes(N, HW, C) - N * C * 4 of the
+ *  workspace -- for a consumer that applies them itself: fd_conv_params.gate) */
 int32_t fd_se_scale_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w1, const float* b1,
                          const float* w2, const float* b2, float* y, int32_t y_cs, int32_t y_co, int32_t N,
                          int32_t HW, int32_t C, int32_t Cr, void* workspace, fd_stream_t stream);

@@ -59,7 +59,8 @@ class ConvParams(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("precision", C.c_int32), ("res_mode", C.c_int32),
                 ("seg_param", C.c_float * FD_MAX_SEG), ("segs", Segs),
                 ("out_H", C.c_int32), ("out_W", C.c_int32), ("sc_sy", C.c_int32), ("sc_sx", C.c_int32), ("sc_oy", C.c_int32),
-                ("sc_ox", C.c_int32), ("sc_H", C.c_int32), ("sc_W", C.c_int32)]
+                ("sc_ox", C.c_int32), ("sc_H", C.c_int32), ("sc_W", C.c_int32),
+                ("gate", C.c_void_p), ("gate_cs", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class PackJob(C.Structure):

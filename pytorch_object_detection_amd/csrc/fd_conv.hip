@@ -13,7 +13,9 @@
 // Replaces nn.Conv2d(+BatchNorm2d eval)+ReLU/SiLU(+add) of the reference models (see include/fcosdet.h).
 #include "fd_conv_common.h"
 
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT>
+// GATE: the A operand is multiplied by a per-(image, input channel) gate on its way to LDS (1x1 GEMM layers, single level): the
+// squeeze-excitation gate of an MBConv block folded into its project conv.
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT, bool GATE = false>
 __global__ __launch_bounds__(WGM * WGN * 64, (TM * TN == 4) ? ((SPLIT || WGM * WGN == 8) ? 2 : (SB ? 3 : 1)) : 1)
 void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -51,9 +53,11 @@ void conv_igemm_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, (int)a.w_bytes, 0x00020000);
     unsigned a_off[AP];                         // byte offset of tap (0, 0), channel chunk 0 (may wrap below zero)
     int a_wcs[AP], a_hi0[AP], a_wi0[AP], a_H[AP], a_W[AP];
+    const float* g_row[GATE ? AP : 1];          // GATE: this row's image's gate vector, at this thread's channel quad
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + lrow + RPP * i;
+        if (GATE) g_row[i] = a.gate + (size_t)(min(m, a.M - 1) / a.gate_hw) * a.gate_cs + chunk * 4;
         if (a.is_gemm) {  // 1x1, stride 1, no padding: the input row IS the output row (no divisions)
             a_off[i] = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) * 4u;
             a_wcs[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = (m < a.M) ? 1 : 0; a_W[i] = 1;
@@ -84,7 +88,7 @@ void conv_igemm_kernel(ConvArgs a) {
         b_off[j] = (n < a.Cout) ? ((unsigned)n * (unsigned)a.Kpacked + (unsigned)(chunk * 4)) * 4u : OOB;
     }
 
-    float4 ra[AP], rb[BP];
+    float4 ra[AP], rb[BP], rg[GATE ? AP : 1];
     // k-tile order = (32-channel chunk, tap): the 9 taps of one channel chunk are consecutive, so the shifted re-reads
     // of the same input pixels hit L1/L2 instead of travelling from the Infinity Cache.  load_tile() is called with
     // consecutive kt, so (chunk, filter row, filter column) advance as counters (no divisions in the K loop).
@@ -100,6 +104,11 @@ void conv_igemm_kernel(ConvArgs a) {
             dq = ld_q * a.dil;
             dbytes = (unsigned)(dq * a.x_cs + ld_cc * 32) * 4u;
             c_ok = ld_cc * 32 + chunk * 4 < a.Cin;
+            if (GATE) {
+#pragma unroll
+                for (int i = 0; i < AP; ++i)
+                    rg[i] = c_ok ? *reinterpret_cast<const float4*>(g_row[i] + ld_cc * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             if (++ld_q == a.KW) { ld_q = 0; if (++ld_r * a.KW == a.ntaps) { ld_r = 0; ++ld_cc; } }
         }
 #pragma unroll
@@ -139,8 +148,10 @@ void conv_igemm_kernel(ConvArgs a) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < AP; ++i)
+            for (int i = 0; i < AP; ++i) {
+                if (GATE) { ra[i].x *= rg[i].x; ra[i].y *= rg[i].y; ra[i].z *= rg[i].z; ra[i].w *= rg[i].w; }
                 *reinterpret_cast<float4*>(As + buf * BM * 32 + lds_off(lrow + RPP * i, chunk)) = ra[i];
+            }
 #pragma unroll
             for (int j = 0; j < BP; ++j)
                 *reinterpret_cast<float4*>(Bs + buf * BN * 32 + lds_off(lrow + RPP * j, chunk)) = rb[j];
@@ -284,7 +295,7 @@ int fd_launch_splitk_reduce(const ConvArgs& orig, const float* ws, int nslice, i
     return FD_OK;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false>
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false, bool GATE = false>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int lds_ab = (SB ? 1 : 2) * (BM + BN) * 32 * 4;
@@ -294,7 +305,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT>;
+    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT, GATE>;
     static std::atomic<unsigned> attr_mask{0};       // per kernel instantiation, one bit per device
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles, (a.KT + a.kt_per - 1) / a.kt_per), dim3(NT), lds, stream, b);
@@ -392,6 +403,22 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     }
     a.Cout_epi = a.Cout; a.kt_per = a.KT; a.slice_stride = 0;
     a.p_halo = 0;
+    a.gate = nullptr; a.gate_cs = 0; a.gate_hw = 1;
+    if (p->gate) {       // input gate folded into the loader (MBConv: squeeze-excitation gate -> project conv)
+        FD_REQUIRE(a.is_gemm && p->in.nseg == 1 && p->precision == FD_PREC_F32 && p->ksplit <= 1 && !a.sc_on && p->out_H <= 0, FD_E_UNSUPPORTED,
+                   "fd_conv2d: `gate` needs an fp32 1x1 stride-1 unpadded conv on a single level, no split-K / scatter");
+        FD_REQUIRE(p->gate_cs >= p->Cin && p->gate_cs % 4 == 0 && ((uintptr_t)p->gate & 15) == 0, FD_E_INVAL, "fd_conv2d: gate rows must be 16-byte aligned, gate_cs >= Cin");
+        a.gate = p->gate; a.gate_cs = p->gate_cs; a.gate_hw = p->in.H[0] * p->in.W[0];
+        if (a.Cout <= 32) return launch_conv<4, 1, 1, 1, false, false, 0, false, true>(a, stream);      // 128 x 32
+        const long m128 = (a.M + 127) / 128;
+        if (a.Cout <= 64) {
+            if (m128 < 512) return launch_conv<2, 2, 1, 1, false, false, 0, false, true>(a, stream);    // 64 x 64: small maps need more workgroups
+            return launch_conv<2, 2, 2, 1, false, false, 0, false, true>(a, stream);                    // 128 x 64
+        }
+        if (a.Cout <= 96 && m128 >= 512) return launch_conv<4, 1, 1, 3, false, false, 0, false, true>(a, stream);      // 128 x 96
+        if (m128 * ((a.Cout + 127) / 128) < 640) return launch_conv<2, 2, 1, 2, false, false, 0, false, true>(a, stream);   // 64 x 128
+        return launch_conv<2, 2, 2, 2, false, false, 0, false, true>(a, stream);                        // 128 x 128
+    }
     if (p->tile == FD_TILE_128x128_PATCH) {     // 3x3 stride-1 'same' conv with the input patch staged in LDS (fd_conv_patch.hip)
         int wmax = 0;
         for (int sg = 0; sg < p->in.nseg; ++sg) wmax = p->in.W[sg] > wmax ? p->in.W[sg] : wmax;

@@ -29,6 +29,7 @@ struct ConvArgs {
     // output scatter (single level): output pixel (n, i, j) is written to row (n*sc_H + sc_sy*i + sc_oy)*sc_W + sc_sx*j + sc_ox of
     // y (and reads `res` there): one parity class of the data gradient of a strided conv lands interleaved in dX
     int sc_on, sc_sy, sc_sx, sc_oy, sc_ox, sc_H, sc_W;
+    const float* gate; int gate_cs, gate_hw;   // per-(image, input channel) input gate (GATE kernels): [M / gate_hw][gate_cs]
     int p_halo;    // patch kernel (fd_conv_patch.hip): input rows staged on either side of an M-tile = dil * (max level width + 1)
 };
 

@@ -1019,29 +1019,57 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const double* __restrict__ p
                                                      const float* __restrict__ w1, const float* __restrict__ b1,
                                                      const float* __restrict__ w2, const float* __restrict__ b2,
                                                      float* __restrict__ gate) {
-    __shared__ float s_mean[SE_MAXC];
+    __shared__ __attribute__((aligned(16))) float s_mean[SE_MAXC];
     __shared__ float s_h[SE_MAXCR];
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (every loop below keeps several independent loads in flight: with one dependent load per iteration these small loops cost
+    //  0.1-0.2 ms per MBConv block on latency alone)
     for (int c = tid; c < C; c += 256) {
-        double a = 0;
-        for (int k = 0; k < nchunk; ++k) a += part[((long)n * SE_MAXCHUNK + k) * C + c];
-        s_mean[c] = (float)(a / (double)HW);
+        const double* pp = part + (long)n * SE_MAXCHUNK * C + c;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int k = 0;
+        for (; k + 4 <= nchunk; k += 4) {
+            a0 += pp[(long)k * C]; a1 += pp[(long)(k + 1) * C]; a2 += pp[(long)(k + 2) * C]; a3 += pp[(long)(k + 3) * C];
+        }
+        for (; k < nchunk; ++k) a0 += pp[(long)k * C];
+        s_mean[c] = (float)(((a0 + a1) + (a2 + a3)) / (double)HW);
     }
     __syncthreads();
-    for (int j = wv; j < Cr; j += 4) {
-        float a = 0.f;
-        const float* wr = w1 + (long)j * C;
-        for (int c = lane; c < C; c += 64) a = fmaf(wr[c], s_mean[c], a);
+    // squeeze layer: a wave owns rows j = wv, wv + 4, ...; two rows at a time, 4 channels per lane and load (C % 4 == 0)
+    const int C4 = C >> 2;
+    for (int j = wv; j < Cr; j += 8) {
+        const int j2 = j + 4;
+        const bool two = j2 < Cr;
+        const float4* wa = reinterpret_cast<const float4*>(w1 + (long)j * C);
+        const float4* wb = reinterpret_cast<const float4*>(w1 + (long)(two ? j2 : j) * C);
+        float a = 0.f, b = 0.f;
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            const float4 m = *reinterpret_cast<const float4*>(s_mean + 4 * c4);
+            const float4 u = wa[c4], v = wb[c4];
+            a = fmaf(u.x, m.x, a); a = fmaf(u.y, m.y, a); a = fmaf(u.z, m.z, a); a = fmaf(u.w, m.w, a);
+            b = fmaf(v.x, m.x, b); b = fmaf(v.y, m.y, b); b = fmaf(v.z, m.z, b); b = fmaf(v.w, m.w, b);
+        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (lane == 0) s_h[j] = fd_act(a + (b1 ? b1[j] : 0.f), FD_ACT_SILU, 0.f);
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (lane == 0) {
+            s_h[j] = fd_act(a + (b1 ? b1[j] : 0.f), FD_ACT_SILU, 0.f);
+            if (two) s_h[j2] = fd_act(b + (b1 ? b1[j2] : 0.f), FD_ACT_SILU, 0.f);
+        }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float a = b2 ? b2[c] : 0.f;
+    // the expand layer: blockIdx.y owns 256 output channels (a thread's w2 row is Cr scattered loads: with one workgroup per image the
+    // wide EfficientNet blocks -- C up to 2304 -- spent 0.2-0.4 ms here; the squeeze layer above is recomputed per workgroup, it is cheap)
+    const int c = blockIdx.y * 256 + tid;
+    if (c < C) {
         const float* wr = w2 + (long)c * Cr;
-        for (int j = 0; j < Cr; ++j) a = fmaf(wr[j], s_h[j], a);
-        gate[(long)n * C + c] = fd_sigmoid(a);
+        float a0 = b2 ? b2[c] : 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int j = 0;
+        for (; j + 4 <= Cr; j += 4) {
+            a0 = fmaf(wr[j], s_h[j], a0); a1 = fmaf(wr[j + 1], s_h[j + 1], a1);
+            a2 = fmaf(wr[j + 2], s_h[j + 2], a2); a3 = fmaf(wr[j + 3], s_h[j + 3], a3);
+        }
+        for (; j < Cr; ++j) a0 = fmaf(wr[j], s_h[j], a0);
+        gate[(long)n * C + c] = fd_sigmoid((a0 + a1) + (a2 + a3));
     }
 }
 
@@ -1066,7 +1094,7 @@ extern "C" int64_t fd_se_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
 extern "C" int32_t fd_se_scale_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w1, const float* b1,
                                     const float* w2, const float* b2, float* y, int32_t y_cs, int32_t y_co, int32_t N,
                                     int32_t HW, int32_t C, int32_t Cr, void* workspace, fd_stream_t stream) {
-    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C) && w1 && w2 && workspace, FD_E_INVAL,
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && (!y || view_ok(y, y_cs, y_co, C)) && w1 && w2 && workspace, FD_E_INVAL,
                "fd_se_scale: bad pointer / channel view (C=%d)", C);
     FD_REQUIRE(N >= 1 && N <= 65535 && HW >= 1 && Cr >= 1 && Cr <= SE_MAXCR && C <= SE_MAXC, FD_E_UNSUPPORTED,
                "fd_se_scale: C=%d Cr=%d unsupported (C <= %d, Cr <= %d)", C, Cr, SE_MAXC, SE_MAXCR);
@@ -1079,9 +1107,10 @@ extern "C" int32_t fd_se_scale_nhwc(const float* x, int32_t x_cs, int32_t x_co, 
     hipLaunchKernelGGL(se_gap_kernel, dim3(nchunk, N, (C / 4 + QW - 1) / QW), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, HW, C,
                        nchunk, QW, part);
     FD_CHECK_LAUNCH("fd_se_scale (gap)");
-    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const double*)part, nchunk, HW, C, Cr, w1,
+    hipLaunchKernelGGL(se_fc_kernel, dim3(N, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)part, nchunk, HW, C, Cr, w1,
                        b1, w2, b2, gate);
     FD_CHECK_LAUNCH("fd_se_scale (fc)");
+    if (!y) return FD_OK;                            // gates only (left in the workspace for fd_conv_params.gate)
     const long total = (long)N * HW * (C / 4);
     hipLaunchKernelGGL(se_scale_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co,
                        (const float*)gate, y, y_cs, y_co, HW, C / 4, total);

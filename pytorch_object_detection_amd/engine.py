@@ -32,6 +32,7 @@ AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see 
 # F(2x2, 3x3) kernel (fd_conv_wino.hip: 2.25x fewer MFMAs, still fp32 arithmetic) where the map is large enough for it to win
 # (ops.wino_preferred: it has no split-K); "force" = wherever it applies; "0" = every conv on the direct implicit-GEMM kernel
 WINOGRAD = _os.environ.get("FD_WINOGRAD", "1") != "0"
+SE_GATE_IN_PROJECT = _os.environ.get("FD_SE_GATE_FUSED", "1") != "0"     # MBConv: SE gate applied by the project conv's loader ("0": a scaling pass)
 STEM_KERNEL = _os.environ.get("FD_STEM_KERNEL", "1") != "0"     # "0": the ResNet stem through the generic conv kernel's FD_CONV_STEM mode
 
 
@@ -132,7 +133,8 @@ def padded_input(plan: Plan, rows: int, C: int):
 
 def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, y: Rows, *, bn=None, act=ACT_NONE,
              res: Optional[Rows] = None, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
-             Cout: Optional[int] = None, act_c0: int = 0, seg_param=None, tag: int = 0, fold=None) -> Segs:
+             Cout: Optional[int] = None, act_c0: int = 0, seg_param=None, tag: int = 0, fold=None,
+             gate: Optional[torch.Tensor] = None) -> Segs:
     """conv (+folded BN / bias) (+res) (+act).  `weight`/`bias` override conv's own (fused multi-conv launches);
     `fold` = (scale, shift) overrides the epilogue constants altogether (convs with different BN / bias merged by hand)."""
     dev = plan.device
@@ -178,12 +180,14 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     call = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                          shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param, tag=tag,
                          precision=1 if split else 0, workspace=ws.buf if ws is not None else None,
-                         tile=_lib.WINO_TILE if wino else 0, ksplit=wino_ks if wino else 1)
+                         tile=_lib.WINO_TILE if wino else 0, ksplit=wino_ks if wino else 1, gate=gate)
     plan.add(name, call)
     if ws is not None:
         plan.pool.put(ws)
     if wino:
         plan.tiles[name] = _lib.WINO_TILE | ((wino_ks if wino_ks > 1 else 0) << 8)
+    elif gate is not None:
+        plan.tiles[name] = 0                 # (the library picks the tile of a gated conv)
     elif plan.autotune:
         hw = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
         key = f"B{segs.batch}|{hw}|{Cin}>{co}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{x.cs}|ycs{y.cs}"
@@ -340,10 +344,17 @@ def build_efficientnet(plan: Plan, net, batch: int, H: int, W: int, image_ref: L
         b2 = _dev(blk._se_expand.bias, dev)
         sews = ops.se_workspace(batch, ho * wo, mid, dev)
         plan.keep += [wd, w1, b1, w2, b2, sews]
-        plan.add(nm + "._se", lambda d=d, w1=w1, b1=b1, w2=w2, b2=b2, sews=sews, hw=ho * wo:
-                 ops.se_scale(d, w1, b1, w2, b2, d, batch, hw, w1.shape[0], sews))
         out = pool.get(so.rows, blk.cout)
-        add_conv(plan, nm + "._project_conv", d, so, blk._project_conv, out, bn=blk._bn2, res=inp if blk.skip else None)
+        if SE_GATE_IN_PROJECT and plan.precision == "f32":
+            # the gate is multiplied in by the project conv's loader: no scaling pass (a read and a write of the expanded map) at all
+            plan.add(nm + "._se", lambda d=d, w1=w1, b1=b1, w2=w2, b2=b2, sews=sews, hw=ho * wo:
+                     ops.se_gate(d, w1, b1, w2, b2, batch, hw, w1.shape[0], sews))
+            add_conv(plan, nm + "._project_conv", d, so, blk._project_conv, out, bn=blk._bn2, res=inp if blk.skip else None,
+                     gate=ops.se_gate_view(sews, batch, ho * wo, mid))
+        else:
+            plan.add(nm + "._se", lambda d=d, w1=w1, b1=b1, w2=w2, b2=b2, sews=sews, hw=ho * wo:
+                     ops.se_scale(d, w1, b1, w2, b2, d, batch, hw, w1.shape[0], sews))
+            add_conv(plan, nm + "._project_conv", d, so, blk._project_conv, out, bn=blk._bn2, res=inp if blk.skip else None)
         pool.put(d)
         # extract_endpoints: the activation in front of every resolution drop is an endpoint (and the last block's output)
         if ho < h and len(ends) in keep:

@@ -149,7 +149,8 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
               seg_param: Optional[Sequence[float]] = None, stem: bool = False, tile: int = 0,
               tag: int = 0, precision: int = 0, ksplit: int = 1,
               workspace: Optional[torch.Tensor] = None, res_mask: bool = False, kw: Optional[int] = None,
-              out_hw: Optional[Tuple[int, int]] = None, scatter: Optional[Tuple[int, int, int, int, int, int]] = None) -> Callable[[], None]:
+              out_hw: Optional[Tuple[int, int]] = None, scatter: Optional[Tuple[int, int, int, int, int, int]] = None,
+              gate: Optional[torch.Tensor] = None) -> Callable[[], None]:
     """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream."""
     _need_gpu(w_packed, scale, shift)
     p = ConvParams()
@@ -168,6 +169,11 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     p.act, p.act_c0, p.mode = act, act_c0, (_lib.CONV_STEM if stem else _lib.CONV_GENERIC)
     p.tile, p.tag, p.precision, p.ksplit = tile, tag, precision, ksplit
     p.res_mode = 1 if (res_mask and res is not None) else 0
+    if gate is not None:             # [batch, >= Cin] fp32: per-(image, input channel) gate applied in the loader (1x1 convs)
+        _need_gpu(gate)
+        if gate.dim() != 2 or gate.shape[0] != segs.batch or gate.stride(1) != 1 or gate.dtype != torch.float32:
+            raise FdError("conv gate must be a [batch, C] fp32 tensor with unit channel stride")
+        p.gate, p.gate_cs = gate.data_ptr(), gate.stride(0)
     if workspace is not None:
         _need_gpu(workspace)
         p.workspace, p.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
@@ -177,7 +183,7 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     p.segs = segs
     fn = _lib.lib().fd_conv2d_nhwc_f32
     ref = C.byref(p)
-    keep = (x, w_packed, y, scale, shift, res, p, workspace)
+    keep = (x, w_packed, y, scale, shift, res, p, workspace, gate)
 
     def run(_keep=keep):
         check(fn(ref, _stream()), "fd_conv2d_nhwc_f32")
@@ -630,6 +636,21 @@ def se_scale(x: Rows, w1, b1, w2, b2, y: Rows, N: int, HW: int, Cr: int, ws: tor
     check(_lib.lib().fd_se_scale_nhwc(x.ptr, x.cs, x.co, w1.data_ptr(), b1.data_ptr() if b1 is not None else None,
                                       w2.data_ptr(), b2.data_ptr() if b2 is not None else None, y.ptr, y.cs, y.co, N, HW,
                                       x.C, Cr, ws.data_ptr(), _stream()), "fd_se_scale_nhwc")
+
+
+def se_gate(x: Rows, w1, b1, w2, b2, N: int, HW: int, Cr: int, ws: torch.Tensor) -> torch.Tensor:
+    """Squeeze-excitation gates only: sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2) as an [N, C] fp32 view into `ws` (se_workspace), for a
+    consumer that applies them itself (conv_call(..., gate=...): the MBConv project conv multiplies them in on its way to LDS)."""
+    check(_lib.lib().fd_se_scale_nhwc(x.ptr, x.cs, x.co, w1.data_ptr(), b1.data_ptr() if b1 is not None else None,
+                                      w2.data_ptr(), b2.data_ptr() if b2 is not None else None, None, 0, 0, N, HW,
+                                      x.C, Cr, ws.data_ptr(), _stream()), "fd_se_scale_nhwc")
+    return se_gate_view(ws, N, HW, x.C)
+
+
+def se_gate_view(ws: torch.Tensor, N: int, HW: int, C_: int) -> torch.Tensor:
+    """The [N, C] gate array inside an se_workspace buffer (the last N * C floats of its fd_se_workspace_bytes)."""
+    nbytes = _lib.lib().fd_se_workspace_bytes(N, HW, C_)
+    return ws.view(torch.float32)[nbytes // 4 - N * C_: nbytes // 4].view(N, C_)
 
 
 def se_scale_bwd(x: Rows, dy: Rows, w1, b1, w2, b2, dx: Rows, N: int, HW: int, Cr: int, fwd_ws: torch.Tensor):

@@ -844,3 +844,41 @@ def test_winograd_vs_direct_kernel_at_the_bench_shapes():
         d = (yw.tensor() - yd.tensor()).abs().max().item()
         assert d < 5e-5, (name, d)            # (measured 1.3e-5 at unit-scale outputs; the parity bar vs the CPU path is 1e-4)
         assert float(yd.tensor().abs().max()) > 1.0
+
+
+@pytest.mark.parametrize("case", [(144, 24, 9, 7), (192, 32, 16, 16), (816, 136, 5, 6), (288, 48, 12, 20), (96, 160, 8, 8)])
+def test_conv1x1_with_input_gate(case):
+    """fd_conv_params.gate: y = conv1x1(x * gate[n][c]) * scale + shift (+ res) -- the MBConv project conv with the squeeze-excitation gate
+    folded into its loader (EfficientNet widths incl. Cin % 32 != 0), against the two-step torch reference; and the gates-only mode of
+    fd_se_scale_nhwc that produces them."""
+    Cin, Cout, H, W = case
+    gen = torch.Generator().manual_seed(Cin + Cout)
+    B = 3
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    gate = torch.rand(B, Cin, generator=gen)
+    w = torch.randn(Cout, Cin, 1, 1, generator=gen) / Cin ** 0.5
+    scale, shift = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen)
+    res = torch.randn(B, Cout, H, W, generator=gen)
+    ref = F.conv2d(x * gate[:, :, None, None], w) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res
+    segs = Segs.make(B, [(H, W)])
+    gbuf = torch.full((B, Cin + 4), float("nan"), device=DEV)           # gate rows with a stride (gate_cs > Cin)
+    gbuf[:, :Cin] = gate.to(DEV)
+    y = ops.new_rows(B * H * W, Cout, DEV)
+    ops.conv_call(to_rows(x), segs, ops.pack_conv_weight(w.to(DEV)), y, Cin=Cin, Cout=Cout, k=1, scale=scale.to(DEV), shift=shift.to(DEV),
+                  res=to_rows(res), gate=gbuf[:, :Cin])()
+    np.testing.assert_allclose(from_rows(y, B, H, W).numpy(), ref.numpy(), atol=ATOL, rtol=1e-4)
+    with pytest.raises(Exception, match="gate"):            # 3x3: not a GEMM layer
+        w3 = torch.randn(Cout, Cin, 3, 3, generator=gen)
+        ops.conv_call(to_rows(x), segs, ops.pack_conv_weight(w3.to(DEV)), y, Cin=Cin, Cout=Cout, k=3, pad=1, gate=gbuf[:, :Cin])()
+    # gates-only squeeze-excitation
+    Cr = max(4, Cin // 24)
+    w1, b1 = torch.randn(Cr, Cin, generator=gen) / Cin ** 0.5, torch.randn(Cr, generator=gen) * 0.1
+    w2, b2 = torch.randn(Cin, Cr, generator=gen) / Cr ** 0.5, torch.randn(Cin, generator=gen) * 0.1
+    m = x.mean(dim=(2, 3))
+    g_ref = torch.sigmoid(F.silu(m @ w1.t() + b1) @ w2.t() + b2)
+    ws = ops.se_workspace(B, H * W, Cin, DEV)
+    xr = to_rows(x)
+    before = xr.tensor().clone()
+    g = ops.se_gate(xr, w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), B, H * W, Cr, ws)
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref.numpy(), atol=1e-5, rtol=1e-5)
+    assert torch.equal(xr.tensor(), before)                 # x untouched
