@@ -181,12 +181,7 @@ void conv_igemm_kernel(ConvArgs a) {
         ld_q = tap0 - ld_r * a.KW;
     }
     float* const ybase = a.y + (size_t)blockIdx.y * a.slice_stride;   // (never write to the kernarg struct itself)
-    load_tile(kt0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = SB ? 0 : ((kt - kt0) & 1);
-        if (kt + 1 < kt1) load_tile(kt + 1);
+    auto mfma_tile = [&](int buf) {
         if constexpr (SPLIT) {
             const _Float16* Ahi = Hs + buf * HSTG + (wm * TM * 32) * 32;
             const _Float16* Alo = Ahi + BM * 32;
@@ -237,16 +232,26 @@ void conv_igemm_kernel(ConvArgs a) {
             }
             __builtin_amdgcn_s_setprio(0);
         }
-        if (SB) {
-            __syncthreads();                       // every wave is done reading the tile
-            if (kt + 1 < kt1) store_tile(0);
-        } else if (kt + 1 < kt1) {
-            store_tile(buf ^ 1);
-        }
+    };
+    load_tile(kt0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1 - 1; ++kt) {
+        const int buf = SB ? 0 : ((kt - kt0) & 1);
+        load_tile(kt + 1);
+        mfma_tile(buf);
+        if (SB) __syncthreads();                   // every wave is done reading the tile
+        store_tile(SB ? 0 : (buf ^ 1));
         __syncthreads();
     }
+    // last K-tile (peeled: no operand loads left): the residual tile is fetched under its MFMAs
+#include "fd_conv_res_prefetch.inc"
+    mfma_tile(SB ? 0 : ((kt1 - 1 - kt0) & 1));
+    __syncthreads();
 
+#define FD_EPI_RES_PREFETCHED
 #include "fd_conv_epilogue.inc"
+#undef FD_EPI_RES_PREFETCHED
 }
 
 // split-K combine: y = act(sum_slices(ws) * scale + shift + res); one float4 of output channels per thread, slices
@@ -487,6 +492,13 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
             case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true, 1>(a, stream);
             case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true, 1>(a, stream);
             default: break;  // other tiles keep the shared symbol
+        }
+    }
+    {   // GEMM-addressed layers: the persistent kernel (fd_conv_pw.hip)
+        static const int pw = getenv("FD_CONV_PERSIST") ? atoi(getenv("FD_CONV_PERSIST")) : 0;
+        if (pw && a.is_gemm && a.kt_per == a.KT && !a.gate) {
+            const int rc = fd_launch_conv_pw(a, p->tile, stream);
+            if (rc != FD_E_UNSUPPORTED) return rc;
         }
     }
     switch (p->tile) {

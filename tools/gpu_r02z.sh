@@ -24,3 +24,9 @@ for b in 1 2; do timeout -k 10 200 python bench.py --batch $b --size 512 --infli
 FD_WINOGRAD=0 timeout -k 10 300 python bench.py --no-fast-mode --no-train-step --no-cpu-baseline > $O/bench_direct_kernels_only.json 2> $O/bench_direct.err
 timeout -k 10 200 python tools/time_wino.py 2>&1 | grep -v amdgpu.ids > $O/time_wino.txt
 du -sh gpurun_out
+# the 1x1 (GEMM-addressed) layers: time against K (compute + memory add up), persistent kernel on / off, socket power in three regimes
+{ for a in "128 512 1 1 80 80 1" "256 512 1 1 80 80 1" "512 512 1 1 80 80 1" "128 512 1 1 80 80 0" "64 256 1 1 160 160 1" "256 64 1 1 160 160 0" "1024 256 1 1 40 40 0"; do
+    for pw in 0 1; do echo "FD_CONV_PERSIST=$pw"; FD_CONV_PERSIST=$pw FD_TILES=4,8,9 timeout -k 10 100 python tools/time_conv.py $a; done; done
+  timeout -k 10 60 python tools/power_probe.py 2048 512 80 80 0 9 3; timeout -k 10 60 python tools/power_probe.py 128 512 80 80 1 9 3
+  timeout -k 10 60 python tools/power_probe.py 32 512 80 80 1 9 3; } 2>&1 | grep -v amdgpu.ids > $O/pw_study.txt
+du -sh gpurun_out
