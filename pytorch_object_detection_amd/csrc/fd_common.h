@@ -55,7 +55,7 @@ __device__ __forceinline__ float fd_act(float v, int act, float p) {
         case FD_ACT_RELU: return v > 0.f ? v : 0.f;
         // SiLU on the hardware exp / reciprocal (v_exp_f32, v_rcp_f32: ~2 ulp): the libm expf + IEEE divide cost ~25 VALU instructions per
         // element, which made the MBConv expand / depthwise epilogues (2.6 GB maps) VALU-bound; parity bar of these layers: 1e-4
-        case FD_ACT_SILU: return __fdividef(v, 1.0f + __expf(-v));
+        case FD_ACT_SILU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // (HIP's __fdividef is a plain IEEE divide)
         case FD_ACT_EXP: return expf(v * p);
         case FD_ACT_SIGMOID: return fd_sigmoid(v);
         default: return v;

@@ -269,13 +269,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, const fl
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
         float o[4] = {v.x, v.y, v.z, v.w};
-        float prm = 0.f;
+        float prm = a.seg_param[0];      // (select chain over uniform argument reads: see fd_conv_epilogue.inc)
         if (a.act == FD_ACT_EXP) {
-            int sg = 0;
 #pragma unroll
             for (int t = 1; t < FD_MAX_SEG; ++t)
-                if (t < a.nseg && m >= a.m_out[t]) sg = t;
-            prm = a.seg_param[sg];
+                prm = (t < a.nseg && m >= a.m_out[t]) ? a.seg_param[t] : prm;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
