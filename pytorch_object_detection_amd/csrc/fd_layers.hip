@@ -16,8 +16,9 @@ static inline unsigned grid_for(long work, int block) {
 __global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float4* __restrict__ y,
                                                               int HW, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long n = i / HW;
-        const long p = i - n * HW;
+        int pi;
+        const long n = fd_div(i, HW, pi);
+        const long p = pi;
         const float* b = x + n * 3 * HW + p;
         y[i] = make_float4(b[0], b[HW], b[2 * (long)HW], 0.f);
     }
@@ -119,8 +120,8 @@ __device__ __forceinline__ float fd_act_deriv(float x, int act, float p) {
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int y_cs,
                                                        int y_co, int C4, int act, float prm, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long m = i / C4;
+        int q;
+        const long m = fd_div(i, C4, q);
         const float4 v = *reinterpret_cast<const float4*>(x + m * x_cs + x_co + 4 * q);
         *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) =
             make_float4(fd_act(v.x, act, prm), fd_act(v.y, act, prm), fd_act(v.z, act, prm), fd_act(v.w, act, prm));
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                                                        int dy_cs, int dy_co, float* __restrict__ dx, int dx_cs, int dx_co, int C4,
                                                        int act, float prm, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long m = i / C4;
+        int q;
+        const long m = fd_div(i, C4, q);
         const float4 v = *reinterpret_cast<const float4*>(x + m * x_cs + x_co + 4 * q);
         const float4 g = *reinterpret_cast<const float4*>(dy + m * dy_cs + dy_co + 4 * q);
         *reinterpret_cast<float4*>(dx + m * dx_cs + dx_co + 4 * q) =
@@ -172,12 +173,12 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
                                                        const float* __restrict__ add, int add_cs, int add_co, int H,
                                                        int W, int Ho, int Wo, int C4, int k, int s, int pad, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long m = i / C4;
-        const int wo = (int)(m % Wo);
-        const long t = m / Wo;
-        const int ho = (int)(t % Ho);
-        const long n = t / Ho;
+        int q;
+        const long m = fd_div(i, C4, q);
+        int wo;
+        const long t = fd_div(m, Wo, wo);
+        int ho;
+        const long n = fd_div(t, Ho, ho);
         float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         for (int r = 0; r < k; ++r) {
             const int hi = ho * s - pad + r;
@@ -224,12 +225,12 @@ __global__ __launch_bounds__(256) void upsample2x_add_kernel(const float* __rest
                                                               int C4, long total) {
     const int Ho = 2 * H, Wo = 2 * W;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long m = i / C4;
-        const int wo = (int)(m % Wo);
-        const long t = m / Wo;
-        const int ho = (int)(t % Ho);
-        const long n = t / Ho;
+        int q;
+        const long m = fd_div(i, C4, q);
+        int wo;
+        const long t = fd_div(m, Wo, wo);
+        int ho;
+        const long n = fd_div(t, Ho, ho);
         const float4 u = *reinterpret_cast<const float4*>(x + ((n * H + (ho >> 1)) * W + (wo >> 1)) * x_cs + x_co + 4 * q);
         const float4 l = *reinterpret_cast<const float4*>(lat + m * lat_cs + lat_co + 4 * q);
         *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) = make_float4(u.x + l.x, u.y + l.y, u.z + l.z, u.w + l.w);
@@ -256,12 +257,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
                                                            int dy_cs, int dy_co, float* __restrict__ dx, int dx_cs, int dx_co, int H,
                                                            int W, int Ho, int Wo, int C4, int k, int s, int pad, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long m = i / C4;
-        const int wi = (int)(m % W);
-        const long t = m / W;
-        const int hi = (int)(t % H);
-        const long n = t / H;
+        int q;
+        const long m = fd_div(i, C4, q);
+        int wi;
+        const long t = fd_div(m, W, wi);
+        int hi;
+        const long n = fd_div(t, H, hi);
         const float* xb = x + (n * H * (long)W) * x_cs + x_co + 4 * q;
         const float4 me = *reinterpret_cast<const float4*>(xb + ((long)hi * W + wi) * x_cs);
         float g[4] = {0.f, 0.f, 0.f, 0.f};
@@ -316,12 +317,12 @@ extern "C" int32_t fd_maxpool_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_c
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, int dy_cs, int dy_co, float* __restrict__ dx,
                                                               int dx_cs, int dx_co, int H, int W, int C4, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long m = i / C4;
-        const int w = (int)(m % W);
-        const long t = m / W;
-        const int h = (int)(t % H);
-        const long n = t / H;
+        int q;
+        const long m = fd_div(i, C4, q);
+        int w;
+        const long t = fd_div(m, W, w);
+        int h;
+        const long n = fd_div(t, H, h);
         const float* b = dy + ((n * 2 * H + 2 * h) * (long)(2 * W) + 2 * w) * dy_cs + dy_co + 4 * q;
         const float4 a0 = *reinterpret_cast<const float4*>(b), a1 = *reinterpret_cast<const float4*>(b + dy_cs);
         const float4 a2 = *reinterpret_cast<const float4*>(b + (long)2 * W * dy_cs), a3 = *reinterpret_cast<const float4*>(b + (long)(2 * W + 1) * dy_cs);
@@ -352,8 +353,8 @@ __device__ __forceinline__ void seg_decode(const fd_segs& sg, long m, int& H, in
     H = sg.H[s]; W = sg.W[s];
     const long local = m - sg.m_start[s];
     const int hw = H * W;
-    const long n = local / hw;
-    const int rem = (int)(local - n * hw);
+    int rem;
+    const long n = fd_div(local, hw, rem);
     h = rem / W; w = rem - h * W;
     img_row0 = sg.m_start[s] + n * hw;
 }
@@ -374,8 +375,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const float* __res
                                                                int y_co, int C, int act, StripTab tab, long total) {
     const int C4 = C >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long t = i / C4;
+        int q;
+        const long t = fd_div(i, C4, q);
         int s = 0;
 #pragma unroll
         for (int k = 1; k < FD_MAX_SEG; ++k)
@@ -383,8 +384,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const float* __res
         const int H = tab.s.H[s], W = tab.s.W[s], spr = tab.spr[s];
         const long local = t - tab.strip_start[s];
         const int per_img = H * spr;
-        const long n = local / per_img;
-        const int rem = (int)(local - n * per_img);
+        int rem;
+        const long n = fd_div(local, per_img, rem);
         const int h = rem / spr, w0 = (rem - h * spr) * S;
         const long r0 = (long)tab.s.m_start[s] + n * H * W;
         float4 acc[S];
@@ -465,8 +466,8 @@ __global__ __launch_bounds__(256) void dwconv_dilated_kernel(const float* __rest
                                                               SegTab tab, long total) {
     const int C4 = C >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long m = i / C4;
+        int q;
+        const long m = fd_div(i, C4, q);
         int H, W, h, w;
         long row0;
         seg_decode(tab.s, m, H, W, row0, h, w);
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ y, int y_cs, int y_co, int C, int G, float eps,
                                                         int act, SegTab tab, const double* __restrict__ gstat) {
-    __shared__ float s_a[1024], s_b[1024];  // per-channel scale / bias
+    __shared__ __attribute__((aligned(16))) float s_a[1024], s_b[1024];  // per-channel scale / bias
     const int img = blockIdx.y;
     const int s = img / tab.s.batch, n = img - s * tab.s.batch;
     const int HW = tab.s.H[s] * tab.s.W[s];
@@ -737,19 +738,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         s_b[c] = beta[c] - (float)p[0] * sc;
     }
     __syncthreads();
-    const int C4 = C >> 2;
+    // C / 4 divides 256 (checked by the host): a thread keeps ONE channel quad (its scale / bias in registers) and walks rows, so the loop
+    // has no index division (a 64-bit i / C4, i % C4 per float4 is ~100 VALU instructions on this ISA)
+    const int C4 = C >> 2, q = tid % C4, rt = tid / C4, RT = 256 / C4;
     const long row0 = (long)tab.s.m_start[s] + (long)n * HW;
-    const long total = (long)(r_end - r_begin) * C4;
-    for (long i = tid; i < total; i += 256) {
-        const int q = (int)(i % C4);
-        const long m = row0 + r_begin + i / C4;
-        const float4 v = *reinterpret_cast<const float4*>(x + m * x_cs + x_co + 4 * q);
+    const float4 sa = *reinterpret_cast<const float4*>(s_a + 4 * q), sb = *reinterpret_cast<const float4*>(s_b + 4 * q);
+    const float* xp = x + (row0 + r_begin + rt) * x_cs + x_co + 4 * q;
+    float* yp = y + (row0 + r_begin + rt) * y_cs + y_co + 4 * q;
+    const long xs = (long)RT * x_cs, ys = (long)RT * y_cs;
+    for (int r = r_begin + rt; r < r_end; r += RT, xp += xs, yp += ys) {
+        const float4 v = *reinterpret_cast<const float4*>(xp);
         float4 o;
-        o.x = fd_act(v.x * s_a[4 * q] + s_b[4 * q], act, 0.f);
-        o.y = fd_act(v.y * s_a[4 * q + 1] + s_b[4 * q + 1], act, 0.f);
-        o.z = fd_act(v.z * s_a[4 * q + 2] + s_b[4 * q + 2], act, 0.f);
-        o.w = fd_act(v.w * s_a[4 * q + 3] + s_b[4 * q + 3], act, 0.f);
-        *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) = o;
+        o.x = fd_act(v.x * sa.x + sb.x, act, 0.f);
+        o.y = fd_act(v.y * sa.y + sb.y, act, 0.f);
+        o.z = fd_act(v.z * sa.z + sb.z, act, 0.f);
+        o.w = fd_act(v.w * sa.w + sb.w, act, 0.f);
+        *reinterpret_cast<float4*>(yp) = o;
     }
 }
 
@@ -900,8 +904,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const long row0 = (long)tab.s.m_start[s] + (long)n * HW;
     const long total = (long)(r_end - r_begin) * C4;
     for (long i = tid; i < total; i += 256) {
-        const int q = (int)(i % C4);
-        const long m = row0 + r_begin + i / C4;
+        int q;
+        const long m = row0 + r_begin + fd_div(i, C4, q);
         const float4 v4 = *reinterpret_cast<const float4*>(x + m * x_cs + x_co + 4 * q);
         const float4 g4 = *reinterpret_cast<const float4*>(dy + m * dy_cs + dy_co + 4 * q);
         const float v[4] = {v4.x, v4.y, v4.z, v4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w};
@@ -1089,9 +1093,9 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const float* __restrict__
                                                         const float* __restrict__ gate, float* __restrict__ y, int y_cs,
                                                         int y_co, int HW, int C4, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long m = i / C4;
-        const long n = m / HW;
+        int q;
+        const long m = fd_div(i, C4, q);
+        int hw_rem_; const long n = fd_div(m, HW, hw_rem_);
         const float4 v = *reinterpret_cast<const float4*>(x + m * x_cs + x_co + 4 * q);
         const float4 g = *reinterpret_cast<const float4*>(gate + n * C4 * 4 + 4 * q);
         *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
@@ -1241,9 +1245,9 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restri
                                                             const float* __restrict__ dmean, float* __restrict__ dx, int dx_cs, int dx_co,
                                                             int HW, int C4, float inv_hw, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long m = i / C4;
-        const long n = m / HW;
+        int q;
+        const long m = fd_div(i, C4, q);
+        int hw_rem_; const long n = fd_div(m, HW, hw_rem_);
         const float4 v = *reinterpret_cast<const float4*>(dy + m * dy_cs + dy_co + 4 * q);
         const float4 g = *reinterpret_cast<const float4*>(gate + n * C4 * 4 + 4 * q);
         const float4 d = *reinterpret_cast<const float4*>(dmean + n * C4 * 4 + 4 * q);

@@ -35,11 +35,11 @@ __global__ __launch_bounds__(256) void dwconv_kxk_kernel(const float* __restrict
     const int C4 = C >> 2;
     const int spr = (Wo + S - 1) / S;          // strips per output row
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        long t = i / C4;
-        const int sx = (int)(t % spr); t /= spr;
-        const int ho = (int)(t % Ho);
-        const long n = t / Ho;
+        int q;
+        long t = fd_div(i, C4, q);
+        int sx; t = fd_div(t, spr, sx);
+        int ho;
+        const long n = fd_div(t, Ho, ho);
         const int wo0 = sx * S;
         const int hi0 = ho * STRIDE - pad_t, wi0 = wo0 * STRIDE - pad_l;
         const float* xb = x + (n * H * (long)W) * x_cs + x_co + 4 * q;
@@ -128,11 +128,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float4* __restrict
     const int C4 = Cout >> 2;
     const int spr = (Wo + S - 1) / S;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        long t = i / C4;
-        const int sx = (int)(t % spr); t /= spr;
-        const int ho = (int)(t % Ho);
-        const long n = t / Ho;
+        int q;
+        long t = fd_div(i, C4, q);
+        int sx; t = fd_div(t, spr, sx);
+        int ho;
+        const long n = fd_div(t, Ho, ho);
         const int wo0 = sx * S;
         const int hi0 = ho * STRIDE - pad_t, wi0 = wo0 * STRIDE - pad_l;
         const float4* xb = x + n * H * (long)W;
@@ -217,10 +217,10 @@ __global__ __launch_bounds__(256) void collate_u8_kernel(const unsigned char* co
                                                           float4* __restrict__ y, int H, int W, float m0, float m1, float m2,
                                                           float s0, float s1, float s2, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int wq = (int)(i % W);
-        const long t = i / W;
-        const int hq = (int)(t % H);
-        const int n = (int)(t / H);
+        int wq;
+        const long t = fd_div(i, W, wq);
+        int hq;
+        const int n = (int)fd_div(t, H, hq);
         const int h = hw[2 * n], w = hw[2 * n + 1];
         float r = 0.f, g = 0.f, b = 0.f;
         if (hq < h && wq < w) {
