@@ -79,6 +79,7 @@ class Plan:
         self.keep: List[object] = []       # tensors that must outlive the plan (packed weights, workspaces)
         self.flops = 0                     # algorithmic conv FLOPs (2*MACs) of one run
         self.step_flops: Dict[int, int] = {}
+        self.step_info: Dict[int, dict] = {}   # conv steps: kernel size / stride / which kernel family ran it (bench.py's family rooflines)
         self.marks: Dict[str, Tuple[int, int]] = {}
         self.autotune = AUTOTUNE        # time block-tile candidates per conv at plan-build time
         self.precision = precision or CONV_PRECISION
@@ -196,6 +197,8 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co, -(-Cin // 32) * k * k, pair=plan.pair_tuned and tag != 1)
     plan.flops += 2 * out.rows * co * Cin * k * k
     plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k
+    plan.step_info[len(plan.steps) - 1] = {"k": k, "stride": stride, "dil": dil, "Cin": Cin, "Cout": co, "rows": out.rows,
+                                           "family": "winograd3x3" if wino else ("1x1" if k == 1 else f"direct{k}x{k}")}
     return out
 
 

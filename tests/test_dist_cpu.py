@@ -67,3 +67,39 @@ def test_gather_detections_gloo_world2():
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     mp.spawn(_worker, args=(2, port), nprocs=2, join=True)
+
+
+# ---------------------------------------------------------------------------------------------- bench.py's own launcher
+def _bench(args, env_extra):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr
+
+
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_gpus_n_launches_n_ranks_itself(mode):
+    """`python bench.py --gpus N` with no launcher around it starts N rank processes, relays rank 0's ONE line and reports
+    n_gpus == N (it used to run one rank silently).  FD_BENCH_DRYRUN: the ranks rendezvous over gloo and run a
+    collective but no GPU work, so the control flow is checked on a CPU-only host."""
+    rc, lines, err = _bench(["--gpus", "2", "--mode", mode], {"FD_BENCH_DRYRUN": "1"})
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["dryrun"] is True and lines[0]["mode"] == mode
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """No GPU here: every rank exits non-zero ('bench.py needs a GPU'); the launcher must say so and print no line."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a CPU-only host")
+    rc, lines, err = _bench(["--gpus", "2"], {})
+    assert rc != 0 and lines == [] and "exited with code" in err
+
+
+def test_bench_rejects_world_size_mismatch():
+    rc, lines, err = _bench(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "FD_BENCH_DRYRUN": "1"})
+    assert rc != 0 and lines == [] and "--gpus 2 but WORLD_SIZE=1" in err
