@@ -1,0 +1,179 @@
+"""a1 (ResNet-50 trunk) pinned STRUCTURALLY against the only thing the reference holds about torchvision's trunk: the layer table it
+recorded at 1x3x512x512 (Result/proposed:12-184 -> tests/golden/g11_trunk_dump.npz by tests/golden/make_g11_trunk_dump.py): every
+conv's input / output shape, kernel, parameter count, multiply-adds; BatchNorm widths; the pooling step; the downsample branches; and
+the parameter totals the reference states (trunk 23 508 032 resnet50.py:45; FPN 7 648 224, head 1 507 358 HISFcos.py:247-248).
+The trunk's ARITHMETIC stays third-party / unpinned; what is pinned here is that the oracle and the product compute
+the same layer graph the reference ran."""
+import numpy as np
+import pytest
+import torch
+
+KIND = {"Conv2d": 0, "BatchNorm2d": 1, "ReLU": 2, "MaxPool2d": 3, "Sequential": 4, "Bottleneck": 5}
+
+
+def _rows(g):
+    return [dict(kind=int(g["kind"][i]), depth=int(g["depth"][i]), inp=tuple(int(v) for v in g["in_shape"][i]),
+                 out=tuple(int(v) for v in g["out_shape"][i]), params=int(g["params"][i]),
+                 ks=tuple(int(v) for v in g["kernel_shape"][i]), madds=int(g["mult_adds"][i])) for i in range(len(g["kind"]))]
+
+
+def _dump_ops(g):
+    """The dump as the ordered list of arithmetic steps: ('conv', in, out, (Cin, Cout, kh, kw), params, madds), ('bn', in, C, params),
+    ('pool', in, out), ('down', in, out, params, madds).  The 'Sequential' row right after a block's third BatchNorm is its downsample
+    branch (1x1 conv + BatchNorm, torchinfo folds the pair into one row)."""
+    ops = []
+    for r in _rows(g):
+        if r["kind"] == KIND["Conv2d"]:
+            ops.append(("conv", r["inp"], r["out"], r["ks"], r["params"], r["madds"]))
+        elif r["kind"] == KIND["BatchNorm2d"]:
+            ops.append(("bn", r["inp"], r["ks"][0], r["params"]))
+        elif r["kind"] == KIND["MaxPool2d"]:
+            ops.append(("pool", r["inp"], r["out"]))
+        elif r["kind"] == KIND["Sequential"] and r["depth"] == 4:
+            ops.append(("down", r["inp"], r["out"], r["params"], r["madds"]))
+    return ops
+
+
+def test_fixture_is_the_resnet50_v15_table(golden):
+    g = golden("g11_trunk_dump")
+    ops = _dump_ops(g)
+    convs = [o for o in ops if o[0] == "conv"]
+    downs = [o for o in ops if o[0] == "down"]
+    assert len(convs) == 49 and len(downs) == 4 and sum(o[0] == "pool" for o in ops) == 1
+    total = sum(o[4] for o in convs) + sum(o[3] for o in ops if o[0] == "bn") + sum(o[3] for o in downs)
+    assert total == int(g["trunk_params"]) == 23508032
+    assert int(g["fpn_params"]) == 7648224 and int(g["head_params_20cls"]) == 1507358
+    # v1.5: the stride sits on the 3x3 of the first block of layers 2-4 (input 128 -> output 64 on a [.., 3, 3] kernel)
+    strided = [o for o in convs if o[3][2:] == (3, 3) and o[1][2] == 2 * o[2][2]]
+    assert [o[3][:2] for o in strided] == [(128, 128), (256, 256), (512, 512)]
+    # multiply-adds recorded per conv = out pixels * Cout * Cin * kh * kw
+    for o in convs:
+        assert o[5] == o[2][2] * o[2][3] * o[3][0] * o[3][1] * o[3][2] * o[3][3], o
+
+
+def test_oracle_trunk_walks_the_recorded_layer_graph(golden, monkeypatch):
+    """oracle/torch_ref.resnet50_c345 at 1x3x512x512: the sequence of conv / BatchNorm / max-pool calls it makes, with their tensor
+    shapes, IS the recorded table."""
+    import torch.nn.functional as F
+    from oracle import torch_ref as R
+    from pytorch_object_detection_amd.model.od import HalfInvertedStageFCOS
+    g = golden("g11_trunk_dump")
+    torch.manual_seed(0)
+    sd = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).state_dict()
+    seen = []
+    conv0, bn0, pool0 = R._conv, R._bn, F.max_pool2d
+
+    def conv(sd_, p, x, stride=1, pad=0, dil=1, groups=1):
+        y = conv0(sd_, p, x, stride, pad, dil, groups)
+        w = sd_[p + ".weight"]
+        seen.append(["conv", tuple(x.shape), tuple(y.shape), (w.shape[1], w.shape[0], w.shape[2], w.shape[3]), w.numel(), p])
+        return y
+
+    def bn(sd_, p, x):
+        seen.append(["bn", tuple(x.shape), x.shape[1], 2 * x.shape[1], p])
+        return bn0(sd_, p, x)
+
+    def pool(x, *a, **k):
+        y = pool0(x, *a, **k)
+        seen.append(["pool", tuple(x.shape), tuple(y.shape)])
+        return y
+
+    monkeypatch.setattr(R, "_conv", conv)
+    monkeypatch.setattr(R, "_bn", bn)
+    monkeypatch.setattr(R.F, "max_pool2d", pool)
+    with torch.no_grad():
+        c3, c4, c5 = R.resnet50_c345(sd, torch.zeros(1, 3, 512, 512))
+    assert tuple(c3.shape) == (1, 512, 64, 64) and tuple(c4.shape) == (1, 1024, 32, 32) and tuple(c5.shape) == (1, 2048, 16, 16)
+    # fold the oracle's (downsample conv, downsample BN) pairs into one 'down' step like the table does
+    mine, i = [], 0
+    while i < len(seen):
+        s = seen[i]
+        if s[0] == "conv" and ".downsample.0" in s[-1]:
+            mine.append(("down", s[1], s[2], s[4] + seen[i + 1][3]))
+            i += 2
+            continue
+        mine.append(tuple(s[:-1]) if s[0] != "pool" else tuple(s))
+        i += 1
+    want = _dump_ops(g)
+    assert len(mine) == len(want)
+    for a, b in zip(mine, want):
+        assert a[0] == b[0]
+        if a[0] == "conv":
+            assert a[1:5] == b[1:5], (a, b)
+        elif a[0] == "down":
+            assert a[1:4] == b[1:4], (a, b)
+        else:
+            assert a == b, (a, b)
+
+
+def test_product_containers_hold_the_recorded_parameters(golden):
+    """pytorch_object_detection_amd's ResNet50v2 / FPN / head containers: per-layer weight shapes in table order and the totals."""
+    from pytorch_object_detection_amd.model.od import HalfInvertedStageFCOS
+    g = golden("g11_trunk_dump")
+    m = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256)
+    trunk = m.backbone.trunk
+    mods = [(n, c) for n, c in trunk.named_modules() if isinstance(c, (torch.nn.Conv2d, torch.nn.BatchNorm2d))]
+    mine = []
+    i = 0
+    while i < len(mods):
+        n, c = mods[i]
+        if isinstance(c, torch.nn.Conv2d) and ".downsample.0" in n:
+            mine.append(("down", c.weight.numel() + sum(p.numel() for p in mods[i + 1][1].parameters())))
+            i += 2
+            continue
+        if isinstance(c, torch.nn.Conv2d):
+            w = c.weight
+            mine.append(("conv", (w.shape[1], w.shape[0], w.shape[2], w.shape[3]), w.numel(), c.stride[0]))
+        else:
+            mine.append(("bn", c.num_features, sum(p.numel() for p in c.parameters())))
+        i += 1
+    want = [o for o in _dump_ops(g) if o[0] != "pool"]
+    # the table lists a block as conv1 bn1 conv2 bn2 conv3 bn3 [downsample]; named_modules() yields the same order
+    assert len(mine) == len(want)
+    for a, b in zip(mine, want):
+        assert a[0] == b[0]
+        if a[0] == "conv":
+            assert a[1] == b[3] and a[2] == b[4] and a[3] == b[1][2] // b[2][2], (a, b)
+        elif a[0] == "bn":
+            assert a[1] == b[2] and a[2] == b[3], (a, b)
+        else:
+            assert a[1] == b[3], (a, b)
+    uniq = {id(p): p.numel() for p in m.backbone.parameters()}
+    assert sum(uniq.values()) == int(g["trunk_params"])
+    assert sum(p.numel() for p in m.fpn.parameters()) == int(g["fpn_params"])
+    assert sum(p.numel() for p in m.head.parameters()) == int(g["head_params_20cls"])
+
+
+@pytest.mark.gpu
+def test_plan_runs_the_recorded_layer_graph(golden):
+    """The compiled HIP plan at 1x3x512x512: one conv launch per recorded conv (+ one per downsample branch), with the recorded
+    (Cin, Cout, k, stride) and output pixel count; BatchNorms are folded into those launches; one max-pool step."""
+    from pytorch_object_detection_amd.model.od import HalfInvertedStageFCOS
+    g = golden("g11_trunk_dump")
+    torch.manual_seed(0)
+    m = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).eval().cuda()
+    plan = m.plan_for(torch.zeros(1, 3, 512, 512, device="cuda"))
+    names = plan.names
+    want = [o for o in _dump_ops(g) if o[0] in ("conv", "down")]
+    # plan order inside a block: conv1, conv2, downsample, conv3 (the residual must exist before conv3's epilogue adds it)
+    steps = [i for i, n in enumerate(names) if n.startswith("backbone.") and n != "backbone.maxpool"]
+    assert names[steps[0]] == "backbone.conv1" and sum(n == "backbone.maxpool" for n in names) == 1
+    by_name = {names[i]: plan.step_info[i] for i in steps[1:]}
+    assert len(by_name) == len(want) - 1
+    seq = want[1:]
+    # walk the table: blocks are conv1, conv2, conv3 [, down]
+    pos, layer_blocks = 0, (3, 4, 6, 3)
+    for L, nb in enumerate(layer_blocks, start=1):
+        for b in range(nb):
+            for cname in ("conv1", "conv2", "conv3") + (("downsample",) if b == 0 else ()):
+                o = seq[pos]; pos += 1
+                info = by_name[f"backbone.layer{L}.{b}.{cname}"]
+                if cname == "downsample":
+                    assert o[0] == "down"
+                    assert (info["Cin"], info["Cout"], info["k"]) == (o[1][1], o[2][1], 1) and info["stride"] == o[1][2] // o[2][2]
+                else:
+                    assert o[0] == "conv" and (info["Cin"], info["Cout"], info["k"]) == (o[3][0], o[3][1], o[3][2])
+                    assert info["stride"] == o[1][2] // o[2][2]
+                assert info["rows"] == o[2][2] * o[2][3]
+    assert pos == len(seq)
+    assert plan.step_flops[steps[0]] == 2 * want[0][5] * 147 // 147      # the stem: 2 x recorded multiply-adds
