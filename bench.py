@@ -387,6 +387,10 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
     ddp_kw = {"find": dict(find_unused_parameters=True),                                   # train.py:101 as written
               "static": dict(static_graph=True, gradient_as_bucket_view=True)}[os.environ.get("FD_BENCH_DDP", "static")]
     net = torch.nn.parallel.DistributedDataParallel(model, **ddp_kw) if use_dist else model
+    if use_dist:
+        # train.py:101-103: DDP wrap, then SyncBatchNorm.convert_sync_batchnorm -- the FPN's batch-statistic BatchNorms take their
+        # statistics over all ranks, on the HIP kernels with one fp64 all-reduce per layer and direction (train_ops._SyncBatchNormTrainRows)
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
     net.train()
     opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-3, momentum=0.9, weight_decay=1e-4)
     gen = torch.Generator().manual_seed(1000 + rank)
@@ -446,7 +450,8 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
         "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"HISFCOS-R50 train.py step, {batch} x {size}x{size} images/GPU, {ncls} classes, 8 GT boxes/image, "
-                               "HIP forward/backward/target/loss kernels" + (", DDP gradient all-reduce over RCCL" if use_dist else ""),
+                               "HIP forward/backward/target/loss kernels" + (", DDP gradient all-reduce + SyncBatchNorm statistics all-reduces over RCCL" if use_dist else ""),
+                   "batchnorm": "backbone frozen (eval); FPN BatchNorms on batch statistics" + (" over all ranks (SyncBatchNorm on the HIP statistics kernels)" if use_dist else ""),
                    "global_batch": batch * world, "parallelism": f"dp{world} (DistributedDataParallel)"},
         "roofline": {"bound": "mfma", "kernel": "conv_wgrad_kernel (head tower 3x3 weight gradient, 5 levels) + ordered slab reduce",
                      "instruction": "v_mfma_f32_32x32x2_f32", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,

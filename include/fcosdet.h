@@ -357,6 +357,25 @@ int32_t fd_upsample2x_bwd_nhwc(const float* dy, int32_t dy_cs, int32_t dy_co, fl
 int32_t fd_batchnorm_update_running(const void* gn_workspace, int64_t rows, int32_t C, float momentum, float eps,
                                     float* running_mean, float* running_var, fd_stream_t stream);
 
+/* nn.SyncBatchNorm in TRAINING mode (train.py:101-103: SyncBatchNorm.convert_sync_batchnorm after the DDP wrap; SURVEY 2.1 collective C3):
+ * batch statistics over ALL ranks' rows.  Forward and backward are each cut in two around ONE all-reduce that the CALLER issues
+ * (torch.distributed / RCCL; the library owns no communicator):
+ *   forward   phase 1: sums[2c], sums[2c+1] = this rank's sum x, sum x^2 of channel c (fp64, fixed order)      -> all-reduce(sums, rows)
+ *             phase 2: y = act((x - mean) * rstd * gamma + beta) with mean / rstd from the global sums and total_rows; (mean, rstd) stay in
+ *                      `workspace` (fd_groupnorm_workspace_bytes of {1 image of rows x 1, G = C}) for the backward and for
+ *                      fd_batchnorm_update_running(workspace, total_rows, ...)
+ *   backward  phase 1: sums[c], sums[C+c] = this rank's sum dz, sum dz * xhat (dz = dy * act'); dgamma / dbeta from THESE local sums
+ *                      (DDP averages them with the other gradients, as torch's SyncBatchNorm does)               -> all-reduce(sums)
+ *             phase 2: dx = rstd * (gamma * dz - mean_global(gamma dz) - xhat * mean_global(gamma dz xhat))
+ *   `workspace` of the backward: fd_groupnorm_bwd_workspace_bytes of the same segment table.  rows = this rank's batch*H*W. */
+int32_t fd_batchnorm_sync_fwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* gamma, const float* beta, float* y,
+                                   int32_t y_cs, int32_t y_co, int64_t rows, int32_t C, float eps, int32_t act, int32_t phase,
+                                   double* sums, double total_rows, void* workspace, fd_stream_t stream);
+int32_t fd_batchnorm_sync_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs, int32_t dy_co,
+                                   const float* gamma, const float* beta, float* dx, int32_t dx_cs, int32_t dx_co, float* dgamma,
+                                   float* dbeta, int64_t rows, int32_t C, float eps, int32_t act, int32_t phase, double* sums,
+                                   double total_rows, const void* fwd_workspace, void* workspace, fd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------- */
 /* Detection post-processing (reference model/modules/head.py:8-102,152-162, utill/utills.py:58-73)   */
 

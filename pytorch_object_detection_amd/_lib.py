@@ -119,6 +119,8 @@ _SIGS = {
     "fd_maxpool_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fd_upsample2x_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fd_batchnorm_update_running": (_I, [_P, _L, _I, _F, _F, _P, _P, _P]),
+    "fd_batchnorm_sync_fwd_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _L, _I, _F, _I, _I, _P, _D, _P, _P]),
+    "fd_batchnorm_sync_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _L, _I, _F, _I, _I, _P, _D, _P, _P, _P]),
     "fd_fcos_decode": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, C.POINTER(Segs), C.POINTER(_I), _P, _P, _P, _P]),
     "fd_topk_workspace_bytes": (_L, [_I, _I, _I]),
     "fd_fcos_topk": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),

@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ dx, int dx_cs, int dx_co, int C, int G, float eps,
                                                             int act, SegTab tab, const double* __restrict__ fpart,
-                                                            const double* __restrict__ img_sums) {
+                                                            const double* __restrict__ img_sums, double cnt_ovr) {
     __shared__ float s_mean[1024], s_rstd[1024], s_k1[1024], s_p[1024], s_q[1024];
     __shared__ double s_ga[1024], s_gb[1024];
     const int img = blockIdx.y;
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
         const int g = c / cg;
         double s1 = 0, s2 = 0;
         for (int k = 0; k < cg; ++k) { s1 += s_ga[g * cg + k]; s2 += s_gb[g * cg + k]; }
-        const double cnt = (double)HW * cg;
+        const double cnt = cnt_ovr > 0.0 ? cnt_ovr : (double)HW * cg;     // (synchronised BatchNorm: the GLOBAL row count)
         const double rstd = (double)s_rstd[c], mean = (double)s_mean[c];
         s_k1[c] = (float)(rstd * (double)gamma[c]);
         s_p[c] = (float)(-rstd * rstd * s2 / cnt);
@@ -985,7 +985,7 @@ extern "C" int32_t fd_groupnorm_act_bwd_nhwc(const float* x, int32_t x_cs, int32
     FD_CHECK_LAUNCH("fd_groupnorm_bwd (reduce)");
     const int ablk = max(1, min(imgs >= 16 ? 64 : 512, (maxhw * (C / 4) + 2047) / 2048));
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ablk, imgs), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, gamma, beta, dx,
-                       dx_cs, dx_co, C, G, eps, act, tab, gstat, (const double*)img_sums);
+                       dx_cs, dx_co, C, G, eps, act, tab, gstat, (const double*)img_sums, 0.0);
     FD_CHECK_LAUNCH("fd_groupnorm_bwd (apply)");
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)img_sums, dgamma, dbeta, C,
                        imgs);
@@ -1319,5 +1319,94 @@ extern "C" int32_t fd_batchnorm_update_running(const void* gn_workspace, int64_t
     hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gstat, running_mean, running_var, C,
                        (double)rows, momentum, eps);
     FD_CHECK_LAUNCH("fd_batchnorm_update_running");
+    return FD_OK;
+}
+
+// ---- nn.SyncBatchNorm (train.py:103 converts the model; collective C3 of SURVEY 2.1) on the same kernels.  Batch statistics
+// are sums over ALL ranks' rows, so forward and backward are cut in two around ONE all-reduce each, issued by the caller
+// (torch.distributed over RCCL): phase 1 leaves this rank's per-channel fp64 sums (fixed summation order) in `sums`,
+// the caller all-reduces them (and the row count), phase 2 finishes from the global sums.
+//   forward  sums = [sum x | sum x^2]            (2C doubles, channel-major pairs: sums[2c], sums[2c+1])
+//   backward sums = [sum dz | sum dz * xhat]     (2C doubles: sums[c], sums[C + c]), dz = dy * act'(z)
+__global__ __launch_bounds__(256) void bn_sync_sums_kernel(const double* __restrict__ part, int nchunk, int C, double* __restrict__ sums) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int k = 0; k < nchunk; ++k) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    sums[2 * c] = a; sums[2 * c + 1] = b;
+}
+
+__global__ __launch_bounds__(256) void bn_sync_finalize_kernel(const double* __restrict__ sums, double count, float eps, int C,
+                                                                double* __restrict__ gstat) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[2 * c] / count;
+    double var = sums[2 * c + 1] / count - mean * mean;
+    if (var < 0) var = 0;
+    gstat[2 * c] = mean;
+    gstat[2 * c + 1] = (double)(float)(1.0 / sqrt(var + (double)eps));        // rounded like gn_finalize_kernel
+}
+
+static bool bn_rows_ok(int64_t rows, int32_t C) { return rows >= 1 && rows < (1L << 31) && C >= 4 && C <= 1024 && C % 4 == 0 && 256 % (C / 4) == 0; }
+
+extern "C" int32_t fd_batchnorm_sync_fwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* gamma, const float* beta, float* y,
+                                              int32_t y_cs, int32_t y_co, int64_t rows, int32_t C, float eps, int32_t act, int32_t phase,
+                                              double* sums, double total_rows, void* workspace, fd_stream_t stream) {
+    FD_REQUIRE(bn_rows_ok(rows, C), FD_E_UNSUPPORTED, "fd_batchnorm_sync_fwd: rows=%ld C=%d unsupported (C/4 must divide 256, C <= 1024)", (long)rows, C);
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && sums && workspace && (phase == 1 || phase == 2), FD_E_INVAL, "fd_batchnorm_sync_fwd: bad argument");
+    SegTab tab;
+    tab = SegTab{};
+    tab.s.nseg = 1; tab.s.batch = 1; tab.s.H[0] = (int)rows; tab.s.W[0] = 1; tab.s.m_start[0] = 0; tab.s.m_start[1] = (int)rows;
+    const int nchunk = (int)min((int64_t)GN_MAXCHUNK, (rows + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+    double* gstat = (double*)workspace + (long)GN_MAXCHUNK * C * 2;          // where fd_groupnorm_act_nhwc (imgs = 1, G = C) leaves (mean, rstd)
+    if (phase == 1) {
+        hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, 1), dim3(256), 0, st, x, x_cs, x_co, C, C, tab, (double*)workspace);
+        FD_CHECK_LAUNCH("fd_batchnorm_sync_fwd (partial)");
+        hipLaunchKernelGGL(bn_sync_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)workspace, nchunk, C, sums);
+        FD_CHECK_LAUNCH("fd_batchnorm_sync_fwd (sums)");
+        return FD_OK;
+    }
+    FD_REQUIRE(view_ok(y, y_cs, y_co, C) && gamma && beta && total_rows >= (double)rows, FD_E_INVAL, "fd_batchnorm_sync_fwd: phase 2 needs y, gamma, beta and the global row count");
+    hipLaunchKernelGGL(bn_sync_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)sums, total_rows, eps, C, gstat);
+    FD_CHECK_LAUNCH("fd_batchnorm_sync_fwd (finalize)");
+    const int ablk = (int)max((int64_t)1, min((int64_t)512, (rows * (C / 4) + 2047) / 2048));
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, 1), dim3(256), 0, st, x, x_cs, x_co, gamma, beta, y, y_cs, y_co, C, C, eps, act, tab,
+                       (const double*)gstat);
+    FD_CHECK_LAUNCH("fd_batchnorm_sync_fwd (apply)");
+    return FD_OK;
+}
+
+extern "C" int32_t fd_batchnorm_sync_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs, int32_t dy_co,
+                                              const float* gamma, const float* beta, float* dx, int32_t dx_cs, int32_t dx_co, float* dgamma,
+                                              float* dbeta, int64_t rows, int32_t C, float eps, int32_t act, int32_t phase, double* sums,
+                                              double total_rows, const void* fwd_workspace, void* workspace, fd_stream_t stream) {
+    FD_REQUIRE(bn_rows_ok(rows, C), FD_E_UNSUPPORTED, "fd_batchnorm_sync_bwd: rows=%ld C=%d unsupported", (long)rows, C);
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(dy, dy_cs, dy_co, C) && gamma && beta && sums && fwd_workspace && (phase == 1 || phase == 2),
+               FD_E_INVAL, "fd_batchnorm_sync_bwd: bad argument");
+    FD_REQUIRE(act == FD_ACT_NONE || act == FD_ACT_RELU || act == FD_ACT_SILU, FD_E_UNSUPPORTED, "fd_batchnorm_sync_bwd: activation %d has no backward", act);
+    SegTab tab;
+    tab = SegTab{};
+    tab.s.nseg = 1; tab.s.batch = 1; tab.s.H[0] = (int)rows; tab.s.W[0] = 1; tab.s.m_start[0] = 0; tab.s.m_start[1] = (int)rows;
+    const int nchunk = (int)min((int64_t)GN_MAXCHUNK, (rows + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+    const double* gstat = (const double*)fwd_workspace + (long)GN_MAXCHUNK * C * 2;   // GLOBAL (mean, rstd) left by the forward's phase 2
+    if (phase == 1) {
+        FD_REQUIRE(workspace && dgamma && dbeta, FD_E_INVAL, "fd_batchnorm_sync_bwd: phase 1 needs the workspace, dgamma, dbeta");
+        hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, 1), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, gamma, beta, C, C, eps, act, tab,
+                           gstat, (double*)workspace);
+        FD_CHECK_LAUNCH("fd_batchnorm_sync_bwd (partial)");
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, (const double*)workspace, sums, C, tab);
+        FD_CHECK_LAUNCH("fd_batchnorm_sync_bwd (reduce)");
+        // the affine gradients come from THIS rank's sums (DistributedDataParallel averages them like every other gradient)
+        hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)sums, dgamma, dbeta, C, 1);
+        FD_CHECK_LAUNCH("fd_batchnorm_sync_bwd (params)");
+        return FD_OK;
+    }
+    FD_REQUIRE(view_ok(dx, dx_cs, dx_co, C) && total_rows >= (double)rows, FD_E_INVAL, "fd_batchnorm_sync_bwd: phase 2 needs dx and the global row count");
+    const int ablk = (int)max((int64_t)1, min((int64_t)512, (rows * (C / 4) + 2047) / 2048));
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ablk, 1), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, gamma, beta, dx, dx_cs, dx_co, C, C, eps,
+                       act, tab, gstat, (const double*)sums, total_rows);
+    FD_CHECK_LAUNCH("fd_batchnorm_sync_bwd (apply)");
     return FD_OK;
 }

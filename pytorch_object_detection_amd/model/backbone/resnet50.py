@@ -65,6 +65,8 @@ def trunk_train_forward(trunk: nn.Module, x: torch.Tensor):
     if stem_is_frozen(trunk, x):
         x = stem_frozen(trunk, x)
     else:                                                     # trainable 7x7 stem (Cin = 3): stock ops
+        from ...train_ops import stock_fallback
+        stock_fallback("a trainable / un-frozen 7x7 stem (Cin = 3)")
         x = F.max_pool2d(F.relu(trunk.bn1(trunk.conv1(x))), 3, 2, 1)
     feats = []
     for li in (1, 2, 3, 4):
@@ -95,7 +97,7 @@ class ResNet50v2(nn.Module):
 
     def freeze_bn(self):
         for layer in self.modules():
-            if isinstance(layer, nn.BatchNorm2d):
+            if isinstance(layer, (nn.BatchNorm2d, nn.SyncBatchNorm)):
                 layer.eval()
 
     def freeze_stages(self, stage: int):
@@ -131,7 +133,7 @@ class ResNet50(nn.Module):
 
     def freeze_bn(self):
         for layer in self.modules():
-            if isinstance(layer, nn.BatchNorm2d):
+            if isinstance(layer, (nn.BatchNorm2d, nn.SyncBatchNorm)):
                 layer.eval()
 
     def freeze_stages(self, stage: int):

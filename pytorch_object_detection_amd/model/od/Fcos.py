@@ -105,6 +105,7 @@ class HeadFCOS(PlannedModule):
         return cls_l, cnt_l, reg_l
 
     def _train_forward_stock(self, inputs):
+        T.stock_fallback("the HeadFCOS GroupNorm layers (widths outside the rows kernels)")
         cls_l, cnt_l, reg_l = [], [], []
         for i, f in enumerate(inputs):
             c, r = f, f

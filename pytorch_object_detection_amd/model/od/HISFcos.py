@@ -69,6 +69,7 @@ class HisBlock(nn.Module):
             out = self.train_forward_rows(T.to_rows(x), Segs.make(B, [(H, W)]))
             if out is not None:
                 return T.from_rows(out, B, H, W)
+        T.stock_fallback("a HisBlock (SE / depthwise / BatchNorm configuration outside the rows kernels)")
         if T.covered(self.conv1, self.bn1, x) and T.covered(self.conv2, None, x) and self.conv1.bias is not None:
             # conv1 (+ frozen bn1) and conv2 read the same map: one 2*half-wide launch forward, one data gradient (no gradient
             # add for x) and one weight gradient backward; the halves are channel views of its output
@@ -138,6 +139,7 @@ class HalfInvertedStageFPN(PlannedModule):
         out = self.train_forward_rows(x)
         if out is not None:
             return out
+        T.stock_fallback("the HalfInvertedStageFPN glue (upsample / max-pool adds, SE) outside the rows kernels")
         c3, c4, c5 = x
         up = lambda t: F.interpolate(t, scale_factor=2.0, mode="nearest")  # noqa: E731
         down = lambda t: F.max_pool2d(t, 2, 2)  # noqa: E731
@@ -219,6 +221,7 @@ class HISFCOSHead(PlannedModule):
         return cls_l, cnt_l, reg_l
 
     def _train_forward_stock(self, inputs):
+        T.stock_fallback("the HISFCOSHead GroupNorm / depthwise layers (widths outside the rows kernels)")
         cls_l, cnt_l, reg_l = [], [], []
         for i, f in enumerate(inputs):
             h = F.silu(self.gn2(tconv(self.dw1, F.relu(self.gn1(tconv(self.pw1, f))))))

@@ -165,7 +165,7 @@ class PlannedModule(nn.Module):
         if mode and getattr(self, "backbone_freeze", False):
             root = self if self.freeze_all_bn else getattr(self, "backbone", None)
             for m in (root.modules() if root is not None else ()):
-                if isinstance(m, nn.BatchNorm2d):
+                if isinstance(m, (nn.BatchNorm2d, nn.SyncBatchNorm)):
                     m.eval()
         return self
 

@@ -36,7 +36,19 @@ _fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _bwd = torch.amp.custom_bwd(device_type="cuda")
 
 _STOCK = os.environ.get("FD_TRAIN_STOCK_CONV") == "1"   # diagnostic: route every layer to the stock ops (timing comparisons)
-STATS = {"cl_copies": 0}                                 # activation-sized layout copies made on entry (should stay 0)
+STATS = {"cl_copies": 0, "stock_fallbacks": 0}           # activation-sized layout copies made on entry / stock-op fallbacks taken (both should stay 0)
+# FD_STRICT=1 (the test suite's default, tests/conftest.py): a layer of the TRAINING forward / backward that the HIP kernels do not cover
+# raises FdError instead of silently running on stock PyTorch-ROCm ops (MIOpen convolutions, native batch / group norm).  Off by
+# default so that exotic user configurations (a trainable 7x7 stem, odd widths) still train; the explicit diagnostic mode
+# FD_TRAIN_STOCK_CONV=1 is exempt.
+STRICT = os.environ.get("FD_STRICT", "0") == "1"
+
+
+def stock_fallback(what: str) -> None:
+    """Called on every path that is about to run a conv / norm of the training step on stock ops."""
+    STATS["stock_fallbacks"] = STATS.get("stock_fallbacks", 0) + 1
+    if STRICT and not _STOCK:
+        raise FdError(f"FD_STRICT=1: {what} is not covered by the HIP kernels and would run on stock PyTorch-ROCm ops")
 
 
 # ----------------------------------------------------------------------------------------------- layout helpers
@@ -121,8 +133,11 @@ def _gn_ok(gn: nn.Module, x: torch.Tensor) -> bool:
     return Cc % 4 == 0 and Cc <= 1024 and 256 % (Cc // 4) == 0 and Cc % gn.num_groups == 0
 
 
+BN_TYPES = (nn.BatchNorm2d, nn.SyncBatchNorm)     # SyncBatchNorm.convert_sync_batchnorm(model) (train.py:103) swaps the class, not the tensors
+
+
 def bn_is_frozen(bn: Optional[nn.Module]) -> bool:
-    return (isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.track_running_stats and bn.affine
+    return (isinstance(bn, BN_TYPES) and not bn.training and bn.track_running_stats and bn.affine
             and not bn.weight.requires_grad and not bn.bias.requires_grad)
 
 
@@ -346,6 +361,7 @@ class _ConvRows(torch.autograd.Function):
             elif segs.nseg == 1 and stride > 1 and dil == 1 and (gx := _strided_dgrad(g, weight, scale, segs, k, stride, pad)) is not None:
                 pass                                   # strided layer: one exact-FLOP launch per parity class (ops.conv_dgrad_strided)
             elif segs.nseg == 1:  # what is left (narrow Cout, dilated + strided): stock op for the data gradient
+                stock_fallback(f"the data gradient of a {k}x{k} stride-{stride} conv with Cout={Cout}")
                 weff = weight.detach() if scale is None else weight.detach() * scale.view(-1, 1, 1, 1)
                 B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
                 gx4 = torch.ops.aten.convolution_backward(from_rows(g, B, Ho, Wo), from_rows(x, B, H, W), weff, None,
@@ -448,6 +464,7 @@ class _BottleneckRows(torch.autograd.Function):
         elif (g1 := _strided_dgrad(g2, w2, s2, segs, 3, stride, 1, res=y1, res_mask=True)) is not None:
             pass    # strided 3x3: four parity-class launches on the conv kernel, ReLU mask of y1 applied in their epilogues
         else:   # strided 3x3: stock data gradient, masked separately
+            stock_fallback("the data gradient of a bottleneck's strided 3x3 conv")
             B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
             g1 = torch.ops.aten.convolution_backward(from_rows(g2, B, Ho, Wo), from_rows(y1, B, H, W), w2.detach() * s2.view(-1, 1, 1, 1),
                                                      None, [stride, stride], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
@@ -465,6 +482,7 @@ class _BottleneckRows(torch.autograd.Function):
             elif (gid := _strided_dgrad(g, wd, sd, segs, 1, stride, 0)) is not None:
                 pass    # 1x1 stride-2 downsample: the (0, 0) parity class is a plain GEMM scattered into a zeroed dX
             else:
+                stock_fallback("the data gradient of a bottleneck's strided downsample conv")
                 B, (H, W), (Ho, Wo) = segs.batch, segs.level_hw()[0], so.level_hw()[0]
                 gid = to_rows(torch.ops.aten.convolution_backward(from_rows(g, B, Ho, Wo), from_rows(x, B, H, W),
                                                                    wd.detach() * sd.view(-1, 1, 1, 1), None, [stride, stride], [0, 0],
@@ -730,14 +748,85 @@ class _BatchNormTrainRows(torch.autograd.Function):
         return gx, dgamma, dbeta, None, None, None, None, None
 
 
+class _SyncBatchNormTrainRows(torch.autograd.Function):
+    """nn.SyncBatchNorm in TRAINING mode + ReLU / SiLU on rows (train.py:101-103 converts the model after the DDP wrap): batch
+    statistics over ALL ranks' rows.  The same HIP kernels as _BatchNormTrainRows, cut in two around ONE all-reduce per direction
+    (fd_batchnorm_sync_fwd_nhwc / _bwd_nhwc): forward all-reduces the fp64 (sum x, sum x^2) of every channel plus the row count
+    -- one flat [2C + 1] buffer --, backward the fp64 (sum dz, sum dz * xhat).  Like torch's SyncBatchNorm the affine gradients come
+    from the local sums (DDP averages them)."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, gamma, beta, rmean, rvar, momentum, eps, act, group):
+        import ctypes as C
+        import torch.distributed as dist
+        x = x.contiguous()
+        rows, Cc = x.shape
+        segs = Segs.make(1, [(rows, 1)])
+        y = torch.empty_like(x)
+        ws = ops.groupnorm_workspace(segs, Cc, x.device)
+        gm, bt = gamma.detach().contiguous(), beta.detach().contiguous()
+        buf = torch.empty(2 * Cc + 1, dtype=torch.float64, device=x.device)
+        fn, st = _lib.lib().fd_batchnorm_sync_fwd_nhwc, ops._stream()
+        ops.check(fn(x.data_ptr(), Cc, 0, None, None, None, 0, 0, rows, Cc, eps, act, 1, buf.data_ptr(), 0.0, ws.data_ptr(), st),
+                  "fd_batchnorm_sync_fwd_nhwc (stats)")
+        buf[2 * Cc] = float(rows)
+        dist.all_reduce(buf, group=group)                       # THE forward collective of this layer (C3)
+        total = float(rows) * dist.get_world_size(group) if _EVEN_SHARDS else float(buf[2 * Cc].item())
+        ops.check(fn(x.data_ptr(), Cc, 0, gm.data_ptr(), bt.data_ptr(), y.data_ptr(), Cc, 0, rows, Cc, eps, act, 2, buf.data_ptr(),
+                     C.c_double(total), ws.data_ptr(), st), "fd_batchnorm_sync_fwd_nhwc (apply)")
+        if rmean is not None and momentum is not None:
+            ops.batchnorm_update_running(ws, int(total), Cc, momentum, eps, rmean, rvar)
+        ctx.save_for_backward(x, gm, bt, ws)
+        ctx.geom = (eps, act, group, total)
+        return y
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, gy):
+        import ctypes as C
+        import torch.distributed as dist
+        x, gm, bt, ws = ctx.saved_tensors
+        eps, act, group, total = ctx.geom
+        rows, Cc = x.shape
+        g = gy.contiguous()
+        gx = torch.empty_like(x)
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        segs = Segs.make(1, [(rows, 1)])
+        nb = _lib.lib().fd_groupnorm_bwd_workspace_bytes(C.byref(segs), Cc)
+        bws = torch.empty(nb // 8, dtype=torch.float64, device=x.device)
+        sums = torch.empty(2 * Cc, dtype=torch.float64, device=x.device)
+        fn, st = _lib.lib().fd_batchnorm_sync_bwd_nhwc, ops._stream()
+        ops.check(fn(x.data_ptr(), Cc, 0, g.data_ptr(), Cc, 0, gm.data_ptr(), bt.data_ptr(), None, 0, 0, dgamma.data_ptr(), dbeta.data_ptr(),
+                     rows, Cc, eps, act, 1, sums.data_ptr(), 0.0, ws.data_ptr(), bws.data_ptr(), st), "fd_batchnorm_sync_bwd_nhwc (sums)")
+        dist.all_reduce(sums, group=group)                      # THE backward collective of this layer
+        ops.check(fn(x.data_ptr(), Cc, 0, g.data_ptr(), Cc, 0, gm.data_ptr(), bt.data_ptr(), gx.data_ptr(), Cc, 0, None, None,
+                     rows, Cc, eps, act, 2, sums.data_ptr(), C.c_double(total), ws.data_ptr(), None, st), "fd_batchnorm_sync_bwd_nhwc (apply)")
+        return gx, dgamma, dbeta, None, None, None, None, None, None
+
+
+_EVEN_SHARDS = True     # every rank holds the same number of rows per layer (DDP with equal per-rank batches, train.py); False: read the
+                        # all-reduced row count back from the device (one host sync per SyncBatchNorm layer)
+
+
 def _bn_train_ok(bn: nn.Module, x: torch.Tensor) -> bool:
     Cc = getattr(bn, "num_features", 0)
-    return (not _STOCK and isinstance(bn, nn.BatchNorm2d) and bn.training and bn.affine and bn.track_running_stats
+    return (not _STOCK and isinstance(bn, BN_TYPES) and bn.training and bn.affine and bn.track_running_stats
             and bn.momentum is not None and Cc % 4 == 0 and Cc <= 1024 and 256 % (Cc // 4) == 0 and _f32(x))
 
 
-def batchnorm_train_rows(bn: nn.BatchNorm2d, x: torch.Tensor, act: int = ACT_NONE) -> torch.Tensor:
-    """act(bn(x)) with batch statistics on rows; bn.running_mean / running_var are updated in place (check with _bn_train_ok)."""
+def batchnorm_train_rows(bn: nn.Module, x: torch.Tensor, act: int = ACT_NONE) -> torch.Tensor:
+    """act(bn(x)) with batch statistics on rows; bn.running_mean / running_var / num_batches_tracked are updated in place like
+    nn.BatchNorm2d does (check with _bn_train_ok).  An nn.SyncBatchNorm in an initialised process group of more than one rank
+    takes its statistics over all ranks (_SyncBatchNormTrainRows: one all-reduce forward, one backward)."""
+    import torch.distributed as dist
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+        group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+        if dist.get_world_size(group) > 1:
+            return _SyncBatchNormTrainRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act, group)
     return _BatchNormTrainRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act)
 
 
@@ -781,8 +870,10 @@ def conv_bn_act(m: nn.Conv2d, bn: Optional[nn.Module], x: torch.Tensor, act: int
             return from_rows(y, B, (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1)
         return from_rows(dw_rows(m, to_rows(x), segs, bn, act), B, H, W)
     if not _STOCK and bn is not None and not bn_is_frozen(bn) and covered(m, None, x):
+        stock_fallback(f"{type(bn).__name__}({getattr(bn, 'num_features', '?')}) in training mode behind a conv")
         y = bn(conv_bn_act(m, None, x))                     # BN in training mode: conv on HIP, statistics stock
     else:                                                   # documented stock-op fallbacks of the TRAINING forward (module docstring)
+        stock_fallback(f"conv {tuple(m.weight.shape)} stride {m.stride[0]} groups {m.groups}" + (f" + {type(bn).__name__}" if bn is not None else ""))
         y = nn.Conv2d.forward(m, x) if bn is None else bn(nn.Conv2d.forward(m, x))
     if residual is not None:
         y = y + residual

@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("FD_STRICT", "1")     # training forward / backward: a layer the HIP kernels do not cover raises instead of running on stock ops
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

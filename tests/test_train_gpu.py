@@ -169,10 +169,15 @@ def test_pyramid_head_matches_per_level_head(which):
             torch.nn.init.normal_(p, std=(2.0 / (p.shape[1] * p.shape[2] * p.shape[3])) ** 0.5)
     feats = [torch.randn(2, 64, s, s + 1, device=DEV).to(memory_format=torch.channels_last) for s in (12, 6, 3, 2, 1)]
     res = []
+    from pytorch_object_detection_amd import train_ops
     for fn in (head.train_forward, head._train_forward_stock):
         head.zero_grad()
         xs = [f.clone().requires_grad_(True) for f in feats]
-        out = fn(xs)
+        train_ops._STOCK = fn.__name__ == "_train_forward_stock"     # the explicit stock-op mode (exempt from FD_STRICT)
+        try:
+            out = fn(xs)
+        finally:
+            train_ops._STOCK = False
         torch.manual_seed(5)
         loss = sum((t * torch.randn(t.shape, device=DEV)).sum() for lst in out for t in lst)
         loss.backward()
