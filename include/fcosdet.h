@@ -390,7 +390,9 @@ int32_t fd_fcos_decode(const float* cls, int32_t cls_cs, int32_t cls_co, const f
                        float* boxes, fd_stream_t stream);
 
 /* torch.topk(score, K, dim=1, largest=True, sorted=True) + gathers (head.py:69-80).  Ties: lower
- * location index first.  Outputs [N][K]; top_idx (int32 location index) may be NULL. */
+ * location index first.  Outputs [N][K]; top_idx (int32 location index) may be NULL.  K <= 1024 runs in LDS / registers with no
+ * workspace (fd_topk_workspace_bytes = 0); any larger K <= L (FCOSHead accepts any max_detection_box, head.py:41-50) sorts its candidate
+ * list in `workspace` (fd_topk_workspace_bytes bytes, 8-byte aligned). */
 int64_t fd_topk_workspace_bytes(int32_t N, int32_t L, int32_t K);
 int32_t fd_fcos_topk(const float* scores, const int32_t* classes, const float* boxes, int32_t N, int32_t L,
                      int32_t K, float* top_scores, int64_t* top_classes, float* top_boxes, int32_t* top_idx,
@@ -400,8 +402,9 @@ int32_t fd_fcos_topk(const float* scores, const int32_t* classes, const float* b
  * (FCOSHead.post_process, head.py:84-102).  Input rows must be score-descending (fd_fcos_topk
  * output).  Greedy rule: suppress j when (double)iou(i,j) > iou_thr, iou on class-offset boxes
  * without the "+1" pixel convention.  Outputs padded to [N][K] (rows >= counts[n] zero-filled),
- * keep_idx[n][r] = index into the K input rows.  K <= 1024.  Two launches: the suppression bitmask is built by
- * K/64 workgroups per image into `workspace` (fd_nms_workspace_bytes), one workgroup per image then scans it.
+ * keep_idx[n][r] = index into the K input rows.  K <= 1024: two launches, the suppression bitmask is built by
+ * K/64 workgroups per image into `workspace` (fd_nms_workspace_bytes), one workgroup per image then scans it in LDS.  K > 1024
+ * (up to 262144): the same rule with the class-offset boxes and bitmask rows of ceil(K/64) words in the workspace (three launches).
  * Outputs must not alias inputs. */
 int64_t fd_nms_workspace_bytes(int32_t N, int32_t K);
 int32_t fd_batched_nms(const float* scores, const int64_t* classes, const float* boxes, int32_t N, int32_t K,

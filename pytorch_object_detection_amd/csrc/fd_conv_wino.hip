@@ -177,14 +177,20 @@ __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kern
         tr[0] = d0_ - d2_; tr[1] = d1_ + d2_; tr[2] = d2_ - d1_; tr[3] = d1_ - d3_;                                               \
     } while (0)
     // column pass across the quad + LDS write of output column j: v = ss * t + so * t[lane {2, 2, 1, 1} of the quad] (v_fmac with DPP)
+    // gfx9 hazard: a VALU write of a VGPR followed by a DPP read of it needs 2 wait states, and the hazard recogniser does not see into
+    // inline asm.  The four DPP operations of one output column are ONE asm statement that opens with `s_nop 1`: whatever the compiler
+    // does to tr[] before the statement (the row pass itself, or a register copy it decides to insert), the wait states sit between that
+    // write and the first DPP read, independent of how the surrounding code is scheduled.
     auto col_store = [&](int stage, int j) {
-        f32x4 v;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float r = tr[j][c];
-            asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(tr[j][c]), "v"(so));
-            v[c] = r;
-        }
+        float r0 = tr[j][0], r1 = tr[j][1], r2 = tr[j][2], r3 = tr[j][3];
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f32_dpp %0, %4, %8 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %1, %5, %8 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %2, %6, %8 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %3, %7, %8 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
+                     : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)
+                     : "v"(tr[j][0]), "v"(tr[j][1]), "v"(tr[j][2]), "v"(tr[j][3]), "v"(so));
+        const f32x4 v = {r0, r1, r2, r3};
         *reinterpret_cast<f32x4*>(Vs + stage * STAGE + v_wr + j * PLANE) = v;
     };
     // one iteration: MFMAs of chunk cc (LDS stage cc & 1), transform of chunk cc + 1 (fetched an iteration ago into pr[SLOT ^ 1]) into the
@@ -224,7 +230,6 @@ __global__ __launch_bounds__(NCH * 128, NCH == 2 ? 2 : 1) void conv3x3_wino_kern
     for (int fi = 0; fi < 8; ++fi) load_u(c0, fi);
     if (WINO_LD_ON(0)) {
         WINO_ROW_PASS(0);
-        asm volatile("s_nop 4");      // (VALU write -> DPP read of the same VGPR needs 2 wait states; the hazard recogniser does not see into asm)
 #pragma unroll
         for (int j = 0; j < 4; ++j) col_store(0, j);
     }

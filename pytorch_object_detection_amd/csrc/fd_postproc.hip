@@ -414,16 +414,135 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ sc
     }
 }
 
-extern "C" int64_t fd_topk_workspace_bytes(int32_t, int32_t, int32_t) { return 0; }
+// ---- K > 1024 (FCOSHead(max_detection_box > 1024): the reference accepts any value, model/modules/head.py:41-50): the same radix
+// select and the same order (score descending, ties by lower index), with the candidate list and its bitonic sort in a global
+// scratch of Kpad = next power of two >= K entries per image instead of LDS / registers.  One 1024-thread workgroup per image.
+__global__ __launch_bounds__(1024) void topk_large_kernel(const float* __restrict__ scores, const int* __restrict__ classes,
+                                                           const float* __restrict__ boxes, int L, int K, int Kpad,
+                                                           unsigned long long* __restrict__ cand_ws, float* top_scores,
+                                                           long long* top_classes, float* top_boxes, int* top_idx) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned sh_prefix, sh_need, sh_gt, sh_eqbase;
+    __shared__ unsigned wave_cnt[16];
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* s = scores + (long)n * L;
+    unsigned long long* cand = cand_ws + (long)n * Kpad;
+    const int nE = (L + 1023) >> 10;
+
+    unsigned prefix = 0, maskbits = 0, need = (unsigned)K;
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        const int sh = shifts[pass];
+        const unsigned dmask = (1u << widths[pass]) - 1u;
+        hist[tid] = 0; hist[tid + 1024] = 0;
+        __syncthreads();
+        for (int i = tid; i < L; i += 1024) {
+            const unsigned kk = fd_order_key(s[i]);
+            if ((kk & maskbits) == prefix) atomicAdd(&hist[(kk >> sh) & dmask], 1u);
+        }
+        __syncthreads();
+        const int d0 = 2047 - 2 * tid;
+        const unsigned h0 = hist[d0], h1 = hist[d0 - 1];
+        unsigned incl = h0 + h1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        unsigned before = 0;
+        for (int w = 0; w < wv; ++w) before += wsum[w];
+        const unsigned excl = before + incl - (h0 + h1);
+        if (excl < need && need <= excl + h0 + h1) {
+            if (need <= excl + h0) { sh_prefix = prefix | ((unsigned)d0 << sh); sh_need = need - excl; }
+            else { sh_prefix = prefix | ((unsigned)(d0 - 1) << sh); sh_need = need - excl - h0; }
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        need = sh_need;
+        maskbits |= dmask << sh;
+        __syncthreads();
+    }
+    const unsigned T = prefix;
+    const unsigned n_gt = (unsigned)K - need;
+
+    for (int i = tid; i < Kpad; i += 1024) cand[i] = 0ull;
+    if (tid == 0) { sh_gt = 0; sh_eqbase = 0; }
+    __syncthreads();
+    for (int e = 0; e < nE; ++e) {
+        const int i = e * 1024 + tid;
+        unsigned kk = 0;
+        bool gt = false, eq = false;
+        if (i < L) { kk = fd_order_key(s[i]); gt = kk > T; eq = kk == T; }
+        if (gt) {
+            const unsigned slot = atomicAdd(&sh_gt, 1u);
+            cand[slot] = ((unsigned long long)kk << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        }
+        const unsigned long long bal = __ballot(eq);
+        if (lane == 0) wave_cnt[wv] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = sh_eqbase;
+        for (int w = 0; w < wv; ++w) before += wave_cnt[w];
+        const unsigned rank = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        if (eq && rank < need)
+            cand[n_gt + rank] = ((unsigned long long)kk << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        __syncthreads();
+        if (tid == 0) {
+            unsigned tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wave_cnt[w];
+            sh_eqbase += tot;
+        }
+        __syncthreads();
+    }
+    // bitonic sort, descending, in the global scratch (writes of a workgroup are visible to it after its barrier)
+    for (int k = 2; k <= Kpad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < Kpad; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long a = cand[i], b = cand[p];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { cand[i] = b; cand[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int t = tid; t < K; t += 1024) {
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(cand[t] & 0xFFFFFFFFull);
+        const long o = (long)n * K + t;
+        const long src = (long)n * L + idx;
+        top_scores[o] = s[idx];
+        top_classes[o] = (long long)classes[src];
+        reinterpret_cast<float4*>(top_boxes)[o] = reinterpret_cast<const float4*>(boxes)[src];
+        if (top_idx) top_idx[o] = (int)idx;
+    }
+}
+
+static int topk_kpad(int K) { int p = 1; while (p < K) p <<= 1; return p; }
+
+extern "C" int64_t fd_topk_workspace_bytes(int32_t N, int32_t L, int32_t K) {
+    if (N < 1 || L < 1 || K < 1 || K > L) return -1;
+    return K <= 1024 ? 0 : (int64_t)N * topk_kpad(K) * (int64_t)sizeof(unsigned long long);
+}
 
 extern "C" int32_t fd_fcos_topk(const float* scores, const int32_t* classes, const float* boxes, int32_t N,
                                 int32_t L, int32_t K, float* top_scores, int64_t* top_classes, float* top_boxes,
-                                int32_t* top_idx, void*, fd_stream_t stream) {
+                                int32_t* top_idx, void* workspace, fd_stream_t stream) {
     FD_REQUIRE(scores && classes && boxes && top_scores && top_classes && top_boxes, FD_E_INVAL,
                "fd_fcos_topk: null pointer");
     FD_REQUIRE(N >= 1 && L >= 1 && K >= 1 && K <= L, FD_E_INVAL, "fd_fcos_topk: need 1 <= K <= L (K=%d L=%d)", K, L);
-    FD_REQUIRE(K <= 1024, FD_E_UNSUPPORTED, "fd_fcos_topk: K=%d > 1024 not supported", K);
     FD_REQUIRE((((uintptr_t)boxes | (uintptr_t)top_boxes) & 15) == 0, FD_E_INVAL, "fd_fcos_topk: boxes not 16-byte aligned");
+    if (K > 1024) {
+        FD_REQUIRE(workspace && ((uintptr_t)workspace & 7) == 0, FD_E_INVAL, "fd_fcos_topk: K=%d > 1024 needs a workspace of fd_topk_workspace_bytes() bytes", K);
+        hipLaunchKernelGGL(topk_large_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, scores, classes, boxes, L, K, topk_kpad(K),
+                           (unsigned long long*)workspace, top_scores, (long long*)top_classes, top_boxes, top_idx);
+        FD_CHECK_LAUNCH("fd_fcos_topk (K > 1024)");
+        return FD_OK;
+    }
     if (L <= TOPK_MAXE * 1024)
         hipLaunchKernelGGL(topk_kernel<true>, dim3(N), dim3(1024), 0, (hipStream_t)stream, scores, classes, boxes, L, K,
                            top_scores, (long long*)top_classes, top_boxes, top_idx);
@@ -677,9 +796,167 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float* __restrict_
     if (tid == 0) counts[img] = total;
 }
 
+// ---- K > 1024: the same greedy rule with everything that lived in LDS moved to a global workspace.  Per image:
+//   prep   valid prefix n, boxes.max(), class-offset boxes + areas                           -> ws.box / ws.area / ws.n
+//   mask   (row block, image): rows x words of the upper-triangular suppression bitmask        -> ws.mask [K][nwK]
+//   scan   one workgroup: per 64-box block wave 0 resolves the in-block chain on the diagonal word, then the 16 waves OR the kept
+//          rows into the later words of `remv` (LDS, nwK <= NMSL_MAXNW words)
+#define NMSL_MAXNW 4096            /* K <= 262144 */
+struct NmsLargeLayout { long mask_off, box_off, area_off, n_off, per_img; int nw; };
+static NmsLargeLayout nms_large_layout(int K) {
+    NmsLargeLayout l;
+    l.nw = (K + 63) / 64;
+    l.mask_off = 0;
+    l.box_off = (long)K * l.nw * 8;
+    l.area_off = l.box_off + (long)K * 16;
+    l.n_off = l.area_off + (((long)K * 4 + 15) & ~15L);
+    l.per_img = l.n_off + 16;
+    return l;
+}
+
+__global__ __launch_bounds__(1024) void nms_large_prep_kernel(const float* __restrict__ scores, const long long* __restrict__ classes,
+                                                               const float* __restrict__ boxes, int K, float score_thr, char* __restrict__ ws,
+                                                               NmsLargeLayout lay) {
+    __shared__ float red[16];
+    __shared__ int n_valid;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const long base = (long)img * K;
+    char* w = ws + (long)img * lay.per_img;
+    float4* obox = reinterpret_cast<float4*>(w + lay.box_off);
+    float* oarea = reinterpret_cast<float*>(w + lay.area_off);
+    if (tid == 0) n_valid = 0;
+    if (tid < 16) red[tid] = -INFINITY;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = tid; i < K; i += 1024) cnt += (scores[base + i] >= score_thr) ? 1 : 0;
+    if (cnt) atomicAdd(&n_valid, cnt);
+    __syncthreads();
+    const int n = n_valid;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += 1024) {
+        const float4 bx = reinterpret_cast<const float4*>(boxes)[base + i];
+        mx = fmaxf(mx, fmaxf(fmaxf(bx.x, bx.y), fmaxf(bx.z, bx.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    float maxc = red[0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) maxc = fmaxf(maxc, red[q]);
+    for (int i = tid; i < n; i += 1024) {
+        const float4 bx = reinterpret_cast<const float4*>(boxes)[base + i];
+        const float off = (float)classes[base + i] * (maxc + 1.0f);
+        const float4 ob = make_float4(bx.x + off, bx.y + off, bx.z + off, bx.w + off);
+        obox[i] = ob;
+        oarea[i] = (ob.z - ob.x) * (ob.w - ob.y);
+    }
+    if (tid == 0) *reinterpret_cast<int*>(w + lay.n_off) = n;
+}
+
+__global__ __launch_bounds__(256) void nms_large_mask_kernel(double iou_thr, char* __restrict__ ws, NmsLargeLayout lay) {
+    const int img = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x;
+    char* w = ws + (long)img * lay.per_img;
+    const int n = *reinterpret_cast<const int*>(w + lay.n_off);
+    const int r0 = rb << 6;
+    if (r0 >= n) return;
+    const float4* box = reinterpret_cast<const float4*>(w + lay.box_off);
+    const float* area = reinterpret_cast<const float*>(w + lay.area_off);
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(w + lay.mask_off);
+    const int nw = (n + 63) >> 6;
+    const int nwork = 64 * (nw - rb);
+    for (int idx = tid; idx < nwork; idx += 256) {
+        const int wd = rb + idx / 64, i = r0 + (idx & 63);
+        if (i < n) out[(long)i * lay.nw + wd] = nms_mask_word(box, area, i, wd, n, iou_thr);
+    }
+}
+
+__global__ __launch_bounds__(1024) void nms_large_scan_kernel(const float* __restrict__ scores, const long long* __restrict__ classes,
+                                                               const float* __restrict__ boxes, int K, const char* __restrict__ ws,
+                                                               NmsLargeLayout lay, float* out_scores, long long* out_classes,
+                                                               float* out_boxes, int* keep_idx, int* counts) {
+    __shared__ unsigned long long remv[NMSL_MAXNW], kept[NMSL_MAXNW];
+    __shared__ int prefix[NMSL_MAXNW + 1];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long base = (long)img * K;
+    const char* w = ws + (long)img * lay.per_img;
+    const int n = *reinterpret_cast<const int*>(w + lay.n_off);
+    const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(w + lay.mask_off);
+    const int nw = (n + 63) >> 6, ld = lay.nw;
+    for (int q = tid; q < nw; q += 1024) { remv[q] = 0ull; kept[q] = 0ull; }
+    __syncthreads();
+    for (int blk = 0; blk < nw; ++blk) {
+        if (wv == 0) {
+            const int row = (blk << 6) + lane;
+            const unsigned long long diag = (row < n) ? mask[(long)row * ld + blk] : 0ull;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            const unsigned long long cur0 = remv[blk];
+            unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)cur0);
+            unsigned chi = __builtin_amdgcn_readfirstlane((unsigned)(cur0 >> 32));
+            const int nb = min(64, n - (blk << 6));
+            unsigned klo = 0, khi = 0;
+#pragma unroll
+            for (int b = 0; b < 32; ++b) {
+                if (b < nb && !((clo >> b) & 1u)) {
+                    klo |= 1u << b;
+                    clo |= __builtin_amdgcn_readlane(dlo, b);
+                    chi |= __builtin_amdgcn_readlane(dhi, b);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 32; ++b) {
+                if (b + 32 < nb && !((chi >> b) & 1u)) {
+                    khi |= 1u << b;
+                    chi |= __builtin_amdgcn_readlane(dhi, b + 32);
+                }
+            }
+            if (lane == 0) kept[blk] = ((unsigned long long)khi << 32) | klo;
+        }
+        __syncthreads();
+        const unsigned long long k = kept[blk];
+        const int row = (blk << 6) + lane;
+        for (int wd = blk + 1 + wv; wd < nw; wd += 16) {      // wave wv takes the later words wd = blk + 1 + wv, + 16, ...
+            unsigned long long v = (((k >> lane) & 1ull) && row < n) ? mask[(long)row * ld + wd] : 0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned lo = __shfl_xor((unsigned)v, o);
+                const unsigned hi = __shfl_xor((unsigned)(v >> 32), o);
+                v |= ((unsigned long long)hi << 32) | lo;
+            }
+            if (lane == 0) remv[wd] |= v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int acc = 0;
+        for (int q = 0; q < nw; ++q) { prefix[q] = acc; acc += __popcll(kept[q]); }
+        prefix[nw] = acc;
+    }
+    __syncthreads();
+    const int total = prefix[nw];
+    for (int t = tid; t < n; t += 1024) {
+        const unsigned long long kw = kept[t >> 6];
+        if ((kw >> (t & 63)) & 1ull) {
+            const int r = prefix[t >> 6] + __popcll(kw & ((1ull << (t & 63)) - 1ull));
+            out_scores[base + r] = scores[base + t];
+            out_classes[base + r] = classes[base + t];
+            reinterpret_cast<float4*>(out_boxes)[base + r] = reinterpret_cast<const float4*>(boxes)[base + t];
+            keep_idx[base + r] = t;
+        }
+    }
+    for (int t = total + tid; t < K; t += 1024) {
+        out_scores[base + t] = 0.f;
+        out_classes[base + t] = 0;
+        reinterpret_cast<float4*>(out_boxes)[base + t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        keep_idx[base + t] = -1;
+    }
+    if (tid == 0) counts[img] = total;
+}
+
 extern "C" int64_t fd_nms_workspace_bytes(int32_t N, int32_t K) {
-    if (N < 1 || K < 1 || K > NMS_MAXK) return -1;
-    return (int64_t)N * NMS_MAXK * NMS_NW * (int64_t)sizeof(unsigned long long);
+    if (N < 1 || K < 1 || K > 64 * NMSL_MAXNW) return -1;
+    if (K <= NMS_MAXK) return (int64_t)N * NMS_MAXK * NMS_NW * (int64_t)sizeof(unsigned long long);
+    return (int64_t)N * nms_large_layout(K).per_img;
 }
 
 extern "C" int32_t fd_batched_nms(const float* scores, const int64_t* classes, const float* boxes, int32_t N,
@@ -689,11 +966,23 @@ extern "C" int32_t fd_batched_nms(const float* scores, const int64_t* classes, c
     FD_REQUIRE(scores && classes && boxes && out_scores && out_classes && out_boxes && keep_idx && counts && workspace,
                FD_E_INVAL, "fd_batched_nms: null pointer");
     FD_REQUIRE(N >= 1 && N <= 65535 && K >= 1, FD_E_INVAL, "fd_batched_nms: N=%d K=%d", N, K);
-    FD_REQUIRE(K <= NMS_MAXK, FD_E_UNSUPPORTED, "fd_batched_nms: K=%d > %d not supported", K, NMS_MAXK);
+    FD_REQUIRE(K <= 64 * NMSL_MAXNW, FD_E_UNSUPPORTED, "fd_batched_nms: K=%d > %d not supported", K, 64 * NMSL_MAXNW);
     FD_REQUIRE((((uintptr_t)boxes | (uintptr_t)out_boxes | (uintptr_t)workspace) & 15) == 0, FD_E_INVAL,
                "fd_batched_nms: boxes / workspace not 16-byte aligned");
     FD_REQUIRE(out_scores != scores && out_boxes != boxes && (const void*)out_classes != (const void*)classes, FD_E_INVAL,
                "fd_batched_nms: outputs must not alias inputs");
+    if (K > NMS_MAXK) {      // FCOSHead(max_detection_box > 1024): bitmask rows of ceil(K/64) words in the global workspace
+        const NmsLargeLayout lay = nms_large_layout(K);
+        hipStream_t st = (hipStream_t)stream;
+        hipLaunchKernelGGL(nms_large_prep_kernel, dim3(N), dim3(1024), 0, st, scores, (const long long*)classes, boxes, K, score_thr, (char*)workspace, lay);
+        FD_CHECK_LAUNCH("fd_batched_nms (K > 1024: prep)");
+        hipLaunchKernelGGL(nms_large_mask_kernel, dim3(lay.nw, N), dim3(256), 0, st, iou_thr, (char*)workspace, lay);
+        FD_CHECK_LAUNCH("fd_batched_nms (K > 1024: mask)");
+        hipLaunchKernelGGL(nms_large_scan_kernel, dim3(N), dim3(1024), 0, st, scores, (const long long*)classes, boxes, K, (const char*)workspace, lay,
+                           out_scores, (long long*)out_classes, out_boxes, keep_idx, counts);
+        FD_CHECK_LAUNCH("fd_batched_nms (K > 1024: scan)");
+        return FD_OK;
+    }
     hipLaunchKernelGGL(nms_mask_kernel, dim3((K + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, scores,
                        (const long long*)classes, boxes, K, score_thr, iou_thr, (unsigned long long*)workspace);
     FD_CHECK_LAUNCH("fd_batched_nms (mask)");

@@ -319,19 +319,30 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
                     return apply(code)
         return apply(heuristic_conv(M, Cout, KT, bool(p.workspace)))
     cands = [(0, 1)]
+    # FD_TILE_128x128_PATCH only exists for 3x3 stride-1 'same' convs whose (128-row tile + halo) patch fits its LDS budget, without split-K
+    wmax = max(p.segs.W[i] for i in range(p.segs.nseg))
+    patch_ok = (p.KH == 3 and p.KW == 3 and p.stride == 1 and p.pad == p.dil and p.out_H <= 0 and p.sc_H <= 0
+                and 128 + 2 * p.dil * (wmax + 1) <= 320)
     for tid, (bm, bn) in _lib.TILES.items():
+        if tid == _lib.PATCH_TILE and not patch_ok:
+            continue
         padded = -(-Cout // bn) * bn
         if padded <= max(32, int(Cout * 1.34)) and not (bn == 32 and Cout > 32):
             cands.append((tid, 1))
             ntile = -(-M // bm) * -(-Cout // bn)
-            if p.workspace:
+            if p.workspace and tid != _lib.PATCH_TILE:
                 for ks in (2, 4, 8):
                     if ks <= KSPLIT_MAX and KT >= 4 * ks and ntile * ks <= 2048 and ntile < 1024:
                         cands.append((tid, ks))
     best, best_t = 0, float("inf")
     for tid, ks in cands:
         apply(tid | (ks << 8))
-        run()  # warm
+        try:
+            run()  # warm
+        except FdError as e:          # a tile the library has no kernel for on this layer (FD_E_UNSUPPORTED): not a candidate
+            if "(-2)" not in str(e) and "UNSUPPORTED" not in str(e).upper():
+                raise
+            continue
         t = float("inf")
         for _ in range(3):
             t = min(t, _time_launches(run, reps, pair))
@@ -720,8 +731,15 @@ def fcos_topk(scores: torch.Tensor, classes: torch.Tensor, boxes: torch.Tensor, 
     tc = torch.empty(N, K, dtype=torch.int64, device=dev)
     tb = torch.empty(N, K, 4, dtype=torch.float32, device=dev)
     ti = torch.empty(N, K, dtype=torch.int32, device=dev) if want_idx else None
+    ws = None
+    if K > 1024:        # (FCOSHead(max_detection_box > 1024): the candidate list is sorted in a global scratch)
+        nb = _lib.lib().fd_topk_workspace_bytes(N, L, K)
+        if nb < 0:
+            raise FdError(f"fd_topk_workspace_bytes: bad arguments N={N} L={L} K={K}")
+        ws = torch.empty(nb // 8, dtype=torch.int64, device=dev)
     check(_lib.lib().fd_fcos_topk(scores.data_ptr(), classes.data_ptr(), boxes.data_ptr(), N, L, K, ts.data_ptr(),
-                                  tc.data_ptr(), tb.data_ptr(), ti.data_ptr() if want_idx else None, None, _stream()),
+                                  tc.data_ptr(), tb.data_ptr(), ti.data_ptr() if want_idx else None,
+                                  ws.data_ptr() if ws is not None else None, _stream()),
           "fd_fcos_topk")
     return (ts, tc, tb, ti) if want_idx else (ts, tc, tb)
 
@@ -734,7 +752,7 @@ def _nms_workspace(N: int, K: int, dev) -> torch.Tensor:
     key = (str(dev), _stream())
     need = _lib.lib().fd_nms_workspace_bytes(N, K)
     if need < 0:
-        raise FdError(f"fd_nms_workspace_bytes: unsupported N={N} K={K} (K <= 1024)")
+        raise FdError(f"fd_nms_workspace_bytes: unsupported N={N} K={K} (K <= 262144)")
     ws = _NMS_WS.get(key)
     if ws is None or ws.numel() * 8 < need:
         ws = torch.empty(need // 8, dtype=torch.int64, device=dev)

@@ -36,6 +36,7 @@ class TwoLanePipeline:
         self.tick = 0
         self.pending = None          # (lane, x, tower_events, tag) of the step whose T / S3 are still to be enqueued
         self.last_result = None
+        self.last_done = None        # event recorded behind the post-processing of the last finished step (on its lane)
 
     def _setup(self, x: torch.Tensor) -> None:
         # own plan instances (slots 1, 2; slot 0 stays the plain single-stream plan).  pair_tuned: take the block tiles from
@@ -121,8 +122,28 @@ class TwoLanePipeline:
             t_end.record()
             plan.run_range(self.hi, len(plan.steps))
             self.last_result = self.post(self.model.outputs_of(plan), x, tag)
+            self.last_done = torch.cuda.Event()
+            self.last_done.record()
         self.pending = None
         return t_end
+
+    def _hand_over(self, result):
+        """Results are allocated on a lane's stream and consumed on the caller's: order the caller's stream behind the lane that
+        produced them and tell the caching allocator about the second stream, so that a block the caller has dropped is not handed
+        to the lane's next launch while a kernel on the caller's stream still reads it."""
+        cur = torch.cuda.current_stream()
+        if getattr(self, "last_done", None) is not None:
+            cur.wait_event(self.last_done)
+
+        def walk(o):
+            if isinstance(o, torch.Tensor):
+                if o.is_cuda:
+                    o.record_stream(cur)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    walk(v)
+        walk(result)
+        return result
 
     def submit(self, x: torch.Tensor, tower_events=None, tag=None):
         """Enqueue one step (model + post) on the next lane; returns the result of the PREVIOUS step (None at first)."""
@@ -142,7 +163,7 @@ class TwoLanePipeline:
         prev = None
         if self.pending is not None:
             t_end = self._finish(p1)
-            prev = self.last_result
+            prev = self._hand_over(self.last_result)
             st.wait_event(t_end)
         with torch.cuda.stream(st):
             plan.run_range(self.cut, self.lo)
@@ -156,4 +177,4 @@ class TwoLanePipeline:
         cur = torch.cuda.current_stream()
         for st in self.streams:
             cur.wait_stream(st)
-        return self.last_result
+        return self._hand_over(self.last_result)

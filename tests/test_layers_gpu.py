@@ -924,3 +924,31 @@ def test_conv1x1_persistent_kernel_matches_default(tmp_path):
         got.append(torch.load(out))
     for a, b in zip(*got):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("k,stride,pad", [(1, 1, 0), (3, 1, 1), (3, 2, 1)])
+def test_autotune_force_mode_times_only_tiles_the_layer_has(k, stride, pad, monkeypatch):
+    """ops.autotune_conv's live-timing path (FD_AUTOTUNE=1 / force) used to offer FD_TILE_128x128_PATCH -- a 3x3 stride-1 'same'
+    only kernel -- to every layer and died on the library's FD_E_UNSUPPORTED.  Force mode on a 1x1, a 3x3 and a strided 3x3 layer: a tile
+    is chosen, the launch under it is correct, and no table entry is written to disk."""
+    monkeypatch.setattr(ops, "_TUNE_MODE", "force")
+    monkeypatch.setattr(ops, "_TUNE_CACHE", {})
+    monkeypatch.setattr(ops, "_TUNE_LOADED", True)
+    gen = torch.Generator().manual_seed(40 + k + stride)
+    B, Cin, Cout, H, W = 2, 64, 128, 24, 20
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * k * k)
+    ref = F.relu(F.conv2d(x, w, None, stride, pad))
+    segs = Segs.make(B, [(H, W)])
+    so = ops.conv_out_segs(segs, k, stride, pad, 1)
+    y = ops.new_rows(so.rows, Cout, DEV)
+    ws = torch.empty(ops.KSPLIT_MAX * so.rows * Cout, device=DEV)
+    call = ops.conv_call(to_rows(x), segs, ops.pack_conv_weight(w.to(DEV)), y, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, act=ACT_RELU,
+                         workspace=ws)
+    code = ops.autotune_conv(call, f"test|k{k}s{stride}", so.rows, Cout, (Cin // 32) * k * k, reps=2)
+    assert (code & 0xFF) in _TILE_IDS or (code & 0xFF) == 0
+    assert (code & 0xFF) != 13 or (k == 3 and stride == 1)
+    y.buf.fill_(float("nan"))
+    call()
+    Ho, Wo = so.level_hw()[0]
+    np.testing.assert_allclose(from_rows(y, B, Ho, Wo).numpy(), ref.numpy(), atol=ATOL, rtol=RTOL)

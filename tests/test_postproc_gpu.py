@@ -63,7 +63,8 @@ def test_decode_full_size_vs_oracle():
     assert diff.mean() < 1e-4
 
 
-@pytest.mark.parametrize("L,K", [(8525, 1000), (23265, 1000), (341, 100), (50, 50), (1000, 1)])
+@pytest.mark.parametrize("L,K", [(8525, 1000), (23265, 1000), (341, 100), (50, 50), (1000, 1),
+                                 (8525, 1025), (8525, 3000), (8525, 8525), (23265, 5000)])      # K > 1024: the global-scratch path
 def test_topk_matches_stable_sort(L, K):
     rng = np.random.default_rng(L + K)
     B = 3
@@ -194,6 +195,50 @@ def test_dataencoder_api(golden):
     np.testing.assert_array_equal(enc._box_iou(_t(g4["a"]), _t(g4["b"])).cpu().numpy(), g4["iou_plus1"])
 
 
+@pytest.mark.parametrize("K", [1025, 1500, 4096, 5000])
+def test_batched_nms_more_than_1024_candidates_vs_oracle(K):
+    """FCOSHead(max_detection_box > 1024) (the reference accepts any value, model/modules/head.py:41-50): fd_batched_nms's
+    global-workspace path -- kept indices bit-exact vs the C oracle, padding, idempotence."""
+    rng = np.random.default_rng(K)
+    B = 3
+    scores = np.sort(np.sqrt(rng.uniform(0, 1, (B, K)) * rng.uniform(0, 1, (B, K))).astype(np.float32), axis=1)[:, ::-1].copy()
+    scores[1, K // 3:] = 0.01
+    classes = rng.integers(1, 21, (B, K)).astype(np.int64)
+    boxes = np.stack([_rand_boxes(rng, K, True) for _ in range(B)])
+    os_, oc, ob, keep, counts = ops.batched_nms(_t(scores), _t(classes), _t(boxes), 0.05, 0.6)
+    exp = R.post_process(scores, classes, boxes, 0.05, 0.6)
+    for b in range(B):
+        n = int(counts[b])
+        assert n == len(exp[b]) and 0 < n < K
+        np.testing.assert_array_equal(keep[b, :n].cpu().numpy(), exp[b], err_msg=f"image {b}")
+        assert (keep[b, n:] == -1).all() and (os_[b, n:] == 0).all()
+        np.testing.assert_array_equal(ob[b, :n].cpu().numpy(), boxes[b][exp[b]])
+    os2, _, ob2, _, counts2 = ops.batched_nms(os_, oc, ob, 0.05, 0.6)
+    assert torch.equal(counts2, counts) and torch.equal(os2, os_) and torch.equal(ob2, ob)
+
+
+def test_fcos_head_max_detection_box_above_1024_vs_oracle():
+    """The whole FCOSHead with max_detection_box = 2000 on a 40 x 40 + 20 x 20 pyramid: top-k order against the oracle's stable sort of the
+    device's scores, NMS kept rows against the oracle's post_process on the device's top-k (per-stage, identical inputs: bit-exact)."""
+    gen = torch.Generator().manual_seed(9)
+    hw = [(40, 40), (20, 20)]
+    outs = [[(torch.randn(2, 20, h, w, generator=gen) * 2 - 1).to(DEV) for h, w in hw], [torch.randn(2, 1, h, w, generator=gen).to(DEV) for h, w in hw],
+            [(torch.rand(2, 4, h, w, generator=gen) * 40 + 4).to(DEV) for h, w in hw]]
+    head = FCOSHead(0.05, 0.6, 1800, [8, 16])
+    ts, tc, tb = head.decode_topk(outs)
+    assert ts.shape == (2, 1800) and bool((ts[:, 1:] <= ts[:, :-1]).all())
+    s, c, b, counts = head.detect_padded(outs)
+    exp = R.post_process(ts.cpu().numpy(), tc.cpu().numpy(), tb.cpu().numpy(), 0.05, 0.6)
+    for i in range(2):
+        n = int(counts[i])
+        assert n == len(exp[i]) and 0 < n < 1800
+        np.testing.assert_array_equal(s[i, :n].cpu().numpy(), ts[i].cpu().numpy()[exp[i]])
+        np.testing.assert_array_equal(c[i, :n].cpu().numpy(), tc[i].cpu().numpy()[exp[i]])
+        np.testing.assert_array_equal(b[i, :n].cpu().numpy(), tb[i].cpu().numpy()[exp[i]])
+    ss, cc, bb = FCOSHead(0.05, 0.6, 5000, [8, 16]).decode_topk(outs)       # K = min(5000, 2000) = every location
+    assert ss.shape == (2, 2000)
+
+
 def test_edge_shapes_and_errors():
     from pytorch_object_detection_amd._lib import FdError
     rng = np.random.default_rng(3)
@@ -216,10 +261,6 @@ def test_edge_shapes_and_errors():
     idx = R.topk(es, 15)
     np.testing.assert_array_equal(c.cpu().numpy()[0], ec[0][idx[0]])
     np.testing.assert_array_equal(b.cpu().numpy()[0], eb[0][idx[0]])
-    # documented limits fail loudly instead of silently truncating
-    big = [[torch.zeros(1, c, 40, 40, device=DEV)] for c in (20, 1, 4)]
-    with pytest.raises(FdError, match="1024"):
-        FCOSHead(0.05, 0.6, 1500, [8])(big)
     with pytest.raises(FdError):
         ops.fcos_topk(_t(np.zeros((1, 10), np.float32)), _t(np.zeros((1, 10), np.int32)), _t(np.zeros((1, 10, 4), np.float32)), 11)
 
