@@ -104,7 +104,9 @@ const char* fd_last_error(void);
                                shift; same epilogue contract incl. ksplit (chunk loop split over workgroups, combined in slice
                                order); the result differs from the direct kernel's fma chain by fp32 rounding (~1e-5 relative),
                                deterministically */
-#define FD_TILE_COUNT 14
+#define FD_TILE_WAVE64 15   /* GEMM-addressed layers (1x1, stride 1, no padding; Cin % 32 == 0, fp32): wave-autonomous 64 x 64 tiles, one wave per
+                               workgroup, no barrier in the K loop (fd_conv_wave.hip) -- needs fd_conv_params.w_frag (fd_pack_conv_weight_wave_f32) */
+#define FD_TILE_COUNT 15
 
 typedef struct fd_conv_params {
     const float* x;
@@ -149,10 +151,19 @@ typedef struct fd_conv_params {
     const float* gate;
     int32_t gate_cs;
     int32_t reserved0;
+    /* FD_TILE_WAVE64 only: the SAME weights as `w` in MFMA fragment order (fd_pack_conv_weight_wave_f32); NULL: that tile is unavailable.
+     * A caller that holds both packings can switch tiles per launch (plan-time autotuning). */
+    const float* w_frag;
 } fd_conv_params;
 
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
 int64_t fd_conv_workspace_bytes(int64_t out_rows, int32_t Cout, int32_t ksplit);
+
+/* Weights for FD_TILE_WAVE64: [Cout][Cin] fp32 (an OIHW 1x1 filter bank, Cin % 32 == 0) -> MFMA fragment order
+ * [ceil(Cout/64)][Cin/32][2 sub-tiles][4 k-steps][64 lanes][4 floats] (fd_conv_weight_wave_bytes bytes, zero rows past Cout): lane
+ * (l & 31, l >> 5) of sub-tile j, k-step s, K-tile kt holds w[64 nt + 32 j + (l & 31)][32 kt + 8 s + 4 (l >> 5) + 0..3]. */
+int64_t fd_conv_weight_wave_bytes(int32_t Cout, int32_t Cin);
+int32_t fd_pack_conv_weight_wave_f32(const float* w, float* out, int32_t Cout, int32_t Cin, fd_stream_t stream);
 
 /* Weights for FD_TILE_WINOGRAD: OIHW fp32 [Cout][Cin][3][3] -> U = G g G^T (computed in double, rounded once) packed
  * [ceil(Cout/32)][Cin/8][16 frequencies][32 cout][8 cin] (fd_wino_weight_bytes(Cout, Cin) bytes, zero rows past Cout).

@@ -12,8 +12,10 @@ TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (128, 32), 6
          7: (128, 128), 8: (128, 64), 9: (64, 128),   # 7-9: single-LDS-buffer variants
          10: (256, 128), 11: (256, 128),             # 8-wave tile (11: single LDS buffer)
          12: (128, 96),                              # 128x96, single LDS buffer
-         13: (128, 128)}                             # 128x128 with the 3x3 input patch staged in LDS (3x3 stride-1 'same' only)
+         13: (128, 128),                             # 128x128 with the 3x3 input patch staged in LDS (3x3 stride-1 'same' only)
+         15: (64, 64)}                               # wave-autonomous 64x64 tiles, one wave per workgroup (1x1 stride-1 layers, needs w_frag)
 PATCH_TILE = 13
+WAVE_TILE = 15
 WINO_TILE = 14      # Winograd F(2x2, 3x3) kernel (own weight packing: ops.pack_conv_weight_wino); not a member of TILES
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -60,7 +62,7 @@ class ConvParams(C.Structure):
                 ("seg_param", C.c_float * FD_MAX_SEG), ("segs", Segs),
                 ("out_H", C.c_int32), ("out_W", C.c_int32), ("sc_sy", C.c_int32), ("sc_sx", C.c_int32), ("sc_oy", C.c_int32),
                 ("sc_ox", C.c_int32), ("sc_H", C.c_int32), ("sc_W", C.c_int32),
-                ("gate", C.c_void_p), ("gate_cs", C.c_int32), ("reserved0", C.c_int32)]
+                ("gate", C.c_void_p), ("gate_cs", C.c_int32), ("reserved0", C.c_int32), ("w_frag", C.c_void_p)]
 
 
 class PackJob(C.Structure):
@@ -88,6 +90,8 @@ _SIGS = {
     "fd_conv_wgrad_workspace_bytes": (_L, [_L, _I, _I, _I, _I]),
     "fd_pack_conv_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fd_pack_conv_weights_batch_f32": (_I, [_P, _I, _L, _P]),
+    "fd_conv_weight_wave_bytes": (_L, [_I, _I]),
+    "fd_pack_conv_weight_wave_f32": (_I, [_P, _P, _I, _I, _P]),
     "fd_wino_weight_bytes": (_L, [_I, _I]),
     "fd_wino_pack_weights_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fd_conv2d_bwd_weight_f32": (_I, [C.POINTER(WgradParams), _P]),

@@ -422,6 +422,14 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
         if (m128 * ((a.Cout + 127) / 128) < 640) return launch_conv<2, 2, 1, 2, false, false, 0, false, true>(a, stream);   // 64 x 128
         return launch_conv<2, 2, 2, 2, false, false, 0, false, true>(a, stream);                        // 128 x 128
     }
+    if (p->tile == FD_TILE_WAVE64) {     // GEMM-addressed layers as wave-autonomous 64 x 64 tiles (fd_conv_wave.hip)
+        FD_REQUIRE(a.is_gemm && p->Cin % 32 == 0 && p->Cout % 32 == 0 && p->precision == FD_PREC_F32 && p->ksplit <= 1 && !a.sc_on && p->out_H <= 0 &&
+                       a.vec_epi && !p->gate && p->act_c0 % 32 == 0 && (p->act == FD_ACT_NONE || p->act == FD_ACT_RELU || p->act == FD_ACT_SILU),
+                   FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WAVE64 needs an fp32 1x1 stride-1 unpadded conv with Cin, Cout, act_c0 multiples of 32, 16-byte output "
+                   "views, ReLU / SiLU / no activation, no split-K / scatter / gate");
+        FD_REQUIRE(p->w_frag && ((uintptr_t)p->w_frag & 15) == 0, FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WAVE64 needs fd_conv_params.w_frag (fd_pack_conv_weight_wave_f32)");
+        return fd_launch_conv_wave(a, p->w_frag, stream);
+    }
     if (p->tile == FD_TILE_128x128_PATCH) {     // 3x3 stride-1 'same' conv with the input patch staged in LDS (fd_conv_patch.hip)
         int wmax = 0;
         for (int sg = 0; sg < p->in.nseg; ++sg) wmax = p->in.W[sg] > wmax ? p->in.W[sg] : wmax;

@@ -33,6 +33,7 @@ AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see 
 # (ops.wino_preferred: it has no split-K); "force" = wherever it applies; "0" = every conv on the direct implicit-GEMM kernel
 WINOGRAD = _os.environ.get("FD_WINOGRAD", "1") != "0"
 SE_GATE_IN_PROJECT = _os.environ.get("FD_SE_GATE_FUSED", "1") != "0"     # MBConv: SE gate applied by the project conv's loader ("0": a scaling pass)
+WAVE_TILE = _os.environ.get("FD_WAVE_TILE", "1") != "0"       # "0": the 1x1 layers never see FD_TILE_WAVE64 (wave-autonomous tiles, fd_conv_wave.hip)
 STEM_KERNEL = _os.environ.get("FD_STEM_KERNEL", "1") != "0"     # "0": the ResNet stem through the generic conv kernel's FD_CONV_STEM mode
 
 
@@ -162,6 +163,12 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         wp = ops.pack_conv_weight_wino(_dev(w, dev))
     else:
         wp = ops.pack_conv_weight_f16x3(_dev(w, dev)) if split else ops.pack_conv_weight(_dev(w, dev))
+    # GEMM-addressed fp32 layers also get their weights in MFMA fragment order: the wave-autonomous tile (FD_TILE_WAVE64) becomes selectable
+    wfrag = None
+    if (not wino and not split and WAVE_TILE and gate is None and ops.wave_ok(Cin, co, k, stride, pad) and act_c0 % 32 == 0
+            and act in (ACT_NONE, ACT_RELU, ACT_SILU) and y.cs % 4 == 0 and y.co % 4 == 0 and (res is None or (res.cs % 4 == 0 and res.co % 4 == 0))):
+        if w.shape[0] == co and w.shape[1] == Cin:
+            wfrag = ops.pack_conv_weight_wave(_dev(w, dev))
     scale = shift = None
     if fold is not None:
         scale, shift = fold
@@ -170,7 +177,7 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
                                    _dev(bn.running_var, dev), bn.eps, _dev(b, dev) if b is not None else None)
     elif b is not None:
         shift = _dev(b, dev)
-    plan.keep += [wp, scale, shift]
+    plan.keep += [wp, scale, shift, wfrag]
     out = ops.conv_out_segs(segs, k, stride, pad, dil)
     # split-K scratch: taken from the pool and handed straight back (stream order makes the sharing safe)
     ws_rows = ops.KSPLIT_MAX * out.rows
@@ -181,7 +188,7 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     call = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                          shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param, tag=tag,
                          precision=1 if split else 0, workspace=ws.buf if ws is not None else None,
-                         tile=_lib.WINO_TILE if wino else 0, ksplit=wino_ks if wino else 1, gate=gate)
+                         tile=_lib.WINO_TILE if wino else 0, ksplit=wino_ks if wino else 1, gate=gate, w_frag=wfrag)
     plan.add(name, call)
     if ws is not None:
         plan.pool.put(ws)

@@ -88,6 +88,24 @@ def pack_conv_weight_f16x3(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo], dim=-2).contiguous()                                   # [O, I/32, KH, KW, 2, 32]
 
 
+def wave_ok(Cin: int, Cout: int, k: int, stride: int, pad: int) -> bool:
+    """Layers FD_TILE_WAVE64 (fd_conv_wave.hip: wave-autonomous 64 x 64 tiles) covers: GEMM-addressed, Cin and Cout multiples of 32."""
+    return k == 1 and stride == 1 and pad == 0 and Cin % 32 == 0 and Cout % 32 == 0
+
+
+def pack_conv_weight_wave(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 1, 1] fp32 -> the MFMA-fragment-order operand of FD_TILE_WAVE64 (fd_pack_conv_weight_wave_f32), one HIP launch."""
+    w = w.detach().float().contiguous()
+    _need_gpu(w)
+    co, ci = w.shape[0], w.shape[1]
+    nb = _lib.lib().fd_conv_weight_wave_bytes(co, ci)
+    if nb < 0 or w.numel() != co * ci:
+        raise FdError(f"pack_conv_weight_wave: needs a 1x1 filter bank with Cin % 32 == 0 (got {tuple(w.shape)})")
+    out = torch.empty(nb // 4, dtype=torch.float32, device=w.device)
+    check(_lib.lib().fd_pack_conv_weight_wave_f32(w.data_ptr(), out.data_ptr(), co, ci, _stream()), "fd_pack_conv_weight_wave_f32")
+    return out
+
+
 def pack_stem_weight(w: torch.Tensor) -> torch.Tensor:
     """[Cout,3,7,7] -> [Cout][7][8][4], zero at kw=7 and c=3 (FD_CONV_STEM)."""
     co = w.shape[0]
@@ -150,8 +168,9 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
               tag: int = 0, precision: int = 0, ksplit: int = 1,
               workspace: Optional[torch.Tensor] = None, res_mask: bool = False, kw: Optional[int] = None,
               out_hw: Optional[Tuple[int, int]] = None, scatter: Optional[Tuple[int, int, int, int, int, int]] = None,
-              gate: Optional[torch.Tensor] = None) -> Callable[[], None]:
-    """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream."""
+              gate: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None) -> Callable[[], None]:
+    """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream.
+    w_frag: the same weights in FD_TILE_WAVE64's fragment order (pack_conv_weight_wave), which makes that tile selectable."""
     _need_gpu(w_packed, scale, shift)
     p = ConvParams()
     p.x, p.w, p.y = x.ptr, w_packed.data_ptr(), y.ptr
@@ -174,6 +193,9 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
         if gate.dim() != 2 or gate.shape[0] != segs.batch or gate.stride(1) != 1 or gate.dtype != torch.float32:
             raise FdError("conv gate must be a [batch, C] fp32 tensor with unit channel stride")
         p.gate, p.gate_cs = gate.data_ptr(), gate.stride(0)
+    if w_frag is not None:
+        _need_gpu(w_frag)
+        p.w_frag = w_frag.data_ptr()
     if workspace is not None:
         _need_gpu(workspace)
         p.workspace, p.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
@@ -183,7 +205,7 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     p.segs = segs
     fn = _lib.lib().fd_conv2d_nhwc_f32
     ref = C.byref(p)
-    keep = (x, w_packed, y, scale, shift, res, p, workspace, gate)
+    keep = (x, w_packed, y, scale, shift, res, p, workspace, gate, w_frag)
 
     def run(_keep=keep):
         check(fn(ref, _stream()), "fd_conv2d_nhwc_f32")
@@ -323,14 +345,15 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
     wmax = max(p.segs.W[i] for i in range(p.segs.nseg))
     patch_ok = (p.KH == 3 and p.KW == 3 and p.stride == 1 and p.pad == p.dil and p.out_H <= 0 and p.sc_H <= 0
                 and 128 + 2 * p.dil * (wmax + 1) <= 320)
+    wave_tile_ok = bool(p.w_frag) and wave_ok(p.Cin, p.Cout, p.KH, p.stride, p.pad) and p.KW == 1 and p.act_c0 % 32 == 0
     for tid, (bm, bn) in _lib.TILES.items():
-        if tid == _lib.PATCH_TILE and not patch_ok:
+        if (tid == _lib.PATCH_TILE and not patch_ok) or (tid == _lib.WAVE_TILE and not wave_tile_ok):
             continue
         padded = -(-Cout // bn) * bn
         if padded <= max(32, int(Cout * 1.34)) and not (bn == 32 and Cout > 32):
             cands.append((tid, 1))
             ntile = -(-M // bm) * -(-Cout // bn)
-            if p.workspace and tid != _lib.PATCH_TILE:
+            if p.workspace and tid not in (_lib.PATCH_TILE, _lib.WAVE_TILE):
                 for ks in (2, 4, 8):
                     if ks <= KSPLIT_MAX and KT >= 4 * ks and ntile * ks <= 2048 and ntile < 1024:
                         cands.append((tid, ks))

@@ -952,3 +952,49 @@ def test_autotune_force_mode_times_only_tiles_the_layer_has(k, stride, pad, monk
     call()
     Ho, Wo = so.level_hw()[0]
     np.testing.assert_allclose(from_rows(y, B, Ho, Wo).numpy(), ref.numpy(), atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("case", [
+    # Cin, Cout, H, W, residual, act, act_c0, res_mask
+    (64, 256, 20, 24, True, ACT_RELU, 0, False),        # bottleneck conv3 (+ residual + ReLU)
+    (256, 64, 20, 24, False, ACT_RELU, 0, False),       # bottleneck conv1
+    (2048, 256, 5, 7, False, ACT_RELU, 0, False),       # FPN lateral, ragged M tail (70 rows)
+    (256, 256, 9, 11, False, ACT_SILU, 128, False),     # HisBlock conv1+2: SiLU on the upper half only
+    (512, 96, 6, 6, True, ACT_NONE, 0, True),           # Cout % 64 == 32, ReLU-mask residual (a data gradient)
+    (32, 64, 3, 3, False, ACT_NONE, 0, False),          # one K-tile
+])
+def test_conv1x1_wave_tile_is_bit_identical_to_the_workgroup_kernel(case):
+    """FD_TILE_WAVE64 (fd_conv_wave.hip: one wave = one 64 x 64 tile, no barrier in the K loop, weights in MFMA fragment order): the same
+    fma chain per output as the workgroup-tiled kernel -> bitwise equal results, on channel-slice views whose neighbours are NaN."""
+    from pytorch_object_detection_amd import _lib
+    Cin, Cout, H, W, use_res, act, act_c0, res_mask = case
+    gen = torch.Generator().manual_seed(sum(case[:4]))
+    B = 3
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 1, 1, generator=gen) / np.sqrt(Cin)
+    scale, shift = (torch.rand(Cout, generator=gen) + 0.5).to(DEV), torch.randn(Cout, generator=gen).to(DEV)
+    segs = Segs.make(B, [(H, W)])
+    rows = B * H * W
+    xb = torch.full((rows, Cin + 8), float("nan"), device=DEV)
+    xb[:, 4:4 + Cin] = x.permute(0, 2, 3, 1).reshape(rows, Cin).to(DEV)
+    xr = ops.Rows(xb, 4, Cin)
+    res = ops.Rows(torch.randn(rows, Cout + 4, generator=gen).to(DEV), 4, Cout) if use_res else None
+    wd = w.to(DEV)
+    outs = []
+    for tile in (4, _lib.WAVE_TILE):
+        yb = torch.full((rows, Cout + 8), float("nan"), device=DEV)
+        y = ops.Rows(yb, 4, Cout)
+        ops.conv_call(xr, segs, ops.pack_conv_weight(wd), y, Cin=Cin, Cout=Cout, k=1, scale=scale, shift=shift, res=res, act=act, act_c0=act_c0,
+                      res_mask=res_mask, tile=tile, w_frag=ops.pack_conv_weight_wave(wd))()
+        assert torch.isnan(yb[:, :4]).all() and torch.isnan(yb[:, 4 + Cout:]).all()       # nothing outside the channel view was written
+        outs.append(y.tensor().clone())
+    assert torch.equal(outs[0], outs[1])
+    ref = F.conv2d(x, w) * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1)
+    if use_res:
+        r = res.tensor().cpu().reshape(B, H, W, Cout).permute(0, 3, 1, 2)
+        ref = torch.where(r > 0, ref, torch.zeros_like(ref)) if res_mask else ref + r
+    if act != ACT_NONE:
+        a = act_ref(ref, act)
+        ref = torch.cat([ref[:, :act_c0], a[:, act_c0:]], 1)
+    got = outs[1].reshape(B, H, W, Cout).permute(0, 3, 1, 2).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=ATOL, rtol=RTOL)

@@ -23,12 +23,13 @@ for key, cur in sorted(table.items()):
     r = ops.Rows(torch.randn(segs.rows, Cout, device=dev)) if res else None
     w = torch.randn(Cout, Cin, 1, 1, device=dev) / Cin ** 0.5
     wp = ops.pack_conv_weight(w)
+    wf = ops.pack_conv_weight_wave(w) if (ops.wave_ok(Cin, Cout, 1, 1, 0) and ycs % 4 == 0) else None
     sc, sf = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
-    tiles = [t for t in (1, 2, 3, 4, 7, 8, 9, 5, 6, 12) if not ((t == 5 and Cout > 32) or (t in (6, 12) and Cout > 96))]
+    tiles = [t for t in (1, 2, 3, 4, 7, 8, 9, 5, 6, 12, 15) if not ((t == 5 and Cout > 32) or (t in (6, 12) and Cout > 96) or (t == 15 and wf is None))]
     times = {t: [] for t in tiles}
     for rnd in range(2):
         for t in tiles:
-            run = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=Cout, k=1, scale=sc, shift=sf, res=r, act=1, tile=t)
+            run = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=Cout, k=1, scale=sc, shift=sf, res=r, act=1, tile=t, w_frag=wf)
             for _ in range(2): run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -16,6 +16,7 @@ so = ops.conv_out_segs(segs, k, stride, pad, 1)
 x = ops.Rows(torch.randn(segs.rows, Cin, device=dev))
 w = torch.randn(Cout, Cin, k, k, device=dev) / (Cin * k * k) ** 0.5
 wp = ops.pack_conv_weight(w)
+wf = ops.pack_conv_weight_wave(w) if ops.wave_ok(Cin, Cout, k, stride, pad) else None
 y = ops.new_rows(so.rows, Cout, dev)
 res = ops.Rows(torch.randn(so.rows, Cout, device=dev)) if use_res else None
 sc, sf = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
@@ -24,9 +25,9 @@ byts = 4 * (segs.rows * Cin + so.rows * Cout * (2 if use_res else 1))
 only = [int(v) for v in os.environ.get('FD_TILES', '').split(',') if v]
 print(f"M={so.rows} Cin={Cin} Cout={Cout} k={k} s={stride} res={use_res}: {flops/1e9:.1f} GF, {byts/1e6:.0f} MB min traffic")
 for tile in (only or sorted(_lib.TILES)):
-    if (tile == 5 and Cout > 32) or (tile == 6 and Cout > 96):
+    if (tile == 5 and Cout > 32) or (tile == 6 and Cout > 96) or (tile == 13 and k != 3) or (tile == 15 and wf is None):
         continue
-    run = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, scale=sc, shift=sf, res=res, act=act, tile=tile)
+    run = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, scale=sc, shift=sf, res=res, act=act, tile=tile, w_frag=wf)
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
