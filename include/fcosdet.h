@@ -154,6 +154,18 @@ typedef struct fd_conv_params {
     /* FD_TILE_WAVE64 only: the SAME weights as `w` in MFMA fragment order (fd_pack_conv_weight_wave_f32); NULL: that tile is unavailable.
      * A caller that holds both packings can switch tiles per launch (plan-time autotuning). */
     const float* w_frag;
+    /* GroupNorm fused around the conv (HISFCOSHead, HISFcos.py:216-225: pw1 -> GN -> ReLU -> dw1 -> GN -> SiLU -> pw2; towers -> GN -> ReLU):
+     *   gn_stats != NULL: the epilogue also writes, per output row m and channel group g of `gn_groups` groups over Cout, the fp32 pair
+     *     (sum, sum of squares) of the group's STORED values to gn_stats[m][g] (float2; rows x gn_groups x 8 bytes) in a fixed summation order;
+     *     fd_groupnorm_from_rowstats turns them into the per-(level, image, group) statistics -- the statistics pass over the map disappears.
+     *     Needs Cout % 32 == 0, (Cout / gn_groups) in {4, 8, 16, 32}, 16-byte output views, no split-K, no output scatter.
+     *   gate_b != NULL (with `gate`): the loader applies x' = act(x * gate[img][c] + gate_b[img][c]), gate_act in {NONE, RELU, SILU}, img =
+     *     level * batch + image -- the GroupNorm affine + activation of the PRECEDING layer applied on the way to LDS (coefficients from
+     *     fd_groupnorm_from_rowstats), so the normalise pass over the map disappears too.  `gate` alone keeps meaning x * gate (MBConv SE). */
+    float* gn_stats;
+    int32_t gn_groups;
+    int32_t gate_act;
+    const float* gate_b;
 } fd_conv_params;
 
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
@@ -359,6 +371,23 @@ int32_t fd_maxpool_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const fl
                             int32_t pad, fd_stream_t stream);
 int32_t fd_upsample2x_bwd_nhwc(const float* dy, int32_t dy_cs, int32_t dy_co, float* dx, int32_t dx_cs, int32_t dx_co, int32_t N,
                                int32_t H, int32_t W, int32_t C, fd_stream_t stream);
+
+/* GroupNorm fused into its neighbours (HISFCOSHead, HISFcos.py:216-225).  A producer (fd_conv_params.gn_stats, fd_dwconv3x3_gn_nhwc) leaves
+ * rowstats[m][g] = (sum, sum of squares) of group g's channels of row m (fp32 float2).  fd_groupnorm_from_rowstats reduces them per
+ * (level, image, group) in fp64 in a fixed order into `workspace` (fd_groupnorm_workspace_bytes(segs, G): the layout fd_groupnorm_act_nhwc
+ * leaves, so fd_groupnorm_apply_nhwc and fd_groupnorm_act_bwd_nhwc work on it) and, with coef != NULL, writes the affine a consumer applies
+ * in its loader: coef[(level * batch + image)][0][c] = rstd * gamma[c], [..][1][c] = beta[c] - mean * rstd * gamma[c]  ([imgs][2][C] floats).
+ * 2 * G must divide 256.  fd_groupnorm_apply_nhwc: y = act(x * a + b) from statistics already in `workspace` (one pass over the map).
+ * fd_dwconv3x3_gn_nhwc: depthwise 3x3 (stride 1, pad 1, no bias) that reads its input as in_act(x * a + b) (in_coef as above, NULL: plain;
+ * the zero padding is applied AFTER the normalisation, as in the reference) and writes gn_stats of its output (NULL: none). */
+int32_t fd_groupnorm_from_rowstats(const float* rowstats, int32_t C, int32_t G, float eps, const float* gamma, const float* beta,
+                                   const fd_segs* segs, void* workspace, float* coef, fd_stream_t stream);
+int32_t fd_groupnorm_apply_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* gamma, const float* beta, float* y,
+                                int32_t y_cs, int32_t y_co, int32_t C, int32_t G, float eps, int32_t act, const fd_segs* segs,
+                                const void* workspace, fd_stream_t stream);
+int32_t fd_dwconv3x3_gn_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w, const float* in_coef, int32_t in_act,
+                             float* y, int32_t y_cs, int32_t y_co, int32_t C, float* gn_stats, int32_t gn_groups,
+                             const fd_segs* segs, fd_stream_t stream);
 
 /* nn.BatchNorm2d in TRAINING mode (the FPN BatchNorms under the reference's model.train(), train.py:151) runs on the
  * GroupNorm entry points: batch statistics per channel = GroupNorm statistics of ONE image of (batch*H) x W pixels with

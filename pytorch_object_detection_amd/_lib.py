@@ -62,7 +62,8 @@ class ConvParams(C.Structure):
                 ("seg_param", C.c_float * FD_MAX_SEG), ("segs", Segs),
                 ("out_H", C.c_int32), ("out_W", C.c_int32), ("sc_sy", C.c_int32), ("sc_sx", C.c_int32), ("sc_oy", C.c_int32),
                 ("sc_ox", C.c_int32), ("sc_H", C.c_int32), ("sc_W", C.c_int32),
-                ("gate", C.c_void_p), ("gate_cs", C.c_int32), ("reserved0", C.c_int32), ("w_frag", C.c_void_p)]
+                ("gate", C.c_void_p), ("gate_cs", C.c_int32), ("reserved0", C.c_int32), ("w_frag", C.c_void_p),
+                ("gn_stats", C.c_void_p), ("gn_groups", C.c_int32), ("gate_act", C.c_int32), ("gate_b", C.c_void_p)]
 
 
 class PackJob(C.Structure):
@@ -111,6 +112,9 @@ _SIGS = {
     "fd_dwconv3x3_bwd_weight_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, C.POINTER(Segs), _P, _P]),
     "fd_groupnorm_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
     "fd_groupnorm_act_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _I, C.POINTER(Segs), _P, _P]),
+    "fd_groupnorm_from_rowstats": (_I, [_P, _I, _I, _F, _P, _P, C.POINTER(Segs), _P, _P, _P]),
+    "fd_groupnorm_apply_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _I, C.POINTER(Segs), _P, _P]),
+    "fd_dwconv3x3_gn_nhwc": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, C.POINTER(Segs), _P]),
     "fd_groupnorm_bwd_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
     "fd_groupnorm_act_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, C.POINTER(Segs), _P, _P,
                                        _P]),

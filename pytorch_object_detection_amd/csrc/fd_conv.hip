@@ -15,7 +15,8 @@
 
 // GATE: the A operand is multiplied by a per-(image, input channel) gate on its way to LDS (1x1 GEMM layers, single level): the
 // squeeze-excitation gate of an MBConv block folded into its project conv.
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT, bool GATE = false>
+// GNS: the epilogue also writes the row-group statistics of the stored output (fd_conv_params.gn_stats; one- and two-sub-tile tiles only).
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT, bool GATE = false, bool GNS = false>
 __global__ __launch_bounds__(WGM * WGN * 64, (TM * TN == 4) ? ((SPLIT || WGM * WGN == 8) ? 2 : (SB ? 3 : 1)) : 1)
 void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -53,11 +54,20 @@ void conv_igemm_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, (int)a.w_bytes, 0x00020000);
     unsigned a_off[AP];                         // byte offset of tap (0, 0), channel chunk 0 (may wrap below zero)
     int a_wcs[AP], a_hi0[AP], a_wi0[AP], a_H[AP], a_W[AP];
-    const float* g_row[GATE ? AP : 1];          // GATE: this row's image's gate vector, at this thread's channel quad
+    const float* g_row[GATE ? AP : 1];          // GATE: this row's (level, image) gate vector, at this thread's channel quad
+    const long gate_bo = GATE && a.gate_b ? (long)(a.gate_b - a.gate) : 0;     // element distance gate -> gate_b (same row layout)
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + lrow + RPP * i;
-        if (GATE) g_row[i] = a.gate + (size_t)(min(m, a.M - 1) / a.gate_hw) * a.gate_cs + chunk * 4;
+        if (GATE) {
+            const int mm = min(m, a.M - 1);
+            int sg = 0;
+#pragma unroll
+            for (int t = 1; t < FD_MAX_SEG; ++t)
+                if (t < a.nseg && mm >= a.m_out[t]) sg = t;
+            const int img = sg * a.gate_batch + (mm - a.m_out[sg]) / (a.Ho[sg] * a.Wo[sg]);
+            g_row[i] = a.gate + (size_t)img * a.gate_cs + chunk * 4;
+        }
         if (a.is_gemm) {  // 1x1, stride 1, no padding: the input row IS the output row (no divisions)
             a_off[i] = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) * 4u;
             a_wcs[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = (m < a.M) ? 1 : 0; a_W[i] = 1;
@@ -88,7 +98,7 @@ void conv_igemm_kernel(ConvArgs a) {
         b_off[j] = (n < a.Cout) ? ((unsigned)n * (unsigned)a.Kpacked + (unsigned)(chunk * 4)) * 4u : OOB;
     }
 
-    float4 ra[AP], rb[BP], rg[GATE ? AP : 1];
+    float4 ra[AP], rb[BP], rg[GATE ? AP : 1], rgb[GATE ? AP : 1];
     // k-tile order = (32-channel chunk, tap): the 9 taps of one channel chunk are consecutive, so the shifted re-reads
     // of the same input pixels hit L1/L2 instead of travelling from the Infinity Cache.  load_tile() is called with
     // consecutive kt, so (chunk, filter row, filter column) advance as counters (no divisions in the K loop).
@@ -106,8 +116,10 @@ void conv_igemm_kernel(ConvArgs a) {
             c_ok = ld_cc * 32 + chunk * 4 < a.Cin;
             if (GATE) {
 #pragma unroll
-                for (int i = 0; i < AP; ++i)
+                for (int i = 0; i < AP; ++i) {
                     rg[i] = c_ok ? *reinterpret_cast<const float4*>(g_row[i] + ld_cc * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.gate_b) rgb[i] = c_ok ? *reinterpret_cast<const float4*>(g_row[i] + gate_bo + ld_cc * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             if (++ld_q == a.KW) { ld_q = 0; if (++ld_r * a.KW == a.ntaps) { ld_r = 0; ++ld_cc; } }
         }
@@ -149,7 +161,19 @@ void conv_igemm_kernel(ConvArgs a) {
         } else {
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
-                if (GATE) { ra[i].x *= rg[i].x; ra[i].y *= rg[i].y; ra[i].z *= rg[i].z; ra[i].w *= rg[i].w; }
+                if (GATE) {
+                    if (a.gate_b) {      // the preceding GroupNorm's affine + activation, applied on the way to LDS (uniform branches)
+                        float4 t = make_float4(fmaf(ra[i].x, rg[i].x, rgb[i].x), fmaf(ra[i].y, rg[i].y, rgb[i].y),
+                                               fmaf(ra[i].z, rg[i].z, rgb[i].z), fmaf(ra[i].w, rg[i].w, rgb[i].w));
+                        if (a.gate_act == FD_ACT_RELU) {
+                            t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+                        } else if (a.gate_act == FD_ACT_SILU) {
+                            t.x *= __builtin_amdgcn_rcpf(1.0f + __expf(-t.x)); t.y *= __builtin_amdgcn_rcpf(1.0f + __expf(-t.y));
+                            t.z *= __builtin_amdgcn_rcpf(1.0f + __expf(-t.z)); t.w *= __builtin_amdgcn_rcpf(1.0f + __expf(-t.w));
+                        }
+                        ra[i] = t;
+                    } else { ra[i].x *= rg[i].x; ra[i].y *= rg[i].y; ra[i].z *= rg[i].z; ra[i].w *= rg[i].w; }
+                }
                 *reinterpret_cast<float4*>(As + buf * BM * 32 + lds_off(lrow + RPP * i, chunk)) = ra[i];
             }
 #pragma unroll
@@ -298,7 +322,7 @@ int fd_launch_splitk_reduce(const ConvArgs& orig, const float* ws, int nslice, i
     return FD_OK;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false, bool GATE = false>
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false, bool GATE = false, bool GNS = false>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int lds_ab = (SB ? 1 : 2) * (BM + BN) * 32 * 4;
@@ -308,7 +332,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT, GATE>;
+    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT, GATE, GNS>;
     static std::atomic<unsigned> attr_mask{0};       // per kernel instantiation, one bit per device
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles, (a.KT + a.kt_per - 1) / a.kt_per), dim3(NT), lds, stream, b);
@@ -406,12 +430,22 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     }
     a.Cout_epi = a.Cout; a.kt_per = a.KT; a.slice_stride = 0;
     a.p_halo = 0;
-    a.gate = nullptr; a.gate_cs = 0; a.gate_hw = 1;
-    if (p->gate) {       // input gate folded into the loader (MBConv: squeeze-excitation gate -> project conv)
-        FD_REQUIRE(a.is_gemm && p->in.nseg == 1 && p->precision == FD_PREC_F32 && p->ksplit <= 1 && !a.sc_on && p->out_H <= 0, FD_E_UNSUPPORTED,
-                   "fd_conv2d: `gate` needs an fp32 1x1 stride-1 unpadded conv on a single level, no split-K / scatter");
+    a.gate = nullptr; a.gate_cs = 0; a.gate_hw = 1; a.gate_b = nullptr; a.gate_act = FD_ACT_NONE; a.gate_batch = p->in.batch;
+    a.gn_stats = nullptr; a.gn_G = 1; a.gn_cg = 4;
+    if (p->gn_stats) {   // row-group statistics of the stored output (GroupNorm fused into the producer)
+        FD_REQUIRE(p->gn_groups >= 1 && p->Cout % p->gn_groups == 0 && (p->Cout / p->gn_groups) % 4 == 0 && 32 % (p->Cout / p->gn_groups) == 0 &&
+                       p->Cout % 32 == 0 && a.vec_epi && !a.sc_on && p->ksplit <= 1 && p->precision == FD_PREC_F32 && ((uintptr_t)p->gn_stats & 7) == 0,
+                   FD_E_UNSUPPORTED, "fd_conv2d: gn_stats needs fp32, Cout %% 32 == 0, 4 | Cout / groups | 32, 16-byte output views, no split-K / scatter");
+        a.gn_stats = p->gn_stats; a.gn_G = p->gn_groups; a.gn_cg = p->Cout / p->gn_groups;
+    }
+    if (p->gate) {       // input gate folded into the loader (MBConv: squeeze-excitation gate -> project conv; HISFCOSHead: GroupNorm + SiLU -> pw2)
+        FD_REQUIRE(a.is_gemm && p->precision == FD_PREC_F32 && p->ksplit <= 1 && !a.sc_on && p->out_H <= 0 && !p->gn_stats, FD_E_UNSUPPORTED,
+                   "fd_conv2d: `gate` needs an fp32 1x1 stride-1 unpadded conv, no split-K / scatter / gn_stats");
         FD_REQUIRE(p->gate_cs >= p->Cin && p->gate_cs % 4 == 0 && ((uintptr_t)p->gate & 15) == 0, FD_E_INVAL, "fd_conv2d: gate rows must be 16-byte aligned, gate_cs >= Cin");
+        FD_REQUIRE(!p->gate_b || ((((uintptr_t)p->gate_b) & 15) == 0 && (p->gate_act == FD_ACT_NONE || p->gate_act == FD_ACT_RELU || p->gate_act == FD_ACT_SILU)),
+                   FD_E_INVAL, "fd_conv2d: gate_b must be 16-byte aligned, gate_act in {NONE, RELU, SILU}");
         a.gate = p->gate; a.gate_cs = p->gate_cs; a.gate_hw = p->in.H[0] * p->in.W[0];
+        a.gate_b = p->gate_b; a.gate_act = p->gate_b ? p->gate_act : FD_ACT_NONE;
         if (a.Cout <= 32) return launch_conv<4, 1, 1, 1, false, false, 0, false, true>(a, stream);      // 128 x 32
         const long m128 = (a.M + 127) / 128;
         if (a.Cout <= 64) {
@@ -433,7 +467,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     if (p->tile == FD_TILE_128x128_PATCH) {     // 3x3 stride-1 'same' conv with the input patch staged in LDS (fd_conv_patch.hip)
         int wmax = 0;
         for (int sg = 0; sg < p->in.nseg; ++sg) wmax = p->in.W[sg] > wmax ? p->in.W[sg] : wmax;
-        FD_REQUIRE(!stem && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == p->dil && p->ksplit <= 1 && !a.sc_on &&
+        FD_REQUIRE(!stem && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == p->dil && p->ksplit <= 1 && !a.sc_on && !p->gn_stats &&
                        p->out_H <= 0 && FD_PATCH_BM + 2 * p->dil * (wmax + 1) <= FD_PATCH_MAXROWS,
                    FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_128x128_PATCH needs a 3x3 stride-1 'same' conv with 128 + 2*dil*(W+1) <= %d rows (W=%d dil=%d)",
                    FD_PATCH_MAXROWS, wmax, p->dil);
@@ -461,7 +495,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
 
 static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStream_t stream) {
 
-    if (stem) return launch_conv<2, 2, 2, 1, true>(a, stream);       // 128 x 64
+    if (stem) { FD_REQUIRE(!a.gn_stats, FD_E_UNSUPPORTED, "fd_conv2d: gn_stats on the stem"); return launch_conv<2, 2, 2, 1, true>(a, stream); }       // 128 x 64
     if (p->precision == FD_PREC_F16X3) {   // split-f16: 3 f16 MFMAs per fp32 product (weights pre-split by the caller)
         FD_REQUIRE(!stem, FD_E_UNSUPPORTED, "fd_conv2d: the stem runs in exact fp32 only");
         const bool tg = p->tag == 1;
@@ -498,6 +532,16 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
             case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true, 1>(a, stream);
             case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true, 1>(a, stream);
             default: break;  // other tiles keep the shared symbol
+        }
+    }
+    if (a.gn_stats) {   // row-group statistics in the epilogue: dedicated instantiations of the one- / two-sub-tile tiles
+        switch (p->tile) {
+            case FD_TILE_64x64: return launch_conv<2, 2, 1, 1, false, false, 0, false, false, true>(a, stream);
+            case FD_TILE_128x64: return launch_conv<2, 2, 2, 1, false, false, 0, false, false, true>(a, stream);
+            case FD_TILE_64x128: return launch_conv<2, 2, 1, 2, false, false, 0, false, false, true>(a, stream);
+            case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true, 0, false, false, true>(a, stream);
+            case FD_TILE_AUTO: case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true, 0, false, false, true>(a, stream);
+            default: fd_set_error("fd_conv2d: gn_stats is built for tiles 64x64, 128x64(_SB), 64x128(_SB), WAVE64 and WINOGRAD (got %d)", p->tile); return FD_E_UNSUPPORTED;
         }
     }
     {   // GEMM-addressed layers: the persistent kernel (fd_conv_pw.hip)

@@ -29,7 +29,11 @@ struct ConvArgs {
     // output scatter (single level): output pixel (n, i, j) is written to row (n*sc_H + sc_sy*i + sc_oy)*sc_W + sc_sx*j + sc_ox of
     // y (and reads `res` there): one parity class of the data gradient of a strided conv lands interleaved in dX
     int sc_on, sc_sy, sc_sx, sc_oy, sc_ox, sc_H, sc_W;
-    const float* gate; int gate_cs, gate_hw;   // per-(image, input channel) input gate (GATE kernels): [M / gate_hw][gate_cs]
+    const float* gate; int gate_cs, gate_hw;   // per-(image, input channel) input gate (GATE kernels): rows of gate_cs floats, one per (level, image)
+    const float* gate_b; int gate_act, gate_batch;   // GATE kernels: x' = act(x * gate + gate_b) (gate_b NULL: x * gate); images per level
+    // row-group statistics of the STORED output (GroupNorm fused into the producer): gn_stats[m][g] = (sum, sum of squares) of the gn_cg
+    // channels of group g in output row m, fp32 float2; gn_G groups over the conv's Cout channels
+    float* gn_stats; int gn_G, gn_cg;
     int p_halo;    // patch kernel (fd_conv_patch.hip): input rows staged on either side of an M-tile = dil * (max level width + 1)
 };
 
@@ -62,6 +66,20 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Row-group statistics of a lane's four stored channels v (channels nn .. nn+3 of output row m): the gn_cg / 4 lanes that hold one group's
+// channels of this row are adjacent (lane & 7 = 16-byte chunk of the row) -- summed by xor-shuffles in a fixed order, written by the first.
+// EVERY lane of the wave must call it (the shuffles); `ok` only guards the store.
+__device__ __forceinline__ void fd_gn_rowstats(float* gn_stats, int gn_G, int gn_cg, const float4& v, size_t m, int nn, int lane, bool ok) {
+    float s1 = (v.x + v.y) + (v.z + v.w);
+    float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    const int cgq = gn_cg >> 2;                   // 1, 2, 4 or 8 lanes per group (uniform)
+    if (cgq > 1) { s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1); }
+    if (cgq > 2) { s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2); }
+    if (cgq > 4) { s1 += __shfl_xor(s1, 4); s2 += __shfl_xor(s2, 4); }
+    if (ok && ((lane & 7) & (cgq - 1)) == 0)
+        reinterpret_cast<float2*>(gn_stats)[m * gn_G + nn / gn_cg] = make_float2(s1, s2);
 }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
             if (++tq == 3) { tq = 0; ++tr; }
         }
     }
+    constexpr bool GNS = false;
 #include "fd_conv_epilogue.inc"
 }
 

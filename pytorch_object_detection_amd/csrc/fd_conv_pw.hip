@@ -134,6 +134,7 @@ void conv1x1_persist_kernel(ConvArgs a) {
         mfma_tile(SB ? 0 : ((a.KT - 1) & 1));
         __syncthreads();                 // the A / B buffers are free: the epilogue's per-wave stage overlays them
 #define FD_EPI_RES_PREFETCHED
+    constexpr bool GNS = false;
 #include "fd_conv_epilogue.inc"
 #undef FD_EPI_RES_PREFETCHED
         if (!more) break;

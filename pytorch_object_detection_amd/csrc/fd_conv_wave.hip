@@ -186,7 +186,9 @@ __global__ __launch_bounds__(64, 3) void conv1x1_wave_kernel(ConvArgs a, const f
                     v.z = fd_act(v.z, FD_ACT_SILU, 0.f); v.w = fd_act(v.w, FD_ACT_SILU, 0.f);
                 }
             }
-            if (mb + prow + 8 * p < a.M) *reinterpret_cast<float4*>(yp + p * ystep) = v;
+            const bool st_ok = mb + prow + 8 * p < a.M;
+            if (st_ok) *reinterpret_cast<float4*>(yp + p * ystep) = v;
+            if (a.gn_stats) fd_gn_rowstats(a.gn_stats, a.gn_G, a.gn_cg, v, (size_t)(mb + prow + 8 * p), nb + c4, lane, st_ok);
         }
         wave_lds_sync();
     }

@@ -38,6 +38,7 @@ struct WinoArgs {
     int nc_per;                   // 8-channel chunks per split-K slice (blockIdx.y = slice; NC when split-K is off)
     long slice_stride;            // elements between consecutive split-K slabs of the workspace y points to
     unsigned x_bytes, u_bytes;
+    float* gn_stats; int gn_G, gn_cg;   // row-group statistics of the stored output (fd_conv_common.h: fd_gn_rowstats)
 };
 
 #define WINO_TB 32     // tiles per workgroup
@@ -306,6 +307,13 @@ int fd_launch_conv_wino(const fd_conv_params* p, hipStream_t stream) {
     a.x_cs = p->x_cs; a.x_co = p->x_co; a.res_cs = p->res_cs; a.res_co = p->res_co; a.y_cs = p->y_cs; a.y_co = p->y_co;
     a.Cin = p->Cin; a.Cout = p->Cout; a.dil = p->dil; a.act = p->act; a.act_c0 = p->act_c0;
     a.res_mask = (p->res && p->res_mode == 1) ? 1 : 0;
+    a.gn_stats = nullptr; a.gn_G = 1; a.gn_cg = 4;
+    if (p->gn_stats) {
+        FD_REQUIRE(p->gn_groups >= 1 && p->Cout % p->gn_groups == 0 && (p->Cout / p->gn_groups) % 4 == 0 && 32 % (p->Cout / p->gn_groups) == 0 &&
+                       p->Cout % 32 == 0 && p->ksplit <= 1 && ((uintptr_t)p->gn_stats & 7) == 0,
+                   FD_E_UNSUPPORTED, "fd_conv2d: gn_stats needs Cout %% 32 == 0, 4 | Cout / groups | 32, no split-K");
+        a.gn_stats = p->gn_stats; a.gn_G = p->gn_groups; a.gn_cg = p->Cout / p->gn_groups;
+    }
     a.NC = p->Cin / 8;
     a.nseg = p->in.nseg;
     long t = 0;

@@ -368,11 +368,17 @@ struct StripTab {
     int spr[FD_MAX_SEG];                // strips per image row = ceil(W / S)
 };
 
-template <int S>
+// FUSE: GroupNorm around the conv (HISFCOSHead: pw1 -> GN1 -> ReLU -> dw1 -> GN2 -> SiLU -> pw2).  in_coef [levels * batch][2][C] = the
+// preceding GroupNorm's per-(level, image, channel) affine (a, b): every in-image input pixel is read as in_act(x * a + b) -- the zero
+// padding stays zero, the reference pads the NORMALISED map -- and gn_stats[m][g] receives the (sum, sum of squares) of the gn_cg
+// channels of group g of output pixel m (fp32 float2, fixed order: the cg / 4 adjacent threads of a pixel are combined by xor-shuffles).
+template <int S, bool FUSE = false>
 __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const float* __restrict__ x, int x_cs, int x_co,
                                                                const float* __restrict__ wt, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, float* __restrict__ y, int y_cs,
-                                                               int y_co, int C, int act, StripTab tab, long total) {
+                                                               int y_co, int C, int act, StripTab tab, long total,
+                                                               const float* __restrict__ in_coef = nullptr, int in_act = 0,
+                                                               float* __restrict__ gn_stats = nullptr, int gn_G = 1) {
     const int C4 = C >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         int q;
@@ -388,6 +394,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const float* __res
         const long n = fd_div(local, per_img, rem);
         const int h = rem / spr, w0 = (rem - h * spr) * S;
         const long r0 = (long)tab.s.m_start[s] + n * H * W;
+        float4 ca = make_float4(1.f, 1.f, 1.f, 1.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FUSE && in_coef) {
+            const float* cp = in_coef + ((long)(s * tab.s.batch + (int)n) * 2) * C + 4 * q;
+            ca = *reinterpret_cast<const float4*>(cp);
+            cb = *reinterpret_cast<const float4*>(cp + C);
+        }
         float4 acc[S];
 #pragma unroll
         for (int j = 0; j < S; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -401,6 +413,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const float* __res
                 const int wi = w0 + c - 1;
                 u[c] = (unsigned)wi < (unsigned)W ? *reinterpret_cast<const float4*>(x + (r0 + (long)hi * W + wi) * x_cs + x_co + 4 * q)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (FUSE && in_coef && (unsigned)wi < (unsigned)W) {
+                    u[c].x = fd_act(u[c].x * ca.x + cb.x, in_act, 0.f); u[c].y = fd_act(u[c].y * ca.y + cb.y, in_act, 0.f);
+                    u[c].z = fd_act(u[c].z * ca.z + cb.z, in_act, 0.f); u[c].w = fd_act(u[c].w * ca.w + cb.w, in_act, 0.f);
+                }
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -424,7 +440,16 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const float* __res
             float4 o;
             o.x = fd_act(acc[j].x * sc.x + sf.x, act, 0.f); o.y = fd_act(acc[j].y * sc.y + sf.y, act, 0.f);
             o.z = fd_act(acc[j].z * sc.z + sf.z, act, 0.f); o.w = fd_act(acc[j].w * sc.w + sf.w, act, 0.f);
-            *reinterpret_cast<float4*>(y + (r0 + (long)h * W + w0 + j) * y_cs + y_co + 4 * q) = o;
+            const long mo = r0 + (long)h * W + w0 + j;
+            *reinterpret_cast<float4*>(y + mo * y_cs + y_co + 4 * q) = o;
+            if (FUSE && gn_stats) {
+                // the cg / 4 threads that hold one group's channels of this pixel are adjacent lanes (q is the fastest index, C4 a multiple
+                // of cg / 4 and of ... see the host checks): all of them are here together (same strip, same j)
+                float s1 = (o.x + o.y) + (o.z + o.w), s2 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                const int cgq = (C / gn_G) >> 2;
+                for (int d = 1; d < cgq; d <<= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+                if ((q & (cgq - 1)) == 0) reinterpret_cast<float2*>(gn_stats)[mo * gn_G + (4 * q) / (C / gn_G)] = make_float2(s1, s2);
+            }
         }
     }
 }
@@ -454,6 +479,41 @@ extern "C" int32_t fd_dwconv3x3_nhwc(const float* x, int32_t x_cs, int32_t x_co,
         hipLaunchKernelGGL(dwconv3x3_strip_kernel<4>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co,
                            w, scale, shift, y, y_cs, y_co, C, act, tab, total);
     FD_CHECK_LAUNCH("fd_dwconv3x3_nhwc");
+    return FD_OK;
+}
+
+extern "C" int32_t fd_dwconv3x3_gn_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w, const float* in_coef, int32_t in_act,
+                                        float* y, int32_t y_cs, int32_t y_co, int32_t C, float* gn_stats, int32_t gn_groups,
+                                        const fd_segs* segs, fd_stream_t stream) {
+    FD_REQUIRE(fd_segs_ok(segs), FD_E_INVAL, "fd_dwconv3x3_gn: bad segment table");
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C) && w && ((uintptr_t)w & 15) == 0, FD_E_INVAL,
+               "fd_dwconv3x3_gn: channel views must be 4-aligned (C=%d)", C);
+    FD_REQUIRE(!in_coef || (((uintptr_t)in_coef & 15) == 0 && (in_act == FD_ACT_NONE || in_act == FD_ACT_RELU || in_act == FD_ACT_SILU)), FD_E_INVAL,
+               "fd_dwconv3x3_gn: in_coef must be 16-byte aligned, in_act in {NONE, RELU, SILU}");
+    if (gn_stats) {
+        const int cg = gn_groups >= 1 && C % gn_groups == 0 ? C / gn_groups : 0;
+        // a group's cg / 4 threads must sit in one wave, aligned: C / 4 a multiple of 64 (or a divisor of 64) keeps a pixel's quads wave-aligned
+        FD_REQUIRE(cg >= 4 && cg % 4 == 0 && 32 % cg == 0 && (((C / 4) % 64 == 0) || (64 % (C / 4) == 0)) && ((uintptr_t)gn_stats & 7) == 0,
+                   FD_E_UNSUPPORTED, "fd_dwconv3x3_gn: gn_stats needs 4 | C / groups | 32 and C / 4 a multiple or divisor of 64 (C=%d groups=%d)", C, gn_groups);
+    }
+    StripTab tab; tab.s = *segs;
+    const int S = (long)segs->m_start[segs->nseg] * (C / 4) >= (16L << 20) ? 8 : 4;
+    long strips = 0;
+    for (int s = 0; s < FD_MAX_SEG; ++s) {
+        tab.strip_start[s] = strips;
+        tab.spr[s] = s < segs->nseg ? (segs->W[s] + S - 1) / S : 1;
+        if (s < segs->nseg) strips += (long)segs->batch * segs->H[s] * tab.spr[s];
+    }
+    tab.strip_start[FD_MAX_SEG] = strips;
+    const long total = strips * (C / 4);
+    // whole waves only: the shuffles of the statistics need every lane of a group active (the grid-stride loop keeps wave-aligned i)
+    if (S == 8)
+        hipLaunchKernelGGL((dwconv3x3_strip_kernel<8, true>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co,
+                           w, (const float*)nullptr, (const float*)nullptr, y, y_cs, y_co, C, FD_ACT_NONE, tab, total, in_coef, in_act, gn_stats, gn_groups);
+    else
+        hipLaunchKernelGGL((dwconv3x3_strip_kernel<4, true>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co,
+                           w, (const float*)nullptr, (const float*)nullptr, y, y_cs, y_co, C, FD_ACT_NONE, tab, total, in_coef, in_act, gn_stats, gn_groups);
+    FD_CHECK_LAUNCH("fd_dwconv3x3_gn_nhwc");
     return FD_OK;
 }
 
@@ -788,6 +848,97 @@ extern "C" int32_t fd_groupnorm_act_nhwc(const float* x, int32_t x_cs, int32_t x
     hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, imgs), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, gamma, beta, y,
                        y_cs, y_co, C, G, eps, act, tab, (const double*)gstat);
     FD_CHECK_LAUNCH("fd_groupnorm (apply)");
+    return FD_OK;
+}
+
+// ---- GroupNorm statistics from the producer's row-group sums (fd_conv_params.gn_stats / fd_dwconv3x3_gn_nhwc): rgs[m][g] = (sum, sum of
+// squares) of group g's channels in row m.  Same two steps as above with the 8x .. 32x smaller rgs in place of the map: chunk partials
+// in fp64 (fixed order) in the layout gn_finalize_kernel reads, then (mean, rstd) per (level, image, group) -- so gn_apply_kernel, the
+// backward and fd_batchnorm_update_running work on the result unchanged -- and optionally the per-(level, image, channel) affine
+// coef[img][0][c] = rstd * gamma[c], coef[img][1][c] = beta[c] - mean * rstd * gamma[c] for a consumer that normalises in its loader.
+__global__ __launch_bounds__(256) void gn_rowstats_partial_kernel(const float* __restrict__ rgs, int G, SegTab tab, double* __restrict__ part) {
+    __shared__ double s_p[256];
+    const int img = blockIdx.y;
+    const int s = img / tab.s.batch, n = img - s * tab.s.batch;
+    const int HW = tab.s.H[s] * tab.s.W[s];
+    const int nchunk = min(GN_MAXCHUNK, (HW + 63) / 64);
+    const int chunk = blockIdx.x;
+    if (chunk >= nchunk) return;
+    const int rows_per = (HW + nchunk - 1) / nchunk;
+    const int r_begin = chunk * rows_per, r_end = min(HW, r_begin + rows_per);
+    const int cols = 2 * G, RT = 256 / cols;                 // (host: 2 G divides 256)
+    const int tid = threadIdx.x, col = tid % cols, rt = tid / cols;
+    const float* base = rgs + ((long)tab.s.m_start[s] + (long)n * HW) * cols + col;
+    double acc = 0;
+    int r = r_begin + rt;
+    for (; r + 3 * RT < r_end; r += 4 * RT) {
+        const float v0 = base[(long)r * cols], v1 = base[(long)(r + RT) * cols], v2 = base[(long)(r + 2 * RT) * cols], v3 = base[(long)(r + 3 * RT) * cols];
+        acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; r < r_end; r += RT) acc += base[(long)r * cols];
+    s_p[tid] = acc;
+    __syncthreads();
+    if (tid < cols) {
+        double a = 0;
+        for (int k = 0; k < RT; ++k) a += s_p[k * cols + tid];
+        part[((long)img * GN_MAXCHUNK + chunk) * cols + tid] = a;      // = part[(img, chunk, g)][k], col = 2 g + k
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__ gstat, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int C, int G, float* __restrict__ coef) {
+    const int img = blockIdx.x, cg = C / G;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double* p = gstat + ((long)img * G + c / cg) * 2;
+        const float sc = (float)p[1] * gamma[c];
+        coef[((long)img * 2) * C + c] = sc;
+        coef[((long)img * 2 + 1) * C + c] = beta[c] - (float)p[0] * sc;       // the arithmetic of gn_apply_kernel
+    }
+}
+
+extern "C" int32_t fd_groupnorm_from_rowstats(const float* rowstats, int32_t C, int32_t G, float eps, const float* gamma, const float* beta,
+                                              const fd_segs* segs, void* workspace, float* coef, fd_stream_t stream) {
+    FD_REQUIRE(fd_segs_ok(segs) && rowstats && workspace, FD_E_INVAL, "fd_groupnorm_from_rowstats: bad argument");
+    FD_REQUIRE(G >= 1 && C % G == 0 && 256 % (2 * G) == 0, FD_E_UNSUPPORTED, "fd_groupnorm_from_rowstats: 2 * groups must divide 256 (C=%d G=%d)", C, G);
+    FD_REQUIRE(!coef || (gamma && beta && ((uintptr_t)coef & 15) == 0 && C % 4 == 0), FD_E_INVAL, "fd_groupnorm_from_rowstats: coef needs gamma, beta, 16-byte alignment");
+    FD_REQUIRE((long)segs->nseg * segs->batch <= 65535, FD_E_UNSUPPORTED, "fd_groupnorm_from_rowstats: too many (level, image) pairs");
+    SegTab tab; tab.s = *segs;
+    const int imgs = segs->nseg * segs->batch;
+    int maxhw = 0;
+    for (int s = 0; s < segs->nseg; ++s) maxhw = max(maxhw, segs->H[s] * segs->W[s]);
+    const int nchunk = min(GN_MAXCHUNK, (maxhw + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_rowstats_partial_kernel, dim3(nchunk, imgs), dim3(256), 0, st, rowstats, G, tab, (double*)workspace);
+    FD_CHECK_LAUNCH("fd_groupnorm_from_rowstats (partial)");
+    double* gstat = (double*)workspace + (long)imgs * GN_MAXCHUNK * G * 2;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((G + 15) / 16, imgs), dim3(256), 0, st, C, G, eps, tab, (const double*)workspace, gstat);
+    FD_CHECK_LAUNCH("fd_groupnorm_from_rowstats (finalize)");
+    if (coef) {
+        hipLaunchKernelGGL(gn_coef_kernel, dim3(imgs), dim3(256), 0, st, (const double*)gstat, gamma, beta, C, G, coef);
+        FD_CHECK_LAUNCH("fd_groupnorm_from_rowstats (coef)");
+    }
+    return FD_OK;
+}
+
+// normalise + affine + activation from statistics already in `workspace` (fd_groupnorm_from_rowstats, or a previous fd_groupnorm_act_nhwc)
+extern "C" int32_t fd_groupnorm_apply_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* gamma, const float* beta, float* y,
+                                           int32_t y_cs, int32_t y_co, int32_t C, int32_t G, float eps, int32_t act, const fd_segs* segs,
+                                           const void* workspace, fd_stream_t stream) {
+    FD_REQUIRE(fd_segs_ok(segs), FD_E_INVAL, "fd_groupnorm_apply: bad segment table");
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C) && gamma && beta && workspace, FD_E_INVAL,
+               "fd_groupnorm_apply: bad pointer / channel view (C=%d)", C);
+    FD_REQUIRE(G >= 1 && C % G == 0 && C <= 1024 && 256 % (C / 4) == 0, FD_E_UNSUPPORTED,
+               "fd_groupnorm_apply: C=%d G=%d unsupported (C/4 must divide 256, C <= 1024)", C, G);
+    FD_REQUIRE((long)segs->nseg * segs->batch <= 65535, FD_E_UNSUPPORTED, "fd_groupnorm_apply: too many (level, image) pairs");
+    SegTab tab; tab.s = *segs;
+    const int imgs = segs->nseg * segs->batch;
+    int maxhw = 0;
+    for (int s = 0; s < segs->nseg; ++s) maxhw = max(maxhw, segs->H[s] * segs->W[s]);
+    const double* gstat = (const double*)workspace + (long)imgs * GN_MAXCHUNK * G * 2;
+    const int ablk = max(1, min(imgs >= 16 ? 64 : 512, (maxhw * (C / 4) + 2047) / 2048));
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, imgs), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, gamma, beta, y, y_cs, y_co, C, G, eps,
+                       act, tab, gstat);
+    FD_CHECK_LAUNCH("fd_groupnorm_apply_nhwc");
     return FD_OK;
 }
 

@@ -33,6 +33,7 @@ AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see 
 # (ops.wino_preferred: it has no split-K); "force" = wherever it applies; "0" = every conv on the direct implicit-GEMM kernel
 WINOGRAD = _os.environ.get("FD_WINOGRAD", "1") != "0"
 SE_GATE_IN_PROJECT = _os.environ.get("FD_SE_GATE_FUSED", "1") != "0"     # MBConv: SE gate applied by the project conv's loader ("0": a scaling pass)
+GN_FUSED = _os.environ.get("FD_GN_FUSED", "1") != "0"       # "0": HISFCOSHead's GroupNorms as three-pass launches (statistics / finalise / normalise)
 WAVE_TILE = _os.environ.get("FD_WAVE_TILE", "1") != "0"       # "0": the 1x1 layers never see FD_TILE_WAVE64 (wave-autonomous tiles, fd_conv_wave.hip)
 STEM_KERNEL = _os.environ.get("FD_STEM_KERNEL", "1") != "0"     # "0": the ResNet stem through the generic conv kernel's FD_CONV_STEM mode
 
@@ -136,7 +137,8 @@ def padded_input(plan: Plan, rows: int, C: int):
 def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, y: Rows, *, bn=None, act=ACT_NONE,
              res: Optional[Rows] = None, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
              Cout: Optional[int] = None, act_c0: int = 0, seg_param=None, tag: int = 0, fold=None,
-             gate: Optional[torch.Tensor] = None) -> Segs:
+             gate: Optional[torch.Tensor] = None, gate_b: Optional[torch.Tensor] = None, gate_act: int = ACT_NONE,
+             gn_stats: Optional[torch.Tensor] = None, gn_groups: int = 0) -> Segs:
     """conv (+folded BN / bias) (+res) (+act).  `weight`/`bias` override conv's own (fused multi-conv launches);
     `fold` = (scale, shift) overrides the epilogue constants altogether (convs with different BN / bias merged by hand)."""
     dev = plan.device
@@ -181,14 +183,19 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     out = ops.conv_out_segs(segs, k, stride, pad, dil)
     # split-K scratch: taken from the pool and handed straight back (stream order makes the sharing safe)
     ws_rows = ops.KSPLIT_MAX * out.rows
-    if wino:
+    if gn_stats is not None:
+        if wino and wino_ks > 1:
+            raise FdError("add_conv: gn_stats with a split-K Winograd launch (the caller checks ops.wino_choice first)")
+        ws = None                  # (row-group statistics come out of the conv's own epilogue: no split-K, whose combine launch has none)
+    elif wino:
         ws = plan.pool.get(wino_ks * out.rows, (co + 3) & ~3) if wino_ks > 1 else None
     else:
         ws = plan.pool.get(ws_rows, (co + 3) & ~3) if (plan.autotune and ws_rows * ((co + 3) & ~3) <= 64 * 1024 * 1024) else None
     call = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                          shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param, tag=tag,
                          precision=1 if split else 0, workspace=ws.buf if ws is not None else None,
-                         tile=_lib.WINO_TILE if wino else 0, ksplit=wino_ks if wino else 1, gate=gate, w_frag=wfrag)
+                         tile=_lib.WINO_TILE if wino else 0, ksplit=wino_ks if wino else 1, gate=gate, w_frag=wfrag,
+                         gate_b=gate_b, gate_act=gate_act, gn_stats=gn_stats, gn_groups=gn_groups)
     plan.add(name, call)
     if ws is not None:
         plan.pool.put(ws)
@@ -202,6 +209,8 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         if split:
             key = "f16x3|" + key
         plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co, -(-Cin // 32) * k * k, pair=plan.pair_tuned and tag != 1)
+        if gn_stats is not None and (plan.tiles[name] & 0xFF) not in (0, 2, 3, 4, 8, 9, _lib.WAVE_TILE):
+            call.params.tile = plan.tiles[name] = 8      # the statistics epilogue exists for the one- / two-sub-tile tiles (and WAVE64 / Winograd)
     plan.flops += 2 * out.rows * co * Cin * k * k
     plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k
     plan.step_info[len(plan.steps) - 1] = {"k": k, "stride": stride, "dil": dil, "Cin": Cin, "Cout": co, "rows": out.rows,
@@ -521,30 +530,83 @@ def _fused_gn(plan: Plan, name: str, x: Rows, segs: Segs, gns, act: int) -> None
     plan.add(name, lambda: ops.groupnorm_act(x, gamma, beta, x, segs, G, act, ws, eps))
 
 
+def _gn_fusable(plan: Plan, gns, Cc: int) -> bool:
+    """GroupNorm(s) over Cc channels whose statistics the producer's epilogue can emit and fd_groupnorm_from_rowstats reduce."""
+    G = sum(g.num_groups for g in gns)
+    cg = Cc // G if G and Cc % G == 0 else 0
+    return (GN_FUSED and plan.precision == "f32" and all(g.num_channels // g.num_groups == cg for g in gns) and cg in (4, 8, 16, 32)
+            and Cc % 32 == 0 and 256 % (2 * G) == 0 and Cc <= 1024 and 256 % (Cc // 4) == 0 and ((Cc // 4) % 64 == 0 or 64 % (Cc // 4) == 0))
+
+
+def _gn_from_rowstats(plan: Plan, name: str, rgs, segs: Segs, gns, Cc: int, want_coef: bool):
+    """The reduction step behind a producer that left row-group sums in `rgs`: -> (workspace, gamma, beta, G, eps, coef | None)."""
+    dev = plan.device
+    gamma = torch.cat([_dev(g.weight, dev) for g in gns]).contiguous()
+    beta = torch.cat([_dev(g.bias, dev) for g in gns]).contiguous()
+    G, eps = sum(g.num_groups for g in gns), gns[0].eps
+    ws = ops.groupnorm_workspace(segs, G, dev)
+    coef = torch.empty(segs.nseg * segs.batch, 2, Cc, dtype=torch.float32, device=dev) if want_coef else None
+    plan.keep += [gamma, beta, ws, coef]
+    plan.add(name, lambda: ops.groupnorm_from_rowstats(rgs.buf, Cc, G, eps, gamma, beta, segs, ws, coef))
+    return ws, gamma, beta, G, eps, coef
+
+
 def build_his_head(plan: Plan, head, pyr: Rows, segs: Segs):
-    """HISFCOSHead.forward (HISFcos.py:211-229), all levels in one launch per layer."""
+    """HISFCOSHead.forward (HISFcos.py:211-229), all levels in one launch per layer.
+
+    GroupNorm is folded into its neighbours (FD_GN_FUSED=1, exact-fp32 plans): the producing conv's epilogue leaves per-row group sums
+    (fd_conv_params.gn_stats), a small reduction turns them into per-(level, image) statistics, and the CONSUMER normalises on its way in
+    -- dw1 reads ReLU(GN1(.)) in its window loads, pw2 reads SiLU(GN2(.)) in its operand loader -- so the pre-block is
+    pw1 | dw1 | pw2 over HBM (4 passes over a 512-channel map instead of 10).  The tower's GroupNorm keeps its one normalise pass
+    (its consumers are the Winograd predictors) but loses its statistics pass."""
     dev, pool = plan.device, plan.pool
     M = segs.rows
     F = head.pw1.weight.shape[1]
     ncls = head.cls_logits.weight.shape[0]
-    h1 = pool.get(M, 2 * F)
-    add_conv(plan, "head.pw1", pyr, segs, head.pw1, h1)
-    _fused_gn(plan, "head.gn1", h1, segs, [head.gn1], ACT_RELU)
-    h2 = pool.get(M, 2 * F)
     wd = ops.pack_dw_weight(_dev(head.dw1.weight, dev))
     plan.keep.append(wd)
-    plan.add("head.dw1", lambda: ops.dwconv3x3(h1, wd, h2, segs, None, None, ACT_NONE))
-    _fused_gn(plan, "head.gn2", h2, segs, [head.gn2], ACT_SILU)
-    pool.put(h1)
-    z = pool.get(M, F)
-    add_conv(plan, "head.pw2", h2, segs, head.pw2, z, res=pyr)
+    pre_fused = _gn_fusable(plan, [head.gn1], 2 * F) and _gn_fusable(plan, [head.gn2], 2 * F) and head.dw1.bias is None
+    h1 = pool.get(M, 2 * F)
+    if pre_fused:
+        G1, G2 = head.gn1.num_groups, head.gn2.num_groups
+        rgs1 = pool.get(M, 2 * G1)
+        add_conv(plan, "head.pw1", pyr, segs, head.pw1, h1, gn_stats=rgs1.buf, gn_groups=G1)
+        coef1 = _gn_from_rowstats(plan, "head.gn1.stats", rgs1, segs, [head.gn1], 2 * F, True)[5]
+        pool.put(rgs1)
+        h2 = pool.get(M, 2 * F)
+        rgs2 = pool.get(M, 2 * G2)
+        plan.add("head.dw1", lambda: ops.dwconv3x3_gn(h1, wd, h2, segs, coef1, ACT_RELU, rgs2.buf, G2))
+        coef2 = _gn_from_rowstats(plan, "head.gn2.stats", rgs2, segs, [head.gn2], 2 * F, True)[5]
+        pool.put(rgs2); pool.put(h1)
+        z = pool.get(M, F)
+        add_conv(plan, "head.pw2", h2, segs, head.pw2, z, res=pyr, gate=coef2[:, 0], gate_b=coef2[:, 1], gate_act=ACT_SILU)
+    else:
+        add_conv(plan, "head.pw1", pyr, segs, head.pw1, h1)
+        _fused_gn(plan, "head.gn1", h1, segs, [head.gn1], ACT_RELU)
+        h2 = pool.get(M, 2 * F)
+        plan.add("head.dw1", lambda: ops.dwconv3x3(h1, wd, h2, segs, None, None, ACT_NONE))
+        _fused_gn(plan, "head.gn2", h2, segs, [head.gn2], ACT_SILU)
+        pool.put(h1)
+        z = pool.get(M, F)
+        add_conv(plan, "head.pw2", h2, segs, head.pw2, z, res=pyr)
     pool.put(h2)
     tower = pool.get(M, 2 * F)
     w = torch.cat([head.cls_conv[0].weight.detach(), head.reg_conv[0].weight.detach()], 0)
+    tgn = [head.cls_conv[1], head.reg_conv[1]]
+    t_fused = (_gn_fusable(plan, tgn, 2 * F) and plan.winograd and ops.wino_ok(F, 2 * F, 3, 1, 1, 1) and ops.wino_choice(segs, F, 2 * F, 1)[1] == 1)
     mark = len(plan.steps)
-    add_conv(plan, "head.tower3x3", z, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F, tag=1)
-    plan.marks["head.tower3x3"] = (mark, len(plan.steps))
-    _fused_gn(plan, "head.tower_gn", tower, segs, [head.cls_conv[1], head.reg_conv[1]], ACT_RELU)
+    if t_fused:
+        Gt = sum(g.num_groups for g in tgn)
+        rgs3 = pool.get(M, 2 * Gt)
+        add_conv(plan, "head.tower3x3", z, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F, tag=1, gn_stats=rgs3.buf, gn_groups=Gt)
+        plan.marks["head.tower3x3"] = (mark, len(plan.steps))
+        ws, gamma, beta, G, eps, _ = _gn_from_rowstats(plan, "head.tower_gn.stats", rgs3, segs, tgn, 2 * F, False)
+        pool.put(rgs3)
+        plan.add("head.tower_gn", lambda: ops.groupnorm_apply(tower, gamma, beta, tower, segs, G, ACT_RELU, ws, eps))
+    else:
+        add_conv(plan, "head.tower3x3", z, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F, tag=1)
+        plan.marks["head.tower3x3"] = (mark, len(plan.steps))
+        _fused_gn(plan, "head.tower_gn", tower, segs, tgn, ACT_RELU)
     pool.put(z)
     return _out_convs(plan, head, tower, segs, F, ncls)
 

@@ -168,7 +168,8 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
               tag: int = 0, precision: int = 0, ksplit: int = 1,
               workspace: Optional[torch.Tensor] = None, res_mask: bool = False, kw: Optional[int] = None,
               out_hw: Optional[Tuple[int, int]] = None, scatter: Optional[Tuple[int, int, int, int, int, int]] = None,
-              gate: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None) -> Callable[[], None]:
+              gate: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None, gn_stats: Optional[torch.Tensor] = None,
+              gn_groups: int = 0, gate_b: Optional[torch.Tensor] = None, gate_act: int = ACT_NONE) -> Callable[[], None]:
     """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream.
     w_frag: the same weights in FD_TILE_WAVE64's fragment order (pack_conv_weight_wave), which makes that tile selectable."""
     _need_gpu(w_packed, scale, shift)
@@ -188,11 +189,20 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     p.act, p.act_c0, p.mode = act, act_c0, (_lib.CONV_STEM if stem else _lib.CONV_GENERIC)
     p.tile, p.tag, p.precision, p.ksplit = tile, tag, precision, ksplit
     p.res_mode = 1 if (res_mask and res is not None) else 0
-    if gate is not None:             # [batch, >= Cin] fp32: per-(image, input channel) gate applied in the loader (1x1 convs)
-        _need_gpu(gate)
-        if gate.dim() != 2 or gate.shape[0] != segs.batch or gate.stride(1) != 1 or gate.dtype != torch.float32:
-            raise FdError("conv gate must be a [batch, C] fp32 tensor with unit channel stride")
+    if gate is not None:             # [levels * batch, >= Cin] fp32: per-(level, image, input channel) gate applied in the loader (1x1 convs)
+        _need_gpu(gate, gate_b)
+        if gate.dim() != 2 or gate.shape[0] != segs.batch * segs.nseg or gate.stride(1) != 1 or gate.dtype != torch.float32:
+            raise FdError("conv gate must be a [levels * batch, C] fp32 tensor with unit channel stride")
         p.gate, p.gate_cs = gate.data_ptr(), gate.stride(0)
+        if gate_b is not None:       # x' = gate_act(x * gate + gate_b): the preceding GroupNorm's affine + activation (groupnorm_from_rowstats coef)
+            if gate_b.shape != gate.shape or gate_b.stride() != gate.stride() or gate_b.dtype != torch.float32:
+                raise FdError("conv gate_b must have gate's shape and strides")
+            p.gate_b, p.gate_act = gate_b.data_ptr(), gate_act
+    if gn_stats is not None:         # [rows, gn_groups, 2] fp32: row-group (sum, sum of squares) of the stored output (GroupNorm fused into the producer)
+        _need_gpu(gn_stats)
+        if gn_stats.dtype != torch.float32 or not gn_stats.is_contiguous() or gn_stats.numel() < y.rows * gn_groups * 2:
+            raise FdError("conv gn_stats must be a contiguous fp32 buffer of rows x gn_groups x 2")
+        p.gn_stats, p.gn_groups = gn_stats.data_ptr(), gn_groups
     if w_frag is not None:
         _need_gpu(w_frag)
         p.w_frag = w_frag.data_ptr()
@@ -205,7 +215,7 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     p.segs = segs
     fn = _lib.lib().fd_conv2d_nhwc_f32
     ref = C.byref(p)
-    keep = (x, w_packed, y, scale, shift, res, p, workspace, gate, w_frag)
+    keep = (x, w_packed, y, scale, shift, res, p, workspace, gate, w_frag, gn_stats, gate_b)
 
     def run(_keep=keep):
         check(fn(ref, _stream()), "fd_conv2d_nhwc_f32")
@@ -642,6 +652,33 @@ def groupnorm_act(x: Rows, gamma: torch.Tensor, beta: torch.Tensor, y: Rows, seg
                   ws: torch.Tensor, eps: float = 1e-5) -> None:
     check(_lib.lib().fd_groupnorm_act_nhwc(x.ptr, x.cs, x.co, gamma.data_ptr(), beta.data_ptr(), y.ptr, y.cs, y.co, x.C,
                                            G, eps, act, C.byref(segs), ws.data_ptr(), _stream()), "fd_groupnorm_act_nhwc")
+
+
+def groupnorm_from_rowstats(rowstats: torch.Tensor, Cc: int, G: int, eps: float, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor],
+                            segs: Segs, ws: torch.Tensor, coef: Optional[torch.Tensor] = None) -> None:
+    """Row-group sums left by a producer (conv_call(gn_stats=...), dwconv3x3_gn) -> GroupNorm statistics per (level, image, group) in `ws`
+    (groupnorm_workspace layout) and, with `coef` [levels * batch, 2, C], the affine (rstd * gamma, beta - mean * rstd * gamma) a consumer
+    applies in its loader."""
+    _need_gpu(rowstats, ws, coef, gamma, beta)
+    check(_lib.lib().fd_groupnorm_from_rowstats(rowstats.data_ptr(), Cc, G, eps, gamma.data_ptr() if gamma is not None else None,
+                                                beta.data_ptr() if beta is not None else None, C.byref(segs), ws.data_ptr(),
+                                                coef.data_ptr() if coef is not None else None, _stream()), "fd_groupnorm_from_rowstats")
+
+
+def groupnorm_apply(x: Rows, gamma: torch.Tensor, beta: torch.Tensor, y: Rows, segs: Segs, G: int, act: int, ws: torch.Tensor, eps: float = 1e-5) -> None:
+    """y = act(GroupNorm(x)) from statistics already in `ws` (groupnorm_from_rowstats / an earlier groupnorm_act): one pass over the map."""
+    check(_lib.lib().fd_groupnorm_apply_nhwc(x.ptr, x.cs, x.co, gamma.data_ptr(), beta.data_ptr(), y.ptr, y.cs, y.co, x.C, G, eps, act,
+                                             C.byref(segs), ws.data_ptr(), _stream()), "fd_groupnorm_apply_nhwc")
+
+
+def dwconv3x3_gn(x: Rows, w9c: torch.Tensor, y: Rows, segs: Segs, in_coef: Optional[torch.Tensor], in_act: int,
+                 gn_stats: Optional[torch.Tensor], gn_groups: int) -> None:
+    """Depthwise 3x3 (stride 1, pad 1, no bias) that reads its input as in_act(x * a + b) (in_coef [levels * batch, 2, C] from
+    groupnorm_from_rowstats; the zero padding applies to the normalised map) and leaves the row-group sums of its output in gn_stats."""
+    _need_gpu(w9c, in_coef, gn_stats)
+    check(_lib.lib().fd_dwconv3x3_gn_nhwc(x.ptr, x.cs, x.co, w9c.data_ptr(), in_coef.data_ptr() if in_coef is not None else None, in_act,
+                                          y.ptr, y.cs, y.co, x.C, gn_stats.data_ptr() if gn_stats is not None else None, gn_groups,
+                                          C.byref(segs), _stream()), "fd_dwconv3x3_gn_nhwc")
 
 
 def groupnorm_act_bwd(x: Rows, dy: Rows, gamma: torch.Tensor, beta: torch.Tensor, dx: Rows, segs: Segs, G: int, act: int,

@@ -66,15 +66,21 @@ def test_conv_single_level(case, prec):
     y = ops.new_rows(B * Ho * Wo, Cout, DEV)
     rr = to_rows(res) if use_res else None
     wp = ops.pack_conv_weight_f16x3(w.to(DEV)) if prec == "f16x3" else ops.pack_conv_weight(w.to(DEV))
-    from pytorch_object_detection_amd._lib import PATCH_TILE
+    from pytorch_object_detection_amd._lib import PATCH_TILE, WAVE_TILE
     patch_ok = k == 3 and stride == 1 and pad == dil
+    wave_ok = prec == "f32" and ops.wave_ok(Cin, Cout, k, stride, pad)
+    wf = ops.pack_conv_weight_wave(w.to(DEV)) if wave_ok else None
     for tile in ([0] if prec == "f32" else []) + sorted(_TILE_IDS):
         y.buf.fill_(float("nan"))
         call = ops.conv_call(xr, segs, wp, y, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil,
                              scale=scale.to(DEV) if use_bn else None, shift=shift.to(DEV), res=rr, act=act, tile=tile,
-                             precision=1 if prec == "f16x3" else 0)
+                             precision=1 if prec == "f16x3" else 0, w_frag=wf)
         if tile == PATCH_TILE and not patch_ok:      # the patch tile is 3x3 stride-1 'same' only: a clean error, no launch
             with pytest.raises(Exception, match="PATCH"):
+                call()
+            continue
+        if tile == WAVE_TILE and not wave_ok:        # the wave tile is fp32 1x1 stride-1 with Cin, Cout multiples of 32 and its own weight packing
+            with pytest.raises(Exception, match="WAVE64"):
                 call()
             continue
         call()
@@ -998,3 +1004,156 @@ def test_conv1x1_wave_tile_is_bit_identical_to_the_workgroup_kernel(case):
         ref = torch.cat([ref[:, :act_c0], a[:, act_c0:]], 1)
     got = outs[1].reshape(B, H, W, Cout).permute(0, 3, 1, 2).cpu()
     np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=ATOL, rtol=RTOL)
+
+
+# ------------------------------------------------------------------------------------------------ GroupNorm fused into its neighbours
+@pytest.mark.parametrize("kind", ["tile4", "tile8", "tile9", "wave", "winograd", "winograd_d2"])
+@pytest.mark.parametrize("G", [32, 64])
+def test_conv_epilogue_row_group_statistics(kind, G):
+    """fd_conv_params.gn_stats: per output row and channel group the (sum, sum of squares) of the stored values, from the epilogue of every
+    kernel that offers it -- against the same sums taken from the conv's own output, on a ragged pyramid (rows past M, tiles straddling
+    images and levels); the conv output itself is bitwise what it is without the statistics."""
+    from pytorch_object_detection_amd import _lib
+    gen = torch.Generator().manual_seed(G + len(kind))
+    B, Cin, Cout = 3, 64, 256
+    hw = [(9, 11), (5, 6), (3, 3), (1, 2)]
+    wino = kind.startswith("winograd")
+    dil = 2 if kind.endswith("d2") else 1
+    k = 3 if wino else 1
+    segs = Segs.make(B, hw)
+    x = ops.Rows(torch.randn(segs.rows, Cin, generator=gen).to(DEV))
+    w = (torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * k * k)).to(DEV)
+    res = ops.Rows(torch.randn(segs.rows, Cout, generator=gen).to(DEV))
+    shift = torch.randn(Cout, generator=gen).to(DEV)
+    tile = {"tile4": 4, "tile8": 8, "tile9": 9, "wave": _lib.WAVE_TILE}.get(kind, _lib.WINO_TILE)
+    wp = ops.pack_conv_weight_wino(w) if wino else ops.pack_conv_weight(w)
+    wf = ops.pack_conv_weight_wave(w) if kind == "wave" else None
+    outs = []
+    for with_stats in (False, True):
+        y = ops.new_rows(segs.rows, Cout, DEV)
+        rgs = torch.full((segs.rows, G, 2), float("nan"), device=DEV) if with_stats else None
+        ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=Cout, k=k, pad=dil if wino else 0, dil=dil, shift=shift, res=res, act=ACT_RELU, tile=tile,
+                      w_frag=wf, gn_stats=rgs, gn_groups=G)()
+        outs.append(y.tensor().clone())
+    assert torch.equal(outs[0], outs[1])
+    yv = outs[1].double().view(segs.rows, G, Cout // G)
+    np.testing.assert_allclose(rgs[..., 0].cpu().numpy(), yv.sum(-1).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rgs[..., 1].cpu().numpy(), (yv * yv).sum(-1).cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_groupnorm_from_rowstats_matches_the_three_pass_groupnorm():
+    """fd_groupnorm_from_rowstats + fd_groupnorm_apply_nhwc on exact row-group sums == fd_groupnorm_act_nhwc (statistics / finalise / normalise
+    over the map itself) to rounding, per (level, image); the coefficient table is the affine the apply kernel uses."""
+    gen = torch.Generator().manual_seed(77)
+    B, Cc, G = 3, 512, 32
+    hw = [(12, 9), (5, 7), (2, 3), (1, 1)]
+    segs = Segs.make(B, hw)
+    x = torch.randn(segs.rows, Cc, generator=gen) * 2 + 0.5
+    gamma, beta = (torch.rand(Cc, generator=gen) + 0.5).to(DEV), torch.randn(Cc, generator=gen).to(DEV)
+    xd = ops.Rows(x.to(DEV))
+    ws0 = ops.groupnorm_workspace(segs, G, DEV)
+    y0 = ops.new_rows(segs.rows, Cc, DEV)
+    ops.groupnorm_act(xd, gamma, beta, y0, segs, G, ACT_SILU, ws0)
+    xv = x.view(segs.rows, G, Cc // G)
+    rgs = torch.stack([xv.sum(-1), (xv * xv).sum(-1)], -1).contiguous().to(DEV)
+    ws1 = ops.groupnorm_workspace(segs, G, DEV)
+    coef = torch.empty(segs.nseg * B, 2, Cc, device=DEV)
+    ops.groupnorm_from_rowstats(rgs, Cc, G, 1e-5, gamma, beta, segs, ws1, coef)
+    y1 = ops.new_rows(segs.rows, Cc, DEV)
+    ops.groupnorm_apply(xd, gamma, beta, y1, segs, G, ACT_SILU, ws1)
+    np.testing.assert_allclose(y1.tensor().cpu().numpy(), y0.tensor().cpu().numpy(), atol=2e-5, rtol=2e-5)
+    # coef: y = silu(x * a + b) row by row
+    img = 0
+    for lv, (h, w) in enumerate(hw):
+        for n in range(B):
+            r0 = segs.m_start[lv] + n * h * w
+            a, b = coef[lv * B + n, 0].cpu(), coef[lv * B + n, 1].cpu()
+            ref = F.silu(x[r0:r0 + h * w] * a + b)
+            np.testing.assert_allclose(y1.tensor()[r0:r0 + h * w].cpu().numpy(), ref.numpy(), atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("Cc", [512, 128])
+def test_dwconv3x3_with_fused_groupnorm_input_and_output_statistics(Cc):
+    """fd_dwconv3x3_gn_nhwc: depthwise 3x3 over act(x * a + b) with the zero padding applied AFTER the affine (the reference pads the
+    normalised map), plus the row-group sums of its output -- against torch on a ragged pyramid."""
+    gen = torch.Generator().manual_seed(Cc)
+    B, G = 2, 32
+    hw = [(10, 13), (4, 5), (2, 2), (1, 1)]
+    segs = Segs.make(B, hw)
+    xs = [torch.randn(B, Cc, h, w, generator=gen) for h, w in hw]
+    wt = torch.randn(Cc, 1, 3, 3, generator=gen) / 3
+    coef = torch.stack([torch.rand(len(hw) * B, Cc, generator=gen) + 0.5, torch.randn(len(hw) * B, Cc, generator=gen)], 1).contiguous()
+    xr = ops.Rows(torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cc) for t in xs]).to(DEV))
+    y = ops.new_rows(segs.rows, Cc, DEV)
+    rgs = torch.full((segs.rows, G, 2), float("nan"), device=DEV)
+    ops.dwconv3x3_gn(xr, ops.pack_dw_weight(wt.to(DEV)), y, segs, coef.to(DEV), ACT_RELU, rgs, G)
+    got = y.tensor().cpu()
+    for lv, ((h, w), x) in enumerate(zip(hw, xs)):
+        a = coef[lv * B:(lv + 1) * B, 0].view(B, Cc, 1, 1)
+        b = coef[lv * B:(lv + 1) * B, 1].view(B, Cc, 1, 1)
+        ref = F.conv2d(F.relu(x * a + b), wt, None, 1, 1, 1, Cc)
+        g = got[segs.m_start[lv]:segs.m_start[lv + 1]].reshape(B, h, w, Cc).permute(0, 3, 1, 2)
+        np.testing.assert_allclose(g.numpy(), ref.numpy(), atol=1e-5, rtol=1e-5, err_msg=f"level {lv}")
+    gv = got.double().view(segs.rows, G, Cc // G)
+    np.testing.assert_allclose(rgs[..., 0].cpu().numpy(), gv.sum(-1).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rgs[..., 1].cpu().numpy(), (gv * gv).sum(-1).numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_conv1x1_with_groupnorm_affine_and_silu_in_its_loader():
+    """fd_conv_params.gate + gate_b + gate_act over a PYRAMID: y = conv1x1(silu(x * a[img] + b[img])) + bias + residual, the form HISFCOSHead's
+    pw2 takes when GroupNorm 2 is folded into it (HISFcos.py:220-222)."""
+    gen = torch.Generator().manual_seed(5)
+    B, Cin, Cout = 2, 512, 256
+    hw = [(9, 12), (4, 6), (2, 3), (1, 1)]
+    segs = Segs.make(B, hw)
+    xs = [torch.randn(B, Cin, h, w, generator=gen) for h, w in hw]
+    w = torch.randn(Cout, Cin, 1, 1, generator=gen) / np.sqrt(Cin)
+    bias = torch.randn(Cout, generator=gen)
+    coef = torch.stack([torch.rand(len(hw) * B, Cin, generator=gen) + 0.5, torch.randn(len(hw) * B, Cin, generator=gen)], 1).contiguous().to(DEV)
+    rs = [torch.randn(B, Cout, h, w_, generator=gen) for h, w_ in hw]
+    xr = ops.Rows(torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cin) for t in xs]).to(DEV))
+    rr = ops.Rows(torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cout) for t in rs]).to(DEV))
+    y = ops.new_rows(segs.rows, Cout, DEV)
+    ops.conv_call(xr, segs, ops.pack_conv_weight(w.to(DEV)), y, Cin=Cin, Cout=Cout, k=1, shift=bias.to(DEV), res=rr, gate=coef[:, 0], gate_b=coef[:, 1],
+                  gate_act=ACT_SILU)()
+    got = y.tensor().cpu()
+    cc = coef.cpu()
+    for lv, ((h, w_), x, r) in enumerate(zip(hw, xs, rs)):
+        a = cc[lv * B:(lv + 1) * B, 0].view(B, Cin, 1, 1)
+        b = cc[lv * B:(lv + 1) * B, 1].view(B, Cin, 1, 1)
+        ref = F.conv2d(F.silu(x * a + b), w, bias) + r
+        g = got[segs.m_start[lv]:segs.m_start[lv + 1]].reshape(B, h, w_, Cout).permute(0, 3, 1, 2)
+        np.testing.assert_allclose(g.numpy(), ref.numpy(), atol=ATOL, rtol=1e-4, err_msg=f"level {lv}")
+
+
+def test_hisfcos_head_fused_groupnorm_equals_unfused_and_oracle(monkeypatch):
+    """HISFCOSHead(256, 80) on a five-level pyramid: the plan with GroupNorm folded into pw1 / dw1 / pw2 / the tower (engine.GN_FUSED) against
+    the three-pass GroupNorm plan and against the oracle's restatement of HISFcos.py:211-229."""
+    from oracle import torch_ref as R
+    from pytorch_object_detection_amd import engine
+    from pytorch_object_detection_amd.model.od.HISFcos import HISFCOSHead
+    torch.manual_seed(12)
+    head = HISFCOSHead(256, 80).eval()
+    with torch.no_grad():
+        for n, p_ in head.named_parameters():
+            if p_.dim() == 4:
+                p_.copy_(torch.randn(p_.shape) * (2.0 / (p_.shape[1] * p_.shape[2] * p_.shape[3])) ** 0.5)
+            elif "gn" in n or ".1." in n:
+                p_.copy_(torch.rand(p_.shape) + 0.5 if n.endswith("weight") else torch.randn(p_.shape) * 0.3)
+    sd = {"head." + k: v.clone() for k, v in head.state_dict().items()}
+    feats = [torch.randn(2, 256, s, s + 1) for s in (20, 10, 5, 3, 1)]
+    with torch.no_grad():
+        ref = R.his_head(sd, feats)
+    head.to(DEV)
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(engine, "GN_FUSED", fused)
+        head.invalidate_plans()
+        o = head([f.to(DEV) for f in feats])
+        outs[fused] = [t.clone() for grp in o for t in grp]
+        names = head._plans[next(iter(head._plans))][1][0].names
+        assert ("head.gn1" in names) == (not fused) and ("head.gn1.stats" in names) == fused
+    for a, b in zip(outs[True], outs[False]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=3e-5, rtol=3e-5)
+    for a, r in zip(outs[True], [t for grp in ref for t in grp]):
+        np.testing.assert_allclose(a.cpu().numpy(), r.numpy(), atol=1e-4, rtol=1e-4)
