@@ -80,6 +80,10 @@ const char* fd_last_error(void);
  *                  loader); w is the pre-split packing [Cout][Cin/32][KH][KW][2][32] f16 (hi plane, lo plane). */
 #define FD_PREC_F32 0
 #define FD_PREC_F16X3 1
+#define FD_PREC_F16 2   /* single-plane f16: operands rounded to f16 once (activations in the loader, weights at pack time: the hi plane of the
+                           FD_PREC_F16X3 packing), ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation and epilogue, fp32 output -- the
+                           arithmetic of a convolution under torch.autocast(float16), which is how the reference trains (train.py:33,175-181).
+                           Operands must stay inside f16's range.  Tiles: AUTO, 128x128(_SB), 128x64, 64x128, 64x64, 128x32, 128x96. */
 
 /* block tiles (output pixels x output channels) of the conv kernel */
 #define FD_TILE_AUTO 0
@@ -213,7 +217,9 @@ int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_stream_t stre
 /* OIHW fp32 weights -> the [N][K/32][KH][KW][32] layout fd_conv2d_nhwc_f32 reads, in one pass (the per-step weight
  * preparation of the train step; plans pack once at build time).  mode 0: forward weights (N = Cout, K = Cin, Cin % 32
  * == 0).  mode 1: weights of the stride-1 data-gradient conv (N = Cin, K = Cout, Cout % 32 == 0):
- * w'[ci][co][r][q] = w[co][ci][KH-1-r][KW-1-q] * (scale ? scale[co] : 1). */
+ * w'[ci][co][r][q] = w[co][ci][KH-1-r][KW-1-q] * (scale ? scale[co] : 1).
+ * mode | 4: the same weights in the FD_PREC_F16X3 / FD_PREC_F16 operand format [N][K/32][KH][KW][2][32] f16 (hi = f16(w) round-to-nearest,
+ * lo = f16((w - hi) * 2^11)); the output buffer has the same byte size as the fp32 packing. */
 int32_t fd_pack_conv_weight_f32(const float* w, const float* scale, float* out, int32_t Cout, int32_t Cin, int32_t KH,
                                 int32_t KW, int32_t mode, fd_stream_t stream);
 
@@ -224,7 +230,7 @@ typedef struct fd_pack_job {
     const float* w;      /* [Cout][Cin][KH][KW] */
     const float* scale;  /* [Cout] or NULL (mode 1 only) */
     float* out;
-    int32_t Cout, Cin, KH, KW, mode, reserved; /* mode: 0 / 1 as fd_pack_conv_weight_f32; 2 / 3 = the Winograd packing of fd_wino_pack_weights_f32 (mode 0 / 1), 3x3 only */
+    int32_t Cout, Cin, KH, KW, mode, reserved; /* mode: 0 / 1 (| 4) as fd_pack_conv_weight_f32; 2 / 3 = the Winograd packing of fd_wino_pack_weights_f32 (mode 0 / 1), 3x3 only */
 } fd_pack_job;
 int32_t fd_pack_conv_weights_batch_f32(const fd_pack_job* jobs_dev, int32_t n_jobs, int64_t max_elems, fd_stream_t stream);
 

@@ -16,7 +16,9 @@
 // GATE: the A operand is multiplied by a per-(image, input channel) gate on its way to LDS (1x1 GEMM layers, single level): the
 // squeeze-excitation gate of an MBConv block folded into its project conv.
 // GNS: the epilogue also writes the row-group statistics of the stored output (fd_conv_params.gn_stats; one- and two-sub-tile tiles only).
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT, bool GATE = false, bool GNS = false>
+// H1 (with SPLIT): single-plane f16 -- operands rounded to f16 once, ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation: the
+// arithmetic of torch.autocast(float16) convolutions (FD_PREC_F16; the reference trains under AMP, train.py:33,175-181).
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT, bool GATE = false, bool GNS = false, bool H1 = false>
 __global__ __launch_bounds__(WGM * WGN * 64, (TM * TN == 4) ? ((SPLIT || WGM * WGN == 8) ? 2 : (SB ? 3 : 1)) : 1)
 void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -95,7 +97,7 @@ void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
         const int n = n0 + lrow + RPP * j;
-        b_off[j] = (n < a.Cout) ? ((unsigned)n * (unsigned)a.Kpacked + (unsigned)(chunk * 4)) * 4u : OOB;
+        b_off[j] = (n < a.Cout && !(H1 && (chunk & 4))) ? ((unsigned)n * (unsigned)a.Kpacked + (unsigned)(chunk * 4)) * 4u : OOB;   // (H1: the lo plane is not fetched)
     }
 
     float4 ra[AP], rb[BP], rg[GATE ? AP : 1], rgb[GATE ? AP : 1];
@@ -147,16 +149,18 @@ void conv_igemm_kernel(ConvArgs a) {
                 const int row = lrow + RPP * i;
                 const f32x4 v = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
                 const h4 hi = __builtin_convertvector(v, h4);                       // round to nearest
-                const f32x4 rem = (v - __builtin_convertvector(hi, f32x4)) * FD_SPLIT_SCALE;   // exact residual
-                const h4 lo = __builtin_convertvector(rem, h4);
                 const int off = row * 32 + ((((chunk >> 1) ^ ((row >> 2) & 3)) << 3) | ((chunk & 1) << 2));
                 *reinterpret_cast<h4*>(Ahi + off) = hi;
-                *reinterpret_cast<h4*>(Alo + off) = lo;
+                if constexpr (!H1) {
+                    const f32x4 rem = (v - __builtin_convertvector(hi, f32x4)) * FD_SPLIT_SCALE;   // exact residual
+                    const h4 lo = __builtin_convertvector(rem, h4);
+                    *reinterpret_cast<h4*>(Alo + off) = lo;
+                }
             }
 #pragma unroll
             for (int j = 0; j < BP; ++j) {   // weights arrive pre-split: 16-B chunks 0-3 = hi, 4-7 = lo of this K-tile
                 const int row = lrow + RPP * j;
-                *reinterpret_cast<float4*>(((chunk & 4) ? Blo : Bhi) + lds_off_h(row, chunk & 3)) = rb[j];
+                if (!H1 || !(chunk & 4)) *reinterpret_cast<float4*>(((chunk & 4) ? Blo : Bhi) + lds_off_h(row, chunk & 3)) = rb[j];
             }
         } else {
 #pragma unroll
@@ -217,20 +221,22 @@ void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     ah[i] = *reinterpret_cast<const h8*>(Ahi + lds_off_h(i * 32 + l31, 2 * ks + lh));
-                    al[i] = *reinterpret_cast<const h8*>(Alo + lds_off_h(i * 32 + l31, 2 * ks + lh));
+                    if constexpr (!H1) al[i] = *reinterpret_cast<const h8*>(Alo + lds_off_h(i * 32 + l31, 2 * ks + lh));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     bh[j] = *reinterpret_cast<const h8*>(Bhi + lds_off_h(j * 32 + l31, 2 * ks + lh));
-                    bl[j] = *reinterpret_cast<const h8*>(Blo + lds_off_h(j * 32 + l31, 2 * ks + lh));
+                    if constexpr (!H1) bl[j] = *reinterpret_cast<const h8*>(Blo + lds_off_h(j * 32 + l31, 2 * ks + lh));
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                        cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], cor[i][j], 0, 0, 0);
-                        cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], cor[i][j], 0, 0, 0);
+                        if constexpr (!H1) {
+                            cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], cor[i][j], 0, 0, 0);
+                            cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], cor[i][j], 0, 0, 0);
+                        }
                     }
             }
         } else {
@@ -322,7 +328,7 @@ int fd_launch_splitk_reduce(const ConvArgs& orig, const float* ws, int nslice, i
     return FD_OK;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false, bool GATE = false, bool GNS = false>
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false, bool GATE = false, bool GNS = false, bool H1 = false>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int lds_ab = (SB ? 1 : 2) * (BM + BN) * 32 * 4;
@@ -332,7 +338,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT, GATE, GNS>;
+    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT, GATE, GNS, H1>;
     static std::atomic<unsigned> attr_mask{0};       // per kernel instantiation, one bit per device
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles, (a.KT + a.kt_per - 1) / a.kt_per), dim3(NT), lds, stream, b);
@@ -446,6 +452,8 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
                    FD_E_INVAL, "fd_conv2d: gate_b must be 16-byte aligned, gate_act in {NONE, RELU, SILU}");
         a.gate = p->gate; a.gate_cs = p->gate_cs; a.gate_hw = p->in.H[0] * p->in.W[0];
         a.gate_b = p->gate_b; a.gate_act = p->gate_b ? p->gate_act : FD_ACT_NONE;
+        // the GroupNorm-fused form (HISFCOSHead pw2): single-LDS-buffer tiles at three workgroups per CU, as the tuned table picks for the plain layer
+        if (p->gate_b && a.Cout > 64 && (long)((a.M + 63) / 64) * ((a.Cout + 127) / 128) >= 512) return launch_conv<2, 2, 1, 2, false, true, 0, false, true>(a, stream);   // 64 x 128 SB
         if (a.Cout <= 32) return launch_conv<4, 1, 1, 1, false, false, 0, false, true>(a, stream);      // 128 x 32
         const long m128 = (a.M + 127) / 128;
         if (a.Cout <= 64) {
@@ -522,6 +530,28 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
             case FD_TILE_256x128_SB:
                 return tg ? launch_conv<4, 2, 2, 2, false, true, 1, true>(a, stream) : launch_conv<4, 2, 2, 2, false, true, 0, true>(a, stream);
             default: fd_set_error("fd_conv2d: tile id %d has no split-f16 kernel", p->tile); return FD_E_UNSUPPORTED;
+        }
+    }
+    if (p->precision == FD_PREC_F16) {   // single-plane f16 products, fp32 accumulation (torch.autocast arithmetic); weights in the FD_PREC_F16X3 packing (hi plane used)
+        FD_REQUIRE(!a.gn_stats && !a.gate, FD_E_UNSUPPORTED, "fd_conv2d: FD_PREC_F16 has no gn_stats / gate form");
+        auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
+        switch (p->tile) {
+            case FD_TILE_AUTO:
+                if (a.Cout <= 32) return launch_conv<4, 1, 1, 1, false, false, 0, true, false, false, true>(a, stream);
+                if (a.Cout <= 64) return blocks(128, 64) >= 512 ? launch_conv<2, 2, 2, 1, false, false, 0, true, false, false, true>(a, stream)
+                                                                : launch_conv<2, 2, 1, 1, false, false, 0, true, false, false, true>(a, stream);
+                if (a.Cout <= 96) return launch_conv<4, 1, 1, 3, false, false, 0, true, false, false, true>(a, stream);
+                if (blocks(128, 128) >= 512) return launch_conv<2, 2, 2, 2, false, false, 0, true, false, false, true>(a, stream);
+                if (blocks(64, 128) >= 256) return launch_conv<2, 2, 1, 2, false, false, 0, true, false, false, true>(a, stream);
+                return launch_conv<2, 2, 1, 1, false, false, 0, true, false, false, true>(a, stream);
+            case FD_TILE_128x128: return launch_conv<2, 2, 2, 2, false, false, 0, true, false, false, true>(a, stream);
+            case FD_TILE_128x128_SB: return launch_conv<2, 2, 2, 2, false, true, 0, true, false, false, true>(a, stream);
+            case FD_TILE_128x64: return launch_conv<2, 2, 2, 1, false, false, 0, true, false, false, true>(a, stream);
+            case FD_TILE_64x128: return launch_conv<2, 2, 1, 2, false, false, 0, true, false, false, true>(a, stream);
+            case FD_TILE_64x64: return launch_conv<2, 2, 1, 1, false, false, 0, true, false, false, true>(a, stream);
+            case FD_TILE_128x32: return launch_conv<4, 1, 1, 1, false, false, 0, true, false, false, true>(a, stream);
+            case FD_TILE_128x96: return launch_conv<4, 1, 1, 3, false, false, 0, true, false, false, true>(a, stream);
+            default: fd_set_error("fd_conv2d: tile id %d has no f16 kernel", p->tile); return FD_E_UNSUPPORTED;
         }
     }
     FD_REQUIRE(p->precision == FD_PREC_F32, FD_E_INVAL, "fd_conv2d: unknown precision %d", p->precision);

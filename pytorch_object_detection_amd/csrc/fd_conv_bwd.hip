@@ -212,6 +212,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// element i of the fp32 packing [N][K/32][taps][32] -> its (hi, lo) f16 pair in the FD_PREC_F16X3 / FD_PREC_F16 packing [..][2][32]
+__device__ __forceinline__ void pack_store_f16(float* out, long i, float v) {
+    _Float16* oh = reinterpret_cast<_Float16*>(out) + (i >> 5) * 64 + (i & 31);
+    const _Float16 hi = (_Float16)v;
+    oh[0] = hi;
+    oh[32] = (_Float16)((v - (float)hi) * 2048.0f);
+}
+
 // framework OIHW weights -> the conv kernel's [N][K/32][KH][KW][32] layout in one pass.
 // mode 0: forward weights (N = Cout, K = Cin).  mode 1: weights of the stride-1 data-gradient conv (N = Cin, K = Cout):
 // w'[ci][co][r][q] = w[co][ci][KH-1-r][KW-1-q] * scale[co].
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
                                                            float* __restrict__ out, int Cout, int Cin, int KH, int KW, int mode,
                                                            long total) {
     const int taps = KH * KW;
-    const int N = mode ? Cin : Cout, K = mode ? Cout : Cin;
+    const int N = (mode & 1) ? Cin : Cout, K = (mode & 1) ? Cout : Cin;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c32 = (int)(i & 31);
         long t = i >> 5;
@@ -228,23 +236,23 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
         const int n = (int)(t / (K / 32));
         const int k = chunk * 32 + c32;
         float v;
-        if (mode == 0) {
+        if ((mode & 1) == 0) {
             v = w[((long)n * Cin + k) * taps + tap];
         } else {
             v = w[((long)k * Cin + n) * taps + (taps - 1 - tap)];
             if (scale) v *= scale[k];
         }
-        out[i] = v;
+        if (mode & 4) pack_store_f16(out, i, v); else out[i] = v;
     }
     (void)N;
 }
 
 extern "C" int32_t fd_pack_conv_weight_f32(const float* w, const float* scale, float* out, int32_t Cout, int32_t Cin,
                                            int32_t KH, int32_t KW, int32_t mode, fd_stream_t stream) {
-    FD_REQUIRE(w && out && Cout >= 1 && Cin >= 1 && KH >= 1 && KW >= 1 && (mode == 0 || mode == 1), FD_E_INVAL,
+    FD_REQUIRE(w && out && Cout >= 1 && Cin >= 1 && KH >= 1 && KW >= 1 && (mode & ~5) == 0, FD_E_INVAL,
                "fd_pack_conv_weight: bad arguments");
-    FD_REQUIRE((mode == 0 ? Cin : Cout) % 32 == 0, FD_E_UNSUPPORTED,
-               "fd_pack_conv_weight: the reduction width (%d) must be a multiple of 32", mode == 0 ? Cin : Cout);
+    FD_REQUIRE(((mode & 1) == 0 ? Cin : Cout) % 32 == 0, FD_E_UNSUPPORTED,
+               "fd_pack_conv_weight: the reduction width (%d) must be a multiple of 32", (mode & 1) == 0 ? Cin : Cout);
     const long total = (long)Cout * Cin * KH * KW;
     long g = (total + 255) / 256;
     if (g > 16384) g = 16384;
@@ -258,7 +266,7 @@ extern "C" int32_t fd_pack_conv_weight_f32(const float* w, const float* scale, f
 // device memory, one workgroup range per job (blockIdx.y = job, grid-stride over its elements).
 __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const fd_pack_job* __restrict__ jobs) {
     const fd_pack_job j = jobs[blockIdx.y];
-    if (j.mode >= 2) {       // Winograd packing (fd_conv_wino.hip): mode 2 = forward, 3 = data-gradient weights; one (n, k) filter per thread
+    if (j.mode == 2 || j.mode == 3) {       // Winograd packing (fd_conv_wino.hip): mode 2 = forward, 3 = data-gradient weights; one (n, k) filter per thread
         const int N = j.mode == 2 ? j.Cout : j.Cin, K = j.mode == 2 ? j.Cin : j.Cout;
         const long total = (long)((N + 31) & ~31) * K;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const fd_pack_jo
         return;
     }
     const int taps = j.KH * j.KW;
-    const int K = j.mode ? j.Cout : j.Cin;
+    const int K = (j.mode & 1) ? j.Cout : j.Cin;
     const long total = (long)j.Cout * j.Cin * taps;
     const float* __restrict__ w = j.w;
     const float* __restrict__ scale = j.scale;
@@ -280,13 +288,13 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const fd_pack_jo
         const int n = (int)(t / (K / 32));
         const int k = chunk * 32 + c32;
         float v;
-        if (j.mode == 0) {
+        if ((j.mode & 1) == 0) {
             v = w[((long)n * j.Cin + k) * taps + tap];
         } else {
             v = w[((long)k * j.Cin + n) * taps + (taps - 1 - tap)];
             if (scale) v *= scale[k];
         }
-        j.out[i] = v;
+        if (j.mode & 4) pack_store_f16(j.out, i, v); else j.out[i] = v;
     }
 }
 

@@ -71,12 +71,16 @@ __device__ __forceinline__ void wave_lds_sync() {
 // Row-group statistics of a lane's four stored channels v (channels nn .. nn+3 of output row m): the gn_cg / 4 lanes that hold one group's
 // channels of this row are adjacent (lane & 7 = 16-byte chunk of the row) -- summed by xor-shuffles in a fixed order, written by the first.
 // EVERY lane of the wave must call it (the shuffles); `ok` only guards the store.
+// lane ^ 1 / lane ^ 2 exchanges inside a quad as DPP modifiers of a VALU move (no LDS-pipe ds_bpermute)
+__device__ __forceinline__ float fd_quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float fd_quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
+
 __device__ __forceinline__ void fd_gn_rowstats(float* gn_stats, int gn_G, int gn_cg, const float4& v, size_t m, int nn, int lane, bool ok) {
     float s1 = (v.x + v.y) + (v.z + v.w);
     float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     const int cgq = gn_cg >> 2;                   // 1, 2, 4 or 8 lanes per group (uniform)
-    if (cgq > 1) { s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1); }
-    if (cgq > 2) { s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2); }
+    if (cgq > 1) { s1 += fd_quad_xor1(s1); s2 += fd_quad_xor1(s2); }
+    if (cgq > 2) { s1 += fd_quad_xor2(s1); s2 += fd_quad_xor2(s2); }
     if (cgq > 4) { s1 += __shfl_xor(s1, 4); s2 += __shfl_xor(s2, 4); }
     if (ok && ((lane & 7) & (cgq - 1)) == 0)
         reinterpret_cast<float2*>(gn_stats)[m * gn_G + nn / gn_cg] = make_float2(s1, s2);

@@ -368,6 +368,9 @@ struct StripTab {
     int spr[FD_MAX_SEG];                // strips per image row = ceil(W / S)
 };
 
+__device__ __forceinline__ float dw_quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dw_quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
+
 // FUSE: GroupNorm around the conv (HISFCOSHead: pw1 -> GN1 -> ReLU -> dw1 -> GN2 -> SiLU -> pw2).  in_coef [levels * batch][2][C] = the
 // preceding GroupNorm's per-(level, image, channel) affine (a, b): every in-image input pixel is read as in_act(x * a + b) -- the zero
 // padding stays zero, the reference pads the NORMALISED map -- and gn_stats[m][g] receives the (sum, sum of squares) of the gn_cg
@@ -395,6 +398,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const float* __res
         const int h = rem / spr, w0 = (rem - h * spr) * S;
         const long r0 = (long)tab.s.m_start[s] + n * H * W;
         float4 ca = make_float4(1.f, 1.f, 1.f, 1.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float act_lo = (FUSE && in_act == FD_ACT_RELU) ? 0.f : -INFINITY;
         if (FUSE && in_coef) {
             const float* cp = in_coef + ((long)(s * tab.s.batch + (int)n) * 2) * C + 4 * q;
             ca = *reinterpret_cast<const float4*>(cp);
@@ -413,9 +417,20 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const float* __res
                 const int wi = w0 + c - 1;
                 u[c] = (unsigned)wi < (unsigned)W ? *reinterpret_cast<const float4*>(x + (r0 + (long)hi * W + wi) * x_cs + x_co + 4 * q)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (FUSE && in_coef && (unsigned)wi < (unsigned)W) {
-                    u[c].x = fd_act(u[c].x * ca.x + cb.x, in_act, 0.f); u[c].y = fd_act(u[c].y * ca.y + cb.y, in_act, 0.f);
-                    u[c].z = fd_act(u[c].z * ca.z + cb.z, in_act, 0.f); u[c].w = fd_act(u[c].w * ca.w + cb.w, in_act, 0.f);
+            }
+            if (FUSE && in_coef) {
+                // all loads of the row are in flight before the first of them is touched; the affine + ReLU is branch-free (a lower bound of
+                // 0 or -inf), the zero padding is re-imposed by a select
+#pragma unroll
+                for (int c = 0; c < S + 2; ++c) {
+                    float4 t = make_float4(fmaf(u[c].x, ca.x, cb.x), fmaf(u[c].y, ca.y, cb.y), fmaf(u[c].z, ca.z, cb.z), fmaf(u[c].w, ca.w, cb.w));
+                    t.x = fmaxf(t.x, act_lo); t.y = fmaxf(t.y, act_lo); t.z = fmaxf(t.z, act_lo); t.w = fmaxf(t.w, act_lo);
+                    if (in_act == FD_ACT_SILU) {        // (uniform)
+                        t.x *= __builtin_amdgcn_rcpf(1.0f + __expf(-t.x)); t.y *= __builtin_amdgcn_rcpf(1.0f + __expf(-t.y));
+                        t.z *= __builtin_amdgcn_rcpf(1.0f + __expf(-t.z)); t.w *= __builtin_amdgcn_rcpf(1.0f + __expf(-t.w));
+                    }
+                    const bool inb = (unsigned)(w0 + c - 1) < (unsigned)W;
+                    u[c] = inb ? t : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
@@ -447,7 +462,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const float* __res
                 // of cg / 4 and of ... see the host checks): all of them are here together (same strip, same j)
                 float s1 = (o.x + o.y) + (o.z + o.w), s2 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
                 const int cgq = (C / gn_G) >> 2;
-                for (int d = 1; d < cgq; d <<= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+                if (cgq > 1) { s1 += dw_quad_xor1(s1); s2 += dw_quad_xor1(s2); }
+                if (cgq > 2) { s1 += dw_quad_xor2(s1); s2 += dw_quad_xor2(s2); }
+                if (cgq > 4) { s1 += __shfl_xor(s1, 4); s2 += __shfl_xor(s2, 4); }
                 if ((q & (cgq - 1)) == 0) reinterpret_cast<float2*>(gn_stats)[mo * gn_G + (4 * q) / (C / gn_G)] = make_float2(s1, s2);
             }
         }

@@ -33,6 +33,7 @@ AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see 
 # (ops.wino_preferred: it has no split-K); "force" = wherever it applies; "0" = every conv on the direct implicit-GEMM kernel
 WINOGRAD = _os.environ.get("FD_WINOGRAD", "1") != "0"
 SE_GATE_IN_PROJECT = _os.environ.get("FD_SE_GATE_FUSED", "1") != "0"     # MBConv: SE gate applied by the project conv's loader ("0": a scaling pass)
+GN_FUSED_TOWER = _os.environ.get("FD_GN_FUSED_TOWER", "0") == "1"   # "1": the tower's statistics from its Winograd epilogue too (measured neutral, costs the tower launch 5 %)
 GN_FUSED = _os.environ.get("FD_GN_FUSED", "1") != "0"       # "0": HISFCOSHead's GroupNorms as three-pass launches (statistics / finalise / normalise)
 WAVE_TILE = _os.environ.get("FD_WAVE_TILE", "1") != "0"       # "0": the 1x1 layers never see FD_TILE_WAVE64 (wave-autonomous tiles, fd_conv_wave.hip)
 STEM_KERNEL = _os.environ.get("FD_STEM_KERNEL", "1") != "0"     # "0": the ResNet stem through the generic conv kernel's FD_CONV_STEM mode
@@ -593,7 +594,7 @@ def build_his_head(plan: Plan, head, pyr: Rows, segs: Segs):
     tower = pool.get(M, 2 * F)
     w = torch.cat([head.cls_conv[0].weight.detach(), head.reg_conv[0].weight.detach()], 0)
     tgn = [head.cls_conv[1], head.reg_conv[1]]
-    t_fused = (_gn_fusable(plan, tgn, 2 * F) and plan.winograd and ops.wino_ok(F, 2 * F, 3, 1, 1, 1) and ops.wino_choice(segs, F, 2 * F, 1)[1] == 1)
+    t_fused = (GN_FUSED_TOWER and _gn_fusable(plan, tgn, 2 * F) and plan.winograd and ops.wino_ok(F, 2 * F, 3, 1, 1, 1) and ops.wino_choice(segs, F, 2 * F, 1)[1] == 1)
     mark = len(plan.steps)
     if t_fused:
         Gt = sum(g.num_groups for g in tgn)
