@@ -402,12 +402,17 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
     gen_t = FCOSGenTargets([8, 16, 32, 64, 128], [[-1, 32], [32, 96], [96, 192], [192, 384], [384, 9999999]])
     crit = FCOSLoss("giou")
 
+    amp = bool(getattr(args, "amp", False))
+    scaler = torch.amp.GradScaler("cuda", enabled=amp)          # train.py:175-181: autocast forward + loss, scaled backward, scaler.step
+
     def one():
         opt.zero_grad(set_to_none=True)
-        out = net(x)
-        losses = crit([out, gen_t([out, gt, labels])])
-        losses[-1].backward()
-        opt.step()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            out = net(x)
+            losses = crit([out, gen_t([out, gt, labels])])
+        scaler.scale(losses[-1]).backward()
+        scaler.step(opt)
+        scaler.update()
         return losses[-1]
 
     for _ in range(args.warmup):
@@ -444,11 +449,31 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
     wms = e0.elapsed_time(e1) / 10
     wflops = 2 * segs.rows * 256 * 256 * 9
     ach = wflops / (wms * 1e-3) / 1e12
+    amp_roof = None
+    if amp:   # the f16 side of the AMP step: the head tower 3x3 forward (256 -> 512, five levels) on v_mfma_f32_32x32x16_f16, against the dense f16 peak
+        from pytorch_object_detection_amd import _lib as L
+        wt = torch.randn(512, 256, 3, 3, device=dev) / 48.0
+        wp16 = ops.pack_conv_weight_hip(wt, f16=True)
+        yt = ops.Rows(torch.empty(segs.rows, 512, device=dev))
+        ft = ops.conv_call(xr, segs, wp16, yt, Cin=256, Cout=512, k=3, pad=1, precision=L.PREC_F16)
+        for _ in range(3):
+            ft()
+        e0.record()
+        for _ in range(10):
+            ft()
+        e1.record()
+        e1.synchronize()
+        tms = e0.elapsed_time(e1) / 10
+        tfl = 2 * segs.rows * 512 * 256 * 9
+        amp_roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<..., H1> head tower 3x3 forward (cls_conv+reg_conv fused, 5 levels), f16 operands / fp32 accumulate",
+                    "instruction": "v_mfma_f32_32x32x16_f16", "achieved": round(tfl / (tms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                    "frac": round(tfl / (tms * 1e-3) / 1e12 / 2500.0, 4), "traffic": None, "flops_per_launch": tfl, "avg_launch_ms": round(tms, 4)}
     print(json.dumps({
         "metric": f"images/sec HISFCOS-R50 {size}x{size} train step (GIoU loss, SGD)", "value": round(batch * world * args.steps / el, 2),
         "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f16 operands / f32 accumulate (torch.autocast + GradScaler, the reference's AMP arithmetic; norms, losses, weight gradient f32)" if amp else "f32",
+        "data": "synthetic", "amp": amp, "roofline_amp_f16": amp_roof,
         "config": {"workload": f"HISFCOS-R50 train.py step, {batch} x {size}x{size} images/GPU, {ncls} classes, 8 GT boxes/image, "
                                "HIP forward/backward/target/loss kernels" + (", DDP gradient all-reduce + SyncBatchNorm statistics all-reduces over RCCL" if use_dist else ""),
                    "batchnorm": "backbone frozen (eval); FPN BatchNorms on batch statistics" + (" over all ranks (SyncBatchNorm on the HIP statistics kernels)" if use_dist else ""),
@@ -557,6 +582,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, choices=[1, 2],
                     help="batches in flight per GPU: 2 = consecutive steps alternate between two plan instances on two HIP streams "
                          "(throughput), 1 = one stream, every step behind the previous one")
+    ap.add_argument("--amp", action="store_true", help="--mode train: the step under torch.autocast(float16) + GradScaler (train.py:33,175-181): f16 MFMA operands, fp32 accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra opt-in f16x3 measurement")
     ap.add_argument("--save-tuning", action="store_true", help="write the conv tile table measured in this run back to tuned/gfx950_tiles.json")

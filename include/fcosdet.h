@@ -210,6 +210,9 @@ typedef struct fd_conv_wgrad_params {
     int32_t layout;  /* dw layout: 0 = [Cout][KH][KW][Cin] (OHWI), 1 = [Cout][Cin][KH][KW] (OIHW, torch's parameter layout) */
     const float* scale; /* optional [Cout]: dw[co] *= scale[co] (a frozen BatchNorm folded into the forward epilogue) */
     fd_segs in;      /* forward INPUT geometry */
+    int32_t precision; /* FD_PREC_F32 (exact, default) | FD_PREC_F16: x and dy rounded to f16 on their way to LDS, v_mfma_f32_32x32x16_f16, fp32
+                          accumulation -- the weight gradient of a convolution under torch.autocast(float16) (train.py:175-181) */
+    int32_t reserved;
 } fd_conv_wgrad_params;
 
 int64_t fd_conv_wgrad_workspace_bytes(int64_t out_rows, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);

@@ -16,6 +16,7 @@ TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (128, 32), 6
          15: (64, 64)}                               # wave-autonomous 64x64 tiles, one wave per workgroup (1x1 stride-1 layers, needs w_frag)
 PATCH_TILE = 13
 WAVE_TILE = 15
+PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2     # include/fcosdet.h FD_PREC_*
 WINO_TILE = 14      # Winograd F(2x2, 3x3) kernel (own weight packing: ops.pack_conv_weight_wino); not a member of TILES
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -77,7 +78,7 @@ class WgradParams(C.Structure):
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("dil", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("nsplit", C.c_int32), ("layout", C.c_int32),
-                ("scale", C.c_void_p), ("segs", Segs)]
+                ("scale", C.c_void_p), ("segs", Segs), ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None

@@ -48,7 +48,7 @@ class HisBlock(nn.Module):
             sc, sf = T._bn_fold(self.bn1)
             half = self.conv1.out_channels
             both = T._ConvRows.apply(x, torch.cat((self.conv1.weight, self.conv2.weight), 0), torch.cat((sc, torch.ones_like(sc))),
-                                     torch.cat((self.conv1.bias * sc + sf, self.conv2.bias)), None, segs, 1, 0, 1, ACT_NONE)
+                                     torch.cat((self.conv1.bias * sc + sf, self.conv2.bias)), None, segs, 1, 0, 1, ACT_NONE, T.amp_prec())
             x1, x2 = T.act_rows(both[:, :half], ACT_SILU), both[:, half:]
         else:
             x1 = T.conv_norm_act_rows(self.conv1, self.bn1, x, segs, ACT_SILU)
@@ -79,7 +79,7 @@ class HisBlock(nn.Module):
             both = T._ConvRows.apply(T.to_rows(x), torch.cat((self.conv1.weight, self.conv2.weight), 0),
                                      torch.cat((sc, torch.ones_like(sc))),
                                      torch.cat((self.conv1.bias * sc + sf, self.conv2.bias)), None, Segs.make(B, [(H, W)]), 1, 0, 1,
-                                     ACT_NONE)
+                                     ACT_NONE, T.amp_prec())
             x1 = F.silu(T.from_rows(both[:, :half], B, H, W))    # SiLU stock (its derivative needs the pre-activation)
             x2 = T.from_rows(both[:, half:], B, H, W)
         else:

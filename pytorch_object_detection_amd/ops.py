@@ -386,9 +386,10 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
 
 
 def conv_wgrad(x: Rows, dy: Rows, segs_in: Segs, *, Cin: int, Cout: int, k: int, stride: int = 1, pad: int = 0,
-               dil: int = 1, nsplit: int = 0, scale: Optional[torch.Tensor] = None, oihw: bool = False) -> torch.Tensor:
+               dil: int = 1, nsplit: int = 0, scale: Optional[torch.Tensor] = None, oihw: bool = False, precision: int = 0) -> torch.Tensor:
     """Weight gradient of conv(x) w.r.t. its weights given dy (rows in output geometry): [Cout, k, k, Cin] (OHWI), or
-    torch's [Cout, Cin, k, k] with oihw=True; `scale` [Cout] multiplies it per output channel (folded frozen BN)."""
+    torch's [Cout, Cin, k, k] with oihw=True; `scale` [Cout] multiplies it per output channel (folded frozen BN).
+    precision = FD_PREC_F16 (AMP): operands rounded to f16, fp32 accumulation (fd_conv_wgrad_params.precision)."""
     out_rows = conv_out_segs(segs_in, k, stride, pad, dil).rows
     dev = x.buf.device
     dw = torch.empty((Cout, Cin, k, k) if oihw else (Cout, k, k, Cin), dtype=torch.float32, device=dev)
@@ -403,17 +404,19 @@ def conv_wgrad(x: Rows, dy: Rows, segs_in: Segs, *, Cin: int, Cout: int, k: int,
     p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = Cin, Cout, k, k, stride, pad, dil
     p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     p.segs = segs_in
+    p.precision = precision
     check(_lib.lib().fd_conv2d_bwd_weight_f32(C.byref(p), _stream()), "fd_conv2d_bwd_weight_f32")
     return dw
 
 
-def pack_conv_weight_hip(w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False) -> torch.Tensor:
-    """pack_conv_weight (dgrad=False) or dgrad_weight with a per-output-channel scale (dgrad=True) as one HIP launch."""
+def pack_conv_weight_hip(w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False, f16: bool = False) -> torch.Tensor:
+    """pack_conv_weight (dgrad=False) or dgrad_weight with a per-output-channel scale (dgrad=True) as one HIP launch; f16=True: the
+    (hi, lo) f16 operand format of FD_PREC_F16 / FD_PREC_F16X3 (same byte size, returned as an fp32-typed buffer)."""
     w = w.detach().contiguous()
     co, ci, kh, kw = w.shape
     out = torch.empty((ci, co // 32, kh, kw, 32) if dgrad else (co, ci // 32, kh, kw, 32), dtype=torch.float32, device=w.device)
     check(_lib.lib().fd_pack_conv_weight_f32(w.data_ptr(), scale.data_ptr() if (scale is not None and dgrad) else None,
-                                             out.data_ptr(), co, ci, kh, kw, 1 if dgrad else 0, _stream()),
+                                             out.data_ptr(), co, ci, kh, kw, (1 if dgrad else 0) | (4 if f16 else 0), _stream()),
           "fd_pack_conv_weight_f32")
     return out
 
@@ -497,7 +500,7 @@ def strided_dgrad_classes(k: int, stride: int, pad: int):
 
 
 def conv_dgrad_strided(dy: Rows, w: torch.Tensor, scale: Optional[torch.Tensor], dx: Rows, N: int, H: int, W: int, k: int,
-                       stride: int, pad: int, res: Optional[Rows] = None, res_mask: bool = False) -> bool:
+                       stride: int, pad: int, res: Optional[Rows] = None, res_mask: bool = False, precision: int = 0) -> bool:
     """dX of y = conv(x, w, stride >= 2, pad, dilation 1) on the MFMA conv kernel, exact FLOPs: one stride-1 launch per parity
     class (h % stride, w % stride) over dY with that class's taps, outputs interleaved straight into dX (fd_conv_params out_H /
     sc_*).  dx must be zero-initialised when some class has no tap (1x1 stride 2).  `scale` [Cout]: a folded frozen BatchNorm;
@@ -518,9 +521,9 @@ def conv_dgrad_strided(dy: Rows, w: torch.Tensor, scale: Optional[torch.Tensor],
             sub = wd[:, :, r0::stride, q0::stride].contiguous()                      # [Cout, Cin, Ta, Tb]
             out = torch.empty(Cin, Cout // 32, Ta, Tb, 32, dtype=torch.float32, device=w.device)
             check(_lib.lib().fd_pack_conv_weight_f32(sub.data_ptr(), scale.data_ptr() if scale is not None else None, out.data_ptr(),
-                                                     Cout, Cin, Ta, Tb, 1, _stream()), "fd_pack_conv_weight_f32")
+                                                     Cout, Cin, Ta, Tb, 1 | (4 if precision else 0), _stream()), "fd_pack_conv_weight_f32")
             conv_call(dy, segs, out, dx, Cin=Cout, Cout=Cin, k=Ta, kw=Tb, stride=1, pad=0, res=res, res_mask=res_mask,
-                      out_hw=(Ia, Jb), scatter=(stride, stride, a, b, H, W))()
+                      out_hw=(Ia, Jb), scatter=(stride, stride, a, b, H, W), precision=precision)()
     return True
 
 

@@ -35,6 +35,19 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SILU, Rows
 _fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _bwd = torch.amp.custom_bwd(device_type="cuda")
 
+AMP_F16 = os.environ.get("FD_AMP_F16", "1") != "0"      # "0": the HIP nodes compute in fp32 under torch.autocast too (wider than the reference)
+
+
+def amp_prec() -> int:
+    """Conv arithmetic of the HIP nodes for the current autocast state: under torch.autocast(float16) -- how the reference trains
+    (train.py:33 amp_enabled, :175-181 autocast + GradScaler) -- dense convolutions (forward, data gradient, weight gradient) run with
+    f16 operands and fp32 accumulation (FD_PREC_F16: what autocast's fp16 convolution computes); GroupNorm / BatchNorm statistics,
+    depthwise convs, SE, activations and the losses stay fp32, as autocast keeps normalisation and loss ops.  Otherwise exact fp32."""
+    if AMP_F16 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16:
+        return _lib.PREC_F16
+    return _lib.PREC_F32
+
+
 _STOCK = os.environ.get("FD_TRAIN_STOCK_CONV") == "1"   # diagnostic: route every layer to the stock ops (timing comparisons)
 STATS = {"cl_copies": 0, "stock_fallbacks": 0}           # activation-sized layout copies made on entry / stock-op fallbacks taken (both should stay 0)
 # FD_STRICT=1 (the test suite's default, tests/conftest.py): a layer of the TRAINING forward / backward that the HIP kernels do not cover
@@ -182,18 +195,20 @@ class _PackCache:
         self.table = None           # (signature, device tensor of fd_pack_job, max_elems)
 
     @staticmethod
-    def _key(w, scale, dgrad, wino=False):
-        return (w.data_ptr(), tuple(w.shape), bool(dgrad), scale.data_ptr() if (scale is not None and dgrad) else 0, bool(wino))
+    def _key(w, scale, dgrad, wino=False, f16=False):
+        return (w.data_ptr(), tuple(w.shape), bool(dgrad), scale.data_ptr() if (scale is not None and dgrad) else 0, (2 if f16 else 0) + (1 if wino else 0))
 
     @staticmethod
-    def _pack_now(w, scale, dgrad, wino):
+    def _pack_now(w, scale, dgrad, wino, f16=False):
         if not wino:
-            return ops.pack_conv_weight_hip(w, scale, dgrad)
+            out = ops.pack_conv_weight_hip(w, scale, dgrad, f16)
+            out._fd_prec = _lib.PREC_F16 if f16 else _lib.PREC_F32
+            return out
         out = ops.pack_conv_weight_wino(w, scale, dgrad)
         out._fd_wino = (w.shape[1] if dgrad else w.shape[0])       # marks the Winograd packing for _conv_launch (value = output channels)
         return out
 
-    def get(self, w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False, wino: bool = False) -> torch.Tensor:
+    def get(self, w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False, wino: bool = False, f16: bool = False) -> torch.Tensor:
         """Packed weights for the conv kernel: the direct kernel's layout, or (wino=True, 3x3 stride-1 'same' layers) the Winograd
         F(2x2, 3x3) packing of fd_conv_wino.hip; dgrad=True = the flipped / transposed / BN-scaled weights of the data gradient."""
         import weakref
@@ -202,13 +217,13 @@ class _PackCache:
         ref = self.params.get(w.data_ptr())
         owner = ref() if ref is not None else None
         if owner is None or owner.data_ptr() != w.data_ptr() or owner.shape != w.shape or not w.is_contiguous():
-            return self._pack_now(w, scale, dgrad, wino)                  # a temporary (merged / padded weights): pack now
-        key = self._key(w, scale, dgrad, wino)
+            return self._pack_now(w, scale, dgrad, wino, f16)             # a temporary (merged / padded weights): pack now
+        key = self._key(w, scale, dgrad, wino, f16)
         e = self.entries.get(key)
         if e is not None and e[0]() is not owner:       # the address was recycled by another parameter: drop the old entry
             e = None
         if e is None:
-            out = self._pack_now(w, scale, dgrad, wino)
+            out = self._pack_now(w, scale, dgrad, wino, f16)
             self.entries[key] = [ref, scale, dgrad, out, w._version]
             self.table = None
             return out
@@ -219,7 +234,7 @@ class _PackCache:
                 ops.check(_lib.lib().fd_wino_pack_weights_f32(w.data_ptr(), sp, e[3].data_ptr(), co, ci, 1 if dgrad else 0, ops._stream()),
                           "fd_wino_pack_weights_f32")
             else:
-                ops.check(_lib.lib().fd_pack_conv_weight_f32(w.data_ptr(), sp, e[3].data_ptr(), co, ci, kh, kw, 1 if dgrad else 0,
+                ops.check(_lib.lib().fd_pack_conv_weight_f32(w.data_ptr(), sp, e[3].data_ptr(), co, ci, kh, kw, (1 if dgrad else 0) | (4 if f16 else 0),
                                                              ops._stream()), "fd_pack_conv_weight_f32")
             e[4] = w._version
         return e[3]
@@ -247,7 +262,7 @@ class _PackCache:
             for j, (key, e) in zip(jobs, live.items()):
                 co, ci, kh, kw = key[1]
                 j.w, j.scale, j.out = key[0], (e[1].data_ptr() if (e[1] is not None and e[2]) else None), e[3].data_ptr()
-                j.Cout, j.Cin, j.KH, j.KW, j.mode = co, ci, kh, kw, (2 if key[4] else 0) + (1 if e[2] else 0)
+                j.Cout, j.Cin, j.KH, j.KW, j.mode = co, ci, kh, kw, (2 if key[4] & 1 else 0) + (1 if e[2] else 0) + (4 if key[4] & 2 else 0)
                 mx = max(mx, co * ci * kh * kw)
             raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).clone()
             dev = next(iter(live.values()))[3].device
@@ -261,12 +276,12 @@ class _PackCache:
 PACKS = _PackCache()
 
 
-def _wino(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int, segs: Segs) -> bool:
+def _wino(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int, segs: Segs, prec: int = 0) -> bool:
     """3x3 stride-1 'same' layers run on the Winograd kernel -- forward (Cin -> Cout) and, with the channel roles swapped, data
     gradient -- unless FD_WINOGRAD=0 (the switch of the inference plans) or the map is so small that the direct kernel's split-K
     wins (ops.wino_preferred, the rule of the inference plans)."""
     from . import engine
-    return engine.WINOGRAD and ops.wino_ok(Cin, Cout, k, stride, pad, dil) and ops.wino_preferred(segs, Cin, Cout, dil)
+    return prec == 0 and engine.WINOGRAD and ops.wino_ok(Cin, Cout, k, stride, pad, dil) and ops.wino_preferred(segs, Cin, Cout, dil)
 
 _TILE_CACHE: dict = {}
 
@@ -283,6 +298,11 @@ def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.T
         return
     Cin, Cout = x.shape[1], w_packed.shape[0]
     out_rows = y.shape[0]
+    prec = getattr(w_packed, "_fd_prec", 0)
+    if prec:             # f16 operands (AMP): the library's own tile choice (the tuned table holds fp32 timings), no split-K
+        ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift,
+                      res=_r(res) if res is not None else None, act=act, res_mask=res_mask, precision=prec)()
+        return
     KT = (Cin // 32) * k * k
     hw = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
     key = f"B{segs.batch}|{hw}|{Cin}>{Cout}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{Cin}|ycs{Cout}"   # (mask / add: same cost)
@@ -304,7 +324,7 @@ def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.T
 
 
 def _strided_dgrad(g: torch.Tensor, weight: torch.Tensor, scale: Optional[torch.Tensor], segs: Segs, k: int, stride: int, pad: int,
-                   res: Optional[torch.Tensor] = None, res_mask: bool = False) -> Optional[torch.Tensor]:
+                   res: Optional[torch.Tensor] = None, res_mask: bool = False, prec: int = 0) -> Optional[torch.Tensor]:
     """dX rows of a strided single-level conv from dY rows `g` on the HIP conv kernel (None: geometry not covered)."""
     if _STOCK or segs.nseg != 1:
         return None
@@ -313,7 +333,7 @@ def _strided_dgrad(g: torch.Tensor, weight: torch.Tensor, scale: Optional[torch.
     empty_class = any(T == 0 for _, T, _ in ops.strided_dgrad_classes(k, stride, pad))
     gx = (torch.zeros if empty_class else torch.empty)(B * H * W, Cin, dtype=torch.float32, device=g.device)
     ok = ops.conv_dgrad_strided(_r(g), weight, scale, _r(gx), B, H, W, k, stride, pad, res=_r(res) if res is not None else None,
-                                res_mask=res_mask)
+                                res_mask=res_mask, precision=prec)
     if not ok:
         return None
     if res_mask and empty_class and res is not None:
@@ -326,25 +346,25 @@ class _ConvRows(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, x, weight, scale, shift, residual, segs, stride, pad, dil, act):
+    def forward(ctx, x, weight, scale, shift, residual, segs, stride, pad, dil, act, prec=0):
         if act not in (ACT_NONE, ACT_RELU):
             raise FdError("_ConvRows differentiates ACT_NONE / ACT_RELU epilogues only (use act_rows for SiLU: it keeps the pre-activation)")
         x = x.contiguous()
         Cout, _, k, _ = weight.shape
         so = ops.conv_out_segs(segs, k, stride, pad, dil)
         y = torch.empty(so.rows, Cout, dtype=torch.float32, device=x.device)
-        _conv_launch(x, segs, PACKS.get(weight, wino=_wino(x.shape[1], Cout, k, stride, pad, dil, segs)), y, k=k, stride=stride, pad=pad,
-                     dil=dil, scale=scale, shift=shift.detach().contiguous() if shift is not None else None,
+        _conv_launch(x, segs, PACKS.get(weight, wino=_wino(x.shape[1], Cout, k, stride, pad, dil, segs, prec), f16=bool(prec)), y, k=k, stride=stride,
+                     pad=pad, dil=dil, scale=scale, shift=shift.detach().contiguous() if shift is not None else None,
                      res=residual.contiguous() if residual is not None else None, act=act)
         ctx.save_for_backward(x, weight, scale, y if act == ACT_RELU else None)
-        ctx.geom = (segs, so, stride, pad, dil, act)
+        ctx.geom = (segs, so, stride, pad, dil, act, prec)
         return y
 
     @staticmethod
     @_bwd
     def backward(ctx, gy):
         x, weight, scale, y = ctx.saved_tensors
-        segs, so, stride, pad, dil, act = ctx.geom
+        segs, so, stride, pad, dil, act, prec = ctx.geom
         g = gy.contiguous()
         if act == ACT_RELU:
             g = relu_mask(g, y)
@@ -356,9 +376,9 @@ class _ConvRows(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if stride == 1 and Cout % 32 == 0:
                 gx = torch.empty_like(x)
-                _conv_launch(g, so, PACKS.get(weight, scale, dgrad=True, wino=_wino(Cout, Cin, k, stride, dil * (k - 1) - pad, dil, so)), gx,
-                             k=k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
-            elif segs.nseg == 1 and stride > 1 and dil == 1 and (gx := _strided_dgrad(g, weight, scale, segs, k, stride, pad)) is not None:
+                _conv_launch(g, so, PACKS.get(weight, scale, dgrad=True, wino=_wino(Cout, Cin, k, stride, dil * (k - 1) - pad, dil, so, prec), f16=bool(prec)),
+                             gx, k=k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
+            elif segs.nseg == 1 and stride > 1 and dil == 1 and (gx := _strided_dgrad(g, weight, scale, segs, k, stride, pad, prec=prec)) is not None:
                 pass                                   # strided layer: one exact-FLOP launch per parity class (ops.conv_dgrad_strided)
             elif segs.nseg == 1:  # what is left (narrow Cout, dilated + strided): stock op for the data gradient
                 stock_fallback(f"the data gradient of a {k}x{k} stride-{stride} conv with Cout={Cout}")
@@ -372,10 +392,10 @@ class _ConvRows(torch.autograd.Function):
                 raise FdError("data gradient of a strided / narrow conv over a pyramid is not supported (pad Cout to 32)")
         if ctx.needs_input_grad[1]:
             gw = ops.conv_wgrad(_r(x), _r(g), segs, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
-                                oihw=True)
+                                oihw=True, precision=prec)
         if ctx.needs_input_grad[3]:
             gshift = g.sum(dim=0)
-        return gx, gw, None, gshift, gres, None, None, None, None, None
+        return gx, gw, None, gshift, gres, None, None, None, None, None, None
 
 
 def conv_rows(m: nn.Conv2d, x: torch.Tensor, segs: Segs, bn: Optional[nn.Module] = None, act: int = ACT_NONE,
@@ -395,7 +415,7 @@ def conv_rows(m: nn.Conv2d, x: torch.Tensor, segs: Segs, bn: Optional[nn.Module]
             scale, shift = F.pad(scale, (0, padn), value=1.0), F.pad(shift, (0, padn))
     if b is not None:
         shift = b if scale is None else b * scale + shift
-    y = _ConvRows.apply(x, w, scale, shift, residual, segs, m.stride[0], _pad_of(m), m.dilation[0], act)
+    y = _ConvRows.apply(x, w, scale, shift, residual, segs, m.stride[0], _pad_of(m), m.dilation[0], act, amp_prec())
     return y[:, :Cout] if padn else y
 
 
@@ -418,50 +438,52 @@ class _BottleneckRows(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, x, w1, w2, w3, wd, c1, c2, c3, cd, segs, stride):
+    def forward(ctx, x, w1, w2, w3, wd, c1, c2, c3, cd, segs, stride, prec=0):
         x = x.contiguous()
+        h = bool(prec)
         dev = x.device
         so = ops.conv_out_segs(segs, 3, stride, 1, 1)
         P, C4 = w1.shape[0], w3.shape[0]
         y1 = torch.empty(segs.rows, P, dtype=torch.float32, device=dev)
         y2 = torch.empty(so.rows, P, dtype=torch.float32, device=dev)
         out = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
-        _conv_launch(x, segs, PACKS.get(w1), y1, k=1, stride=1, pad=0, dil=1, scale=c1[0], shift=c1[1], act=ACT_RELU)
-        _conv_launch(y1, segs, PACKS.get(w2, wino=_wino(P, P, 3, stride, 1, 1, segs)), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0], shift=c2[1],
-                     act=ACT_RELU)
+        _conv_launch(x, segs, PACKS.get(w1, f16=h), y1, k=1, stride=1, pad=0, dil=1, scale=c1[0], shift=c1[1], act=ACT_RELU)
+        _conv_launch(y1, segs, PACKS.get(w2, wino=_wino(P, P, 3, stride, 1, 1, segs, prec), f16=h), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0],
+                     shift=c2[1], act=ACT_RELU)
         if wd is not None:
             idt = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
-            _conv_launch(x, segs, PACKS.get(wd), idt, k=1, stride=stride, pad=0, dil=1, scale=cd[0], shift=cd[1])
+            _conv_launch(x, segs, PACKS.get(wd, f16=h), idt, k=1, stride=stride, pad=0, dil=1, scale=cd[0], shift=cd[1])
         else:
             idt = x
-        _conv_launch(y2, so, PACKS.get(w3), out, k=1, stride=1, pad=0, dil=1, scale=c3[0], shift=c3[1], res=idt,
+        _conv_launch(y2, so, PACKS.get(w3, f16=h), out, k=1, stride=1, pad=0, dil=1, scale=c3[0], shift=c3[1], res=idt,
                      act=ACT_RELU)
         ctx.save_for_backward(x, y1, y2, out, w1, w2, w3, wd, c1[0], c2[0], c3[0], cd[0] if wd is not None else None)
-        ctx.geom = (segs, so, stride)
+        ctx.geom = (segs, so, stride, prec)
         return out
 
     @staticmethod
     @_bwd
     def backward(ctx, gout):
         x, y1, y2, out, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors
-        segs, so, stride = ctx.geom
+        segs, so, stride, prec = ctx.geom
+        h = bool(prec)
         need_x = ctx.needs_input_grad[0]
         P, Cin, C4 = w1.shape[0], w1.shape[1], w3.shape[0]
         g = relu_mask(gout.contiguous(), out)                                        # the one elementwise pass of the block
         gw1 = gw2 = gw3 = gwd = gx = None
         wg = lambda xx, gg, sg, Ci, Co, k, st, pad, sc: ops.conv_wgrad(_r(xx), _r(gg), sg, Cin=Ci, Cout=Co, k=k, stride=st,  # noqa: E731
-                                                                     pad=pad, dil=1, scale=sc, oihw=True)
+                                                                     pad=pad, dil=1, scale=sc, oihw=True, precision=prec)
         if ctx.needs_input_grad[3]:
             gw3 = wg(y2, g, so, P, C4, 1, 1, 0, s3)
         g2 = torch.empty_like(y2)                                                    # d/d(conv2 output), ReLU-masked in the epilogue
-        _conv_launch(g, so, PACKS.get(w3, s3, dgrad=True), g2, k=1, stride=1, pad=0, dil=1, res=y2, res_mask=True)
+        _conv_launch(g, so, PACKS.get(w3, s3, dgrad=True, f16=h), g2, k=1, stride=1, pad=0, dil=1, res=y2, res_mask=True)
         if ctx.needs_input_grad[2]:
             gw2 = wg(y1, g2, segs, P, P, 3, stride, 1, s2)
         if stride == 1:
             g1 = torch.empty_like(y1)
-            _conv_launch(g2, so, PACKS.get(w2, s2, dgrad=True, wino=_wino(w2.shape[0], w2.shape[1], 3, 1, 1, 1, so)), g1, k=3, stride=1, pad=1, dil=1,
-                         res=y1, res_mask=True)
-        elif (g1 := _strided_dgrad(g2, w2, s2, segs, 3, stride, 1, res=y1, res_mask=True)) is not None:
+            _conv_launch(g2, so, PACKS.get(w2, s2, dgrad=True, wino=_wino(w2.shape[0], w2.shape[1], 3, 1, 1, 1, so, prec), f16=h), g1, k=3, stride=1, pad=1,
+                         dil=1, res=y1, res_mask=True)
+        elif (g1 := _strided_dgrad(g2, w2, s2, segs, 3, stride, 1, res=y1, res_mask=True, prec=prec)) is not None:
             pass    # strided 3x3: four parity-class launches on the conv kernel, ReLU mask of y1 applied in their epilogues
         else:   # strided 3x3: stock data gradient, masked separately
             stock_fallback("the data gradient of a bottleneck's strided 3x3 conv")
@@ -478,8 +500,8 @@ class _BottleneckRows(torch.autograd.Function):
                 gid = g                                                             # identity path
             elif stride == 1:
                 gid = torch.empty_like(x)
-                _conv_launch(g, so, PACKS.get(wd, sd, dgrad=True), gid, k=1, stride=1, pad=0, dil=1)
-            elif (gid := _strided_dgrad(g, wd, sd, segs, 1, stride, 0)) is not None:
+                _conv_launch(g, so, PACKS.get(wd, sd, dgrad=True, f16=h), gid, k=1, stride=1, pad=0, dil=1)
+            elif (gid := _strided_dgrad(g, wd, sd, segs, 1, stride, 0, prec=prec)) is not None:
                 pass    # 1x1 stride-2 downsample: the (0, 0) parity class is a plain GEMM scattered into a zeroed dX
             else:
                 stock_fallback("the data gradient of a bottleneck's strided downsample conv")
@@ -488,8 +510,8 @@ class _BottleneckRows(torch.autograd.Function):
                                                                    wd.detach() * sd.view(-1, 1, 1, 1), None, [stride, stride], [0, 0],
                                                                    [1, 1], False, [0, 0], 1, [True, False, False])[0])
             gx = torch.empty_like(x)                                                # conv1's data gradient + the identity gradient
-            _conv_launch(g1, segs, PACKS.get(w1, s1, dgrad=True), gx, k=1, stride=1, pad=0, dil=1, res=gid)
-        return gx, gw1, gw2, gw3, gwd, None, None, None, None, None, None
+            _conv_launch(g1, segs, PACKS.get(w1, s1, dgrad=True, f16=h), gx, k=1, stride=1, pad=0, dil=1, res=gid)
+        return gx, gw1, gw2, gw3, gwd, None, None, None, None, None, None, None
 
 
 def bottleneck(blk: nn.Module, x: torch.Tensor) -> torch.Tensor:
@@ -513,7 +535,7 @@ def bottleneck(blk: nn.Module, x: torch.Tensor) -> torch.Tensor:
     s = blk.conv2.stride[0]
     out = _BottleneckRows.apply(to_rows(x), blk.conv1.weight, blk.conv2.weight, blk.conv3.weight, ds[0].weight if ds is not None else None,
                                 _bn_fold(blk.bn1), _bn_fold(blk.bn2), _bn_fold(blk.bn3), _bn_fold(ds[1]) if ds is not None else (None, None),
-                                Segs.make(B, [(H, W)]), s)
+                                Segs.make(B, [(H, W)]), s, amp_prec())
     return from_rows(out, B, (H - 1) // s + 1, (W - 1) // s + 1)
 
 
