@@ -286,13 +286,14 @@ def postproc_bench(dev, ncls: int = 80, size: int = 640):
     return res
 
 
-def fast_mode(model, head, clip, x, args, ref_res):
+def fast_mode(model, head, clip, x, args, ref_res, precision="f16x3"):
     """Extra, NOT the headline: the same model with conv_precision='f16x3' (three f16 MFMAs per fp32 product, fp32
-    accumulation; passes the same 1e-4 parity tests).  Reports its throughput, its head-tower rate and its deviation
-    from the exact-fp32 path on this batch."""
+    accumulation; passes the same 1e-4 parity tests) -- or 'mixed': only the 1x1 layers on the split-f16 products, the 3x3
+    stride-1 layers on the exact-fp32 Winograd kernel.  Reports its throughput, its head-tower rate and its deviation
+    from the exact-fp32 path on this batch (one batch in flight)."""
     from pytorch_object_detection_amd import ops
     ref_out = [[t.clone() for t in grp] for grp in model(x)]
-    model.conv_precision = "f16x3"
+    model.conv_precision = precision
     try:
         plan = model.plan_for(x)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -312,14 +313,38 @@ def fast_mode(model, head, clip, x, args, ref_res):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         dev_abs = max(float((a - b).abs().max()) for g1, g2 in zip(out, ref_out) for a, b in zip(g1, g2))
+        dev_rel = max(float(((a - b).abs() / (b.abs() + 1.0)).max()) for g1, g2 in zip(out, ref_out) for a, b in zip(g1, g2))
         tower_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
         flops = 2 * plan.segs.rows * 512 * 256 * 9
-        return {"conv_precision": "f16x3 (x = hi + lo*2^-11, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
-                "value": round(args.batch * args.steps / el, 2), "unit": "images/sec", "ms_per_step": round(el / args.steps * 1e3, 3),
-                "head_tower_tflops_fp32_equivalent": round(flops / (tower_ms * 1e-3) / 1e12, 1),
-                "head_tower_f16_mfma_frac_of_2500TF": round(3 * flops / (tower_ms * 1e-3) / 1e12 / 2500.0, 3),
-                "max_abs_dev_vs_f32_path": dev_abs,
-                "same_kept_counts_as_f32_path": bool(torch.equal(counts, ref_res[3][:args.batch]))}
+        r = {"conv_precision": ("f16x3 (x = hi + lo*2^-11, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)" if precision == "f16x3" else
+                                "mixed: 1x1 layers f16x3, 3x3 stride-1 layers exact-fp32 Winograd F(2x2,3x3)"),
+             "value": round(args.batch * args.steps / el, 2), "unit": "images/sec", "ms_per_step": round(el / args.steps * 1e3, 3), "batches_in_flight": 1,
+             "head_tower_tflops_fp32_equivalent": round(flops / (tower_ms * 1e-3) / 1e12, 1),
+             "max_abs_dev_vs_f32_path": dev_abs, "max_dev_over_1_plus_abs_vs_f32_path": dev_rel,
+             "same_kept_counts_as_f32_path": bool(torch.equal(counts, ref_res[3][:args.batch]))}
+        if precision == "f16x3":
+            r["head_tower_f16_mfma_frac_of_2500TF"] = round(3 * flops / (tower_ms * 1e-3) / 1e12 / 2500.0, 3)
+        if args.inflight == 2:      # the same schedule as the headline: two batches in flight, the tower exclusive
+            from pytorch_object_detection_amd.pipeline import TwoLanePipeline
+
+            def post(o, xx, tag):
+                s, c, b = head.decode_topk(o)
+                return ops.batched_nms(s, c, b, 0.05, 0.6)[4]
+            pipe = TwoLanePipeline(model, post)
+            pipe.calibrate(x)
+            for _ in range(args.warmup):
+                pipe.submit(x)
+            pipe.drain()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                pipe.submit(x)
+            pipe.drain()
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t0
+            r["value_two_batches_in_flight"] = round(args.batch * args.steps / el2, 2)
+            r["ms_per_step_two_batches_in_flight"] = round(el2 / args.steps * 1e3, 3)
+        return r
     finally:
         model.conv_precision = None
 
@@ -437,7 +462,8 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
     lv = [(size // st, size // st) for st in (8, 16, 32, 64, 128)]
     segs = Segs.make(batch, lv)
     xr, dy = ops.Rows(torch.randn(segs.rows, 256, device=dev)), ops.Rows(torch.randn(segs.rows, 256, device=dev))
-    f = lambda: ops.conv_wgrad(xr, dy, segs, Cin=256, Cout=256, k=3, pad=1, oihw=True)  # noqa: E731
+    wprec = 2 if bool(getattr(args, "amp", False)) else 0        # (--amp: the f16-operand weight gradient the AMP step runs)
+    f = lambda: ops.conv_wgrad(xr, dy, segs, Cin=256, Cout=256, k=3, pad=1, oihw=True, precision=wprec)  # noqa: E731
     for _ in range(3):
         f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -472,15 +498,16 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
         "metric": f"images/sec HISFCOS-R50 {size}x{size} train step (GIoU loss, SGD)", "value": round(batch * world * args.steps / el, 2),
         "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 operands / f32 accumulate (torch.autocast + GradScaler, the reference's AMP arithmetic; norms, losses, weight gradient f32)" if amp else "f32",
+        "dtype": "f16 operands / f32 accumulate in every dense conv: forward, data gradient, weight gradient (torch.autocast + GradScaler, the reference's AMP arithmetic); norms, depthwise, losses f32" if amp else "f32",
         "data": "synthetic", "amp": amp, "roofline_amp_f16": amp_roof,
         "config": {"workload": f"HISFCOS-R50 train.py step, {batch} x {size}x{size} images/GPU, {ncls} classes, 8 GT boxes/image, "
                                "HIP forward/backward/target/loss kernels" + (", DDP gradient all-reduce + SyncBatchNorm statistics all-reduces over RCCL" if use_dist else ""),
                    "batchnorm": "backbone frozen (eval); FPN BatchNorms on batch statistics" + (" over all ranks (SyncBatchNorm on the HIP statistics kernels)" if use_dist else ""),
                    "global_batch": batch * world, "parallelism": f"dp{world} (DistributedDataParallel)"},
-        "roofline": {"bound": "mfma", "kernel": "conv_wgrad_kernel (head tower 3x3 weight gradient, 5 levels) + ordered slab reduce",
-                     "instruction": "v_mfma_f32_32x32x2_f32", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "roofline": {"bound": "mfma", "kernel": ("conv_wgrad_f16_kernel" if wprec else "conv_wgrad_kernel") + " (head tower 3x3 weight gradient, 5 levels) + ordered slab reduce",
+                     "instruction": "v_mfma_f32_32x32x16_f16" if wprec else "v_mfma_f32_32x32x2_f32", "achieved": round(ach, 2),
+                     "peak": 2500.0 if wprec else PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(ach / (2500.0 if wprec else PEAK_F32_MFMA_TFLOPS), 4), "traffic": None,
                      "flops_per_launch": wflops, "avg_launch_ms": round(wms, 4)},
         "final_loss": round(float(loss.detach()), 5)}), file=out, flush=True)
 
@@ -582,6 +609,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, choices=[1, 2],
                     help="batches in flight per GPU: 2 = consecutive steps alternate between two plan instances on two HIP streams "
                          "(throughput), 1 = one stream, every step behind the previous one")
+    ap.add_argument("--graph", action="store_true", help="inference: capture the plan's launches into a HIP graph and replay it (the latency path; implies --inflight 1)")
     ap.add_argument("--amp", action="store_true", help="--mode train: the step under torch.autocast(float16) + GradScaler (train.py:33,175-181): f16 MFMA operands, fp32 accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra opt-in f16x3 measurement")
@@ -654,6 +682,8 @@ def main():
         args.no_cpu_baseline = True   # the CPU-baseline leg restates HISFCOS only
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     model.to(dev)
+    if args.graph:
+        model.use_graph, args.inflight = True, 1
     head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
     clip = ClipBoxes()
     gen = torch.Generator().manual_seed(1000 + rank)
@@ -681,6 +711,9 @@ def main():
         return gather_detections(os_, oc, ob, counts, force=use_dist)
 
     def step(i=None):
+        if args.graph:      # the latency path: model + FCOSHead + ClipBoxes as ONE plan, captured into one HIP graph (model.detect)
+            os_, oc, ob, counts = model.detect(x, head)
+            return gather_detections(os_, oc, ob, counts, force=use_dist)
         out = model(x, events=None if i is None else {"head.tower3x3": ev_pairs[i]})
         return post(out, x, i)
 
@@ -720,6 +753,10 @@ def main():
         el = float(t.item())
 
     if rank == 0:
+        if args.graph:      # (a replayed graph has no per-launch events: tower / NMS times come from the same plans launched eagerly afterwards)
+            for i in range(args.steps):
+                post(model(x, events={"head.tower3x3": ev_pairs[i]}), x, i)
+            torch.cuda.synchronize()
         images = args.batch * world * args.steps
         tower_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / args.steps
         nms_ms = sum(a.elapsed_time(b) for a, b in nms_pairs) / args.steps
@@ -734,7 +771,7 @@ def main():
                                    f"fused conv head + HIP NMS ({args.classes} classes, score>=0.05, IoU 0.6, top-1000)"
                                    + (", RCCL detection all-gather" if world > 1 else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (image-sharded)",
-                       "batches_in_flight": args.inflight},
+                       "batches_in_flight": args.inflight, "hip_graph": bool(args.graph)},
             "roofline": tower_roofline(plan, tower_flops, tower_ms),
             "model_conv_tflops": round(plan.flops / (ms_step * 1e-3) / 1e12, 2),
             "nms_boxes_per_ms": round(args.batch * 1000 / nms_ms, 1), "nms_ms": round(nms_ms, 4),
@@ -755,6 +792,7 @@ def main():
         line["kernel_families"] = fams
         if world == 1 and not args.no_fast_mode:
             line["fast_mode"] = fast_mode(model, head, clip, x, args, res)
+            line["fast_mode_mixed"] = fast_mode(model, head, clip, x, args, res, "mixed")
         if world == 1:
             line["nms_micro"] = nms_micro(dev, args.batch, with_cpu=sd_cpu is not None)
             line["postproc"] = postproc_bench(dev, args.classes)

@@ -187,6 +187,141 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
 }
 
+// ---- the same weight gradient with f16 operands (FD_PREC_F16: torch.autocast's arithmetic, train.py:175-181): dY and X are rounded to f16
+// on their way to LDS and multiplied on v_mfma_f32_32x32x16_f16 with fp32 accumulation.  The reduction index of this GEMM is the PIXEL,
+// and both operands arrive pixel-major ([pixel][channel] rows, coalesced along channels), while the MFMA wants 8 consecutive k (pixels)
+// of one channel per lane: the hardware transposing LDS read of gfx950 (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns
+// of 16-bit elements and receives them column-major) turns the staged [pixel][channel] image into operands with no shuffles.
+// LDS image: plain 256-byte rows (128 halves per pixel), 16-byte chunks XORed with ((row & 3) << 2 | (row >> 2) & 3) -- conflict-free for
+// the 8-byte staging writes and for the transposed reads (cdna guide T10, layout (b)).  128 x 128 tiles only (narrower layers are masked).
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+__device__ __forceinline__ int wg16_off(int row, int chunk) { return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+__global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(WgradArgs a) {
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WAVES_N = 2;
+    __shared__ __attribute__((aligned(16))) char As[32 * 256];      // [32 pixels][128 co] f16
+    __shared__ __attribute__((aligned(16))) char Bs[32 * 256];      // [32 pixels][128 ci] f16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int t = blockIdx.x;
+    const int cit = t % a.ci_tiles; t /= a.ci_tiles;
+    const int tap = t % a.ntaps;
+    const int cot = t / a.ntaps;
+    const int co0 = cot * BM, ci0 = cit * BN;
+    const int fr = tap / a.KW, fq = tap - fr * a.KW;
+    const int m_begin = a.is_gemm ? blockIdx.y * a.rows_per_split : a.r_begin[blockIdx.y];
+    const int m_end = a.is_gemm ? min(a.M, m_begin + a.rows_per_split) : a.r_end[blockIdx.y];
+
+    constexpr unsigned OOB = 0xC0000000u;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, (short)0, (int)a.dy_bytes, 0x00020000);
+
+    // staging: 32 threads per pixel row (4 channels each), 8 rows per pass, 4 passes for the 32 pixels of a K-tile
+    const int srow = tid >> 5, sc4 = tid & 31;
+    const bool a_col_ok = co0 + sc4 * 4 < a.Cout, b_col_ok = ci0 + sc4 * 4 < a.Cin;
+    const int gs = a.is_gemm ? 0 : a.r_seg[blockIdx.y];
+    const int g_Wo = a.Wo[gs], g_hw = a.Ho[gs] * a.Wo[gs], g_H = a.H[gs], g_W = a.W[gs], g_mout = a.m_out[gs], g_min = a.m_in[gs];
+    const unsigned g_mgh = a.mg_hw[gs], g_mgw = a.mg_w[gs];
+    const int g_shh = a.sh_hw[gs], g_shw = a.sh_w[gs];
+
+    float4 ra[4], rb[4];
+    auto load_tile = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + srow + 8 * i;
+            const unsigned off = ((unsigned)m * (unsigned)a.dy_cs + (unsigned)(a.dy_co + co0 + sc4 * 4)) * 4u;
+            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(yrsrc, (int)((m < m_end && a_col_ok) ? off : OOB), 0, 0));
+            unsigned xo = OOB;
+            if (m < m_end && b_col_ok) {
+                if (a.is_gemm) {
+                    xo = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + sc4 * 4)) * 4u;
+                } else {
+                    const int local = m - g_mout;
+                    const int n = fast_div(local, g_mgh, g_shh);
+                    const int rem = local - n * g_hw;
+                    const int ho = fast_div(rem, g_mgw, g_shw), wo = rem - ho * g_Wo;
+                    const int hi = ho * a.stride - a.pad + fr * a.dil, wi = wo * a.stride - a.pad + fq * a.dil;
+                    if ((unsigned)hi < (unsigned)g_H && (unsigned)wi < (unsigned)g_W)
+                        xo = ((unsigned)(g_min + (n * g_H + hi) * g_W + wi) * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + sc4 * 4)) * 4u;
+                }
+            }
+            rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)xo, 0, 0));
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 8 * i;
+            const int off = wg16_off(row, sc4 >> 1) + 8 * (sc4 & 1);
+            const f32x4 va = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, vb = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+            *reinterpret_cast<h4*>(As + off) = __builtin_convertvector(va, h4);       // round to nearest
+            *reinterpret_cast<h4*>(Bs + off) = __builtin_convertvector(vb, h4);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // transposed-read addresses: lane 4q + p of the 16-lane group g supplies row q, 8-byte piece p of its block; group g holds channels
+    // 16 (g & 1) .. + 15 of the sub-tile and the k-half g >> 1 (= lane >> 5, as the MFMA operand layout wants)
+    const int grp = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    auto tr_read = [&](const char* base, int sub_chunk0, int ks) -> h8 {
+        const int chunk = sub_chunk0 + 2 * (grp & 1) + (tp >> 1);
+        const int r0 = 16 * ks + 8 * (grp >> 1) + tq;
+        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) fp16x4_t*)(base + wg16_off(r0, chunk) + 8 * (tp & 1)));
+        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) fp16x4_t*)(base + wg16_off(r0 + 4, chunk) + 8 * (tp & 1)));
+        const h4 l4 = __builtin_bit_cast(h4, lo), h4_ = __builtin_bit_cast(h4, hi);
+        return h8{l4[0], l4[1], l4[2], l4[3], h4_[0], h4_[1], h4_[2], h4_[3]};
+    };
+
+    if (m_begin < m_end) {
+        load_tile(m_begin);
+        for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+            __syncthreads();                 // previous tile fully consumed
+            store_tile();
+            __syncthreads();
+            if (m0 + 32 < m_end) load_tile(m0 + 32);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                h8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = tr_read(As, (wm * TM + i) * 4, ks);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = tr_read(Bs, (wn * TN + j) * 4, ks);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    float* out = a.out + (size_t)blockIdx.y * a.slab;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ci = ci0 + wn * (TN * 32) + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wm * (TM * 32) + i * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+                if (co < a.Cout && ci < a.Cin) out[(size_t)co * a.Ktot + tap * a.Cin + ci] = acc[i][j][e];
+            }
+        }
+}
+
 // ordered sum of the split slabs (+ optional per-output-channel scale) written as OHWI (layout 0) or OIHW (layout 1)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4,
                                                             int nsplit, long slab, const float* __restrict__ scale, int layout,
@@ -346,8 +481,10 @@ extern "C" int64_t fd_conv_wgrad_workspace_bytes(int64_t out_rows, int32_t Cin, 
     const int bn = (Cin % 128 == 0) ? 128 : 64;
     const int bm = (Cout <= 32 && bn == 128) ? 32 : 128;
     const int tiles = ((Cout + bm - 1) / bm) * KH * KW * ((Cin + bn - 1) / bn);
-    // upper bound over both split rules (the launcher knows stride / padding, this query does not)
-    const int ns = std::max(wgrad_splits(out_rows, tiles, false), wgrad_splits(out_rows, tiles, true));
+    const int tiles16 = ((Cout + 127) / 128) * KH * KW * ((Cin + 127) / 128);      // FD_PREC_F16: 128 x 128 tiles whatever the widths
+    // upper bound over both split rules (the launcher knows stride / padding, this query does not) and both precisions
+    const int ns = std::max(std::max(wgrad_splits(out_rows, tiles, false), wgrad_splits(out_rows, tiles, true)),
+                            std::max(wgrad_splits(out_rows, tiles16, false), wgrad_splits(out_rows, tiles16, true)));
     // + FD_MAX_SEG: level-aligned ranges give every pyramid level at least one slab of its own
     return (int64_t)(ns + FD_MAX_SEG) * Cout * KH * KW * Cin * 4;
 }
@@ -391,7 +528,10 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
     FD_REQUIRE(xb < 0xC0000000L && yb < 0xC0000000L, FD_E_UNSUPPORTED, "fd_conv2d_bwd_weight: buffer exceeds 3 GiB");
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     a.is_gemm = (p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0) ? 1 : 0;
-    const int bn = (p->Cin % 128 == 0) ? 128 : 64;
+    // FD_PREC_F16: f16 operands on 128 x 128 tiles (narrow predictors, Cout <= 32, stay on the exact-fp32 kernel: a wider result)
+    FD_REQUIRE(p->precision == FD_PREC_F32 || p->precision == FD_PREC_F16, FD_E_INVAL, "fd_conv2d_bwd_weight: precision must be FD_PREC_F32 or FD_PREC_F16");
+    const bool h16 = p->precision == FD_PREC_F16 && p->Cout > 32;
+    const int bn = (h16 || p->Cin % 128 == 0) ? 128 : 64;
     const int bm = (p->Cout <= 32 && bn == 128) ? 32 : 128;
     a.co_tiles = (p->Cout + bm - 1) / bm;
     a.ci_tiles = (p->Cin + bn - 1) / bn;
@@ -436,7 +576,8 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
     const bool need_reduce = nsplit > 1 || p->layout != 0 || p->scale != nullptr;
     a.out = need_reduce ? (float*)p->workspace : p->dw;
     const dim3 grid(tiles, ny);
-    if (bm == 32) hipLaunchKernelGGL((conv_wgrad_kernel<128, 32>), grid, dim3(256), 0, stream, a);
+    if (h16) hipLaunchKernelGGL(conv_wgrad_f16_kernel, grid, dim3(256), 0, stream, a);
+    else if (bm == 32) hipLaunchKernelGGL((conv_wgrad_kernel<128, 32>), grid, dim3(256), 0, stream, a);
     else if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, stream, a);
     FD_CHECK_LAUNCH("fd_conv2d_bwd_weight");

@@ -86,19 +86,56 @@ class Plan:
         self.marks: Dict[str, Tuple[int, int]] = {}
         self.autotune = AUTOTUNE        # time block-tile candidates per conv at plan-build time
         self.precision = precision or CONV_PRECISION
-        if self.precision not in ("f32", "f16x3"):
-            raise FdError(f"unknown conv precision '{self.precision}' (f32 | f16x3)")
+        if self.precision not in ("f32", "f16x3", "mixed"):
+            raise FdError(f"unknown conv precision '{self.precision}' (f32 | f16x3 | mixed)")
         self.tiles: Dict[str, int] = {}
-        self.winograd = WINOGRAD and self.precision == "f32"
+        # 'mixed' (opt-in): the 3x3 stride-1 layers stay on the exact-fp32 Winograd kernel, the GEMM-addressed 1x1 layers -- 48 % of the step,
+        # short K, epilogue-heavy -- take the split-f16 products (three f16 MFMAs per fp32 product = 3/16 of the matrix time, same 1e-4 bar)
+        self.winograd = WINOGRAD and self.precision in ("f32", "mixed")
         self.pair_tuned = pair_tuned       # block tiles picked for throughput beside a second batch (pipeline.TwoLanePipeline)
 
     def add(self, name: str, fn: Callable[[], None]) -> None:
         self.steps.append(fn)
         self.names.append(name)
 
+    graph = None        # torch.cuda.CUDAGraph of one run() (capture_graph): the ~190 launches of a forward replayed as ONE hipGraphLaunch
+
+    def capture_graph(self, warmup: int = 2) -> None:
+        """Capture one run() of the plan into a HIP graph (torch.cuda.CUDAGraph); later run() calls without `events` replay it.
+        For the launch-bound shapes (the reference's own: batch 1, 512 x 512, test.py:202-223 -- ~190 launches of ~10 us each).  The
+        steps read plan-owned buffers at fixed addresses; the caller's image is staged into `static_in` (same shape / dtype as the
+        tensor in image_ref at capture time) by run(), so any input tensor works afterwards.  Inputs whose ADDRESSES the steps bake in
+        per call (the mixed-aspect `collate` list) cannot be captured."""
+        if self.graph is not None:
+            return
+        if getattr(self, "input_mode", None) == "collate":
+            raise FdError("capture_graph: a 'collate' plan rebuilds its pointer table on every run and cannot be captured")
+        src = self.image_ref[0]
+        self.static_in = torch.empty_like(src).copy_(src)
+        self.image_ref[0] = self.static_in
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                for st in self.steps:
+                    st()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for st in self.steps:
+                st()
+        self.graph = g
+
     def run(self, events=None) -> None:
         """Launch every step on the current stream.  `events` maps a mark name to an (start, end) pair of
         torch.cuda.Event recorded around that mark's launches (used by bench.py for per-kernel timing)."""
+        if self.graph is not None and not events:
+            src = self.image_ref[0]
+            if src is not self.static_in:
+                self.static_in.copy_(src)
+                self.image_ref[0] = self.static_in
+            self.graph.replay()
+            return
         if not events:
             for s in self.steps:
                 s()
@@ -156,7 +193,8 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         # the weights get matching zero input channels
         w = torch.nn.functional.pad(_dev(w, dev).detach(), (0, 0, 0, 0, 0, x.C - Cin))
         Cin = x.C
-    split = plan.precision == "f16x3"
+    split = plan.precision == "f16x3" or (plan.precision == "mixed" and k == 1 and stride == 1 and gate is None and gn_stats is None
+                                           and Cin % 32 == 0)
     wino, wino_ks = False, 1
     if (plan.winograd and ops.wino_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0 and
             (res is None or (res.cs % 4 == 0 and res.co % 4 == 0))):
@@ -252,7 +290,7 @@ def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: Lis
                          _dev(trunk.bn1.running_var, dev), trunk.bn1.eps)
     s1 = ops.conv_out_segs(s_in, 7, 2, 3, 1)
     y1 = pool.get(s1.rows, 64)
-    if STEM_KERNEL and plan.precision == "f32" and tuple(trunk.conv1.weight.shape) == (64, 3, 7, 7):
+    if STEM_KERNEL and plan.precision in ("f32", "mixed") and tuple(trunk.conv1.weight.shape) == (64, 3, 7, 7):
         wp = ops.pack_stem7_weight(_dev(trunk.conv1.weight, dev))      # the dedicated stem kernel (fd_stem.hip): patch + filters staged in LDS
         plan.add("backbone.conv1", lambda: ops.stem7x7(x4, wp, y1, batch, H, W, sc, sf, ACT_RELU))
     else:
@@ -365,7 +403,7 @@ def build_efficientnet(plan: Plan, net, batch: int, H: int, W: int, image_ref: L
         sews = ops.se_workspace(batch, ho * wo, mid, dev)
         plan.keep += [wd, w1, b1, w2, b2, sews]
         out = pool.get(so.rows, blk.cout)
-        if SE_GATE_IN_PROJECT and plan.precision == "f32":
+        if SE_GATE_IN_PROJECT and plan.precision in ("f32", "mixed"):
             # the gate is multiplied in by the project conv's loader: no scaling pass (a read and a write of the expanded map) at all
             plan.add(nm + "._se", lambda d=d, w1=w1, b1=b1, w2=w2, b2=b2, sews=sews, hw=ho * wo:
                      ops.se_gate(d, w1, b1, w2, b2, batch, hw, w1.shape[0], sews))
@@ -535,7 +573,7 @@ def _gn_fusable(plan: Plan, gns, Cc: int) -> bool:
     """GroupNorm(s) over Cc channels whose statistics the producer's epilogue can emit and fd_groupnorm_from_rowstats reduce."""
     G = sum(g.num_groups for g in gns)
     cg = Cc // G if G and Cc % G == 0 else 0
-    return (GN_FUSED and plan.precision == "f32" and all(g.num_channels // g.num_groups == cg for g in gns) and cg in (4, 8, 16, 32)
+    return (GN_FUSED and plan.precision in ("f32", "mixed") and all(g.num_channels // g.num_groups == cg for g in gns) and cg in (4, 8, 16, 32)
             and Cc % 32 == 0 and 256 % (2 * G) == 0 and Cc <= 1024 and 256 % (Cc // 4) == 0 and ((Cc // 4) % 64 == 0 or 64 % (Cc // 4) == 0))
 
 
@@ -755,6 +793,64 @@ def build_mn_head(plan: Plan, head, pyr: Rows, segs: Segs):
     _fused_gn(plan, "head.tower_gn", tower, segs, [head.cls_conv[1], head.reg_conv[1]], ACT_SILU)
     pool.put(b2)
     return _out_convs(plan, head, tower, segs, F, ncls)
+
+
+# ------------------------------------------------------------------------------------------------ post-processing inside the plan
+def add_postprocess(plan: Plan, outs, segs: Segs, strides, score_thr: float, iou_thr: float, max_box: int, img_hw, clip: bool = True):
+    """FCOSHead (head.py:52-102: decode, top-k, score threshold, per-class NMS) + ClipBoxes (head.py:152-162) as plan steps on preallocated
+    buffers -- no Python-side allocation between the launches, so the whole detection (model + post-process) is one launch sequence that
+    Plan.capture_graph turns into ONE graph launch (the latency path).  -> (scores [B,K], classes [B,K] int64, boxes [B,K,4], counts [B] int32),
+    padded like FCOSHead.detect_padded; the tensors are plan-owned and overwritten by the next run."""
+    import ctypes as C
+    dev = plan.device
+    cls, cnt, reg = outs
+    nlev = min(len(strides), segs.nseg)
+    if nlev != segs.nseg:
+        raise FdError("add_postprocess: one stride per pyramid level expected")
+    N = segs.batch
+    L = sum(h * w for h, w in segs.level_hw())
+    K = min(int(max_box), L)
+    lib = _lib.lib()
+    st = (C.c_int32 * nlev)(*[int(v) for v in strides][:nlev])
+    scores = torch.empty(N, L, dtype=torch.float32, device=dev)
+    classes = torch.empty(N, L, dtype=torch.int32, device=dev)
+    boxes = torch.empty(N, L, 4, dtype=torch.float32, device=dev)
+    ts = torch.empty(N, K, dtype=torch.float32, device=dev)
+    tc = torch.empty(N, K, dtype=torch.int64, device=dev)
+    tb = torch.empty(N, K, 4, dtype=torch.float32, device=dev)
+    os_ = torch.empty(N, K, dtype=torch.float32, device=dev)
+    oc = torch.empty(N, K, dtype=torch.int64, device=dev)
+    ob = torch.empty(N, K, 4, dtype=torch.float32, device=dev)
+    keep = torch.empty(N, K, dtype=torch.int32, device=dev)
+    counts = torch.empty(N, dtype=torch.int32, device=dev)
+    nb_t, nb_n = lib.fd_topk_workspace_bytes(N, L, K), lib.fd_nms_workspace_bytes(N, K)
+    if nb_t < 0 or nb_n < 0:
+        raise FdError(f"add_postprocess: unsupported N={N} L={L} K={K}")
+    ws_t = torch.empty(max(nb_t // 8, 1), dtype=torch.int64, device=dev)
+    ws_n = torch.empty(max(nb_n // 8, 1), dtype=torch.int64, device=dev)
+    plan.keep += [scores, classes, boxes, ts, tc, tb, os_, oc, ob, keep, counts, ws_t, ws_n, st, segs]
+    ncls = cls.C
+    H, W = img_hw
+
+    def decode():
+        ops.check(lib.fd_fcos_decode(cls.ptr, cls.cs, cls.co, cnt.ptr, cnt.cs, cnt.co, reg.ptr, reg.cs, reg.co, ncls, C.byref(segs), st,
+                                     scores.data_ptr(), classes.data_ptr(), boxes.data_ptr(), ops._stream()), "fd_fcos_decode")
+
+    def topk():
+        ops.check(lib.fd_fcos_topk(scores.data_ptr(), classes.data_ptr(), boxes.data_ptr(), N, L, K, ts.data_ptr(), tc.data_ptr(), tb.data_ptr(),
+                                   None, ws_t.data_ptr() if nb_t > 0 else None, ops._stream()), "fd_fcos_topk")
+
+    def nms():
+        ops.check(lib.fd_batched_nms(ts.data_ptr(), tc.data_ptr(), tb.data_ptr(), N, K, float(score_thr), float(iou_thr), os_.data_ptr(), oc.data_ptr(),
+                                     ob.data_ptr(), keep.data_ptr(), counts.data_ptr(), ws_n.data_ptr(), ops._stream()), "fd_batched_nms")
+
+    plan.add("post.decode", decode)
+    plan.add("post.topk", topk)
+    plan.add("post.nms", nms)
+    if clip:
+        plan.add("post.clip", lambda: ops.check(lib.fd_clip_boxes(ob.data_ptr(), N * K, int(H), int(W), ops._stream()), "fd_clip_boxes"))
+    plan.dets = (os_, oc, ob, counts)
+    return plan.dets
 
 
 # ------------------------------------------------------------------------------------------------ views

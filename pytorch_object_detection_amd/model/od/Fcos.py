@@ -204,5 +204,7 @@ class FCOS(PlannedModule):
             return self._forward_chunked(x, chunk)
         plan = self.plan_for(x)
         plan.image_ref[0] = x.contiguous()
+        if self.use_graph and plan.graph is None and not events:
+            plan.capture_graph()
         plan.run(events)
         return self.outputs_of(plan)

@@ -92,6 +92,8 @@ class PlannedModule(nn.Module):
     pixel_mean = (0.485, 0.456, 0.406)   # dataset/voc.py:57-58
     pixel_std = (0.229, 0.224, 0.225)
 
+    use_graph = False        # True: every plan's launches are captured into a HIP graph on its first forward and replayed afterwards
+                             # (engine.Plan.capture_graph: the latency path -- batch 1 is launch-bound); results are identical
     copy_outputs = False     # True: forward returns fresh tensors (the reference's behaviour) instead of views of plan-owned
                              # buffers that the next forward of the same shape overwrites
 
@@ -133,6 +135,24 @@ class PlannedModule(nn.Module):
         self._check_image(x)
         B, _, H, W = x.shape
         return self._get_plan(("model", B, H, W, str(x.device)), lambda: self.build_plan(B, H, W, x.device))
+
+    def detect(self, x: torch.Tensor, head, clip: bool = True):
+        """model(x) -> FCOSHead -> ClipBoxes as ONE plan (engine.add_postprocess): the padded detections of FCOSHead.detect_padded --
+        (scores [B,K], classes [B,K] int64, boxes [B,K,4] clipped to the image, counts [B] int32) -- with no Python-side work between the
+        launches; with `use_graph` the whole detection is one HIP graph launch.  The reference's test loop (test.py:202-223: model,
+        FCOSHead(0.05, 0.6, 1000, strides), ClipBoxes at batch 1) is launch-bound; this is its latency path.  Results are plan-owned
+        (overwritten by the next call with the same shape)."""
+        self._check_eval()
+        self._check_image(x)
+        key = ("det", float(head.score), float(head.nms_threshold), int(head.max_box), tuple(int(v) for v in head.strides), bool(clip))
+        plan = self.plan_for(x, slot=key)
+        if getattr(plan, "dets", None) is None:
+            engine.add_postprocess(plan, plan.outs, plan.segs, head.strides, head.score, head.nms_threshold, head.max_box, (x.shape[2], x.shape[3]), clip)
+        plan.image_ref[0] = x.contiguous()
+        if self.use_graph and plan.graph is None:
+            plan.capture_graph()
+        plan.run()
+        return plan.dets
 
     def forward_images(self, images, events=None):
         """Input pipeline tail on the device: a list of RESIZED uint8 [h_n, w_n, 3] CUDA images (cv2.resize

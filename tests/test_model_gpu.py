@@ -88,7 +88,7 @@ def test_tiny_fcos_fpn_head_golden(golden):
         np.testing.assert_allclose(reg[i].cpu().numpy(), g[f"reg{i}"], **TOL)
 
 
-@pytest.mark.parametrize("prec", ["f32", "f32-winograd-everywhere", "f16x3"])
+@pytest.mark.parametrize("prec", ["f32", "f32-winograd-everywhere", "f16x3", "mixed"])
 @pytest.mark.parametrize("shape", [(2, 128, 128), (1, 256, 192)])
 def test_full_hisfcos_vs_oracle(shape, prec, monkeypatch):
     if prec == "f32-winograd-everywhere":      # small maps normally go to the direct kernel (ops.wino_preferred): force the Winograd
@@ -159,7 +159,7 @@ def test_plan_cache_follows_weight_updates():
     np.testing.assert_allclose((c - a).cpu().numpy(), 1.0, atol=1e-5)
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "mixed"])
 def test_baseline_config_640_batch2_vs_oracle(prec):
     """BASELINE configs[1] geometry (640x640, 80 classes; batch 2 keeps the CPU oracle to a few seconds):
     every head output within 1e-4 (abs + rel) of the oracle and detections identical to the oracle post-process
@@ -363,3 +363,58 @@ def test_copy_outputs_returns_tensors_that_survive_the_next_forward():
     assert torch.equal(b[0][0], keep)
     head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
     assert head.detect_padded(b)[0].shape[0] == 1        # plain lists of tensors are accepted by FCOSHead
+
+
+def test_plan_as_hip_graph_is_bit_identical_to_eager_launches():
+    """model.use_graph = True (engine.Plan.capture_graph): the ~190 launches of a forward captured once and replayed as one hipGraphLaunch --
+    the latency path of the reference's own shape (batch 1, 512 x 512, test.py:202-223).  Same kernels, same order: outputs bitwise equal to
+    the eager plan for fresh inputs at new addresses, across several replays, with FCOSHead consuming the graph's output buffers."""
+    torch.manual_seed(41)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).eval()
+    randomize_norms(model, 42)
+    model.to(DEV)
+    head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
+    xs = [torch.randn(1, 3, 256, 320, device=DEV) for _ in range(4)]
+    eager = []
+    for x in xs:
+        out = model(x)
+        eager.append(([t.clone() for grp in out for t in grp], [t.clone() for t in head.detect_padded(out)]))
+    model.use_graph = True
+    model.invalidate_plans()
+    for rep in range(2):
+        for x, (eo, ed) in zip(xs, eager):
+            out = model(x.clone())                       # a new address every call: the plan stages it into its static input
+            plan = model.plan_for(x)
+            assert plan.graph is not None
+            for a, b in zip([t for grp in out for t in grp], eo):
+                assert torch.equal(a, b)
+            for a, b in zip(head.detect_padded(out), ed):
+                assert torch.equal(a, b)
+    model.use_graph = False
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_detect_one_plan_equals_model_head_clip(graph):
+    """model.detect(x, head): model + FCOSHead + ClipBoxes as one plan on preallocated buffers (one HIP graph with use_graph) == the three
+    calls the reference's test loop makes (test.py:202-223), bitwise, also for batch 3 and across replays with new inputs."""
+    torch.manual_seed(51)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).eval()
+    randomize_norms(model, 52)
+    model.to(DEV)
+    head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
+    model.use_graph = graph
+    try:
+        for B in (1, 3):
+            for rep in range(3):
+                x = torch.randn(B, 3, 256, 256, device=DEV)
+                model.use_graph = False
+                s0, c0, b0, n0 = head.detect_padded(model(x))
+                b0 = ClipBoxes()(x, b0.contiguous())
+                ref = [t.clone() for t in (s0, c0, b0, n0)]
+                model.use_graph = graph
+                got = model.detect(x, head)
+                for a, b in zip(got, ref):
+                    assert torch.equal(a, b)
+                assert int(got[3].max()) > 0
+    finally:
+        model.use_graph = False
