@@ -18,12 +18,16 @@ gt = torch.cat([c - s / 2, c + s / 2], -1).clamp(0, 511)
 labels = torch.randint(1, 21, (B, 8), device=dev)
 gen = FCOSGenTargets([8, 16, 32, 64, 128], [[-1, 32], [32, 96], [96, 192], [192, 384], [384, 9999999]])
 crit = FCOSLoss("giou")
+AMP = os.environ.get("FD_AMP") == "1"        # FD_AMP=1: the step under torch.autocast(float16) + GradScaler (train.py:175-181)
+scaler = torch.amp.GradScaler("cuda", enabled=AMP)
 def step():
     opt.zero_grad(set_to_none=True)
-    out = model(x)
-    losses = crit([out, gen([out, gt, labels])])
-    losses[-1].backward()
-    opt.step()
+    with torch.autocast("cuda", dtype=torch.float16, enabled=AMP):
+        out = model(x)
+        losses = crit([out, gen([out, gt, labels])])
+    scaler.scale(losses[-1]).backward()
+    scaler.step(opt)
+    scaler.update()
     return losses
 for _ in range(2):
     l = step()
@@ -34,5 +38,5 @@ for _ in range(n):
     l = step()
 torch.cuda.synchronize()
 el = (time.perf_counter() - t) / n
-print(f"train step B={B} 512x512 ({'stock' if os.environ.get('FD_TRAIN_STOCK_CONV') == '1' else 'HIP'} convs): {el * 1e3:.1f} ms "
+print(f"train step B={B} 512x512 {'AMP f16 ' if AMP else ''}({'stock' if os.environ.get('FD_TRAIN_STOCK_CONV') == '1' else 'HIP'} convs): {el * 1e3:.1f} ms "
       f"-> {B / el:.1f} img/s; losses {[round(float(v), 4) for v in l]}")
