@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pytorch_object_detection_amd.dist import gather_detections, pack_detections, shard_batch, unpack_detections
+from pytorch_object_detection_amd.dist import gather_detections, pack_detections, shard_batch, unpack_detections, unpad_gathered
 
 
 def test_shard_batch_partition():
@@ -67,6 +67,30 @@ def test_gather_detections_gloo_world2():
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     mp.spawn(_worker, args=(2, port), nprocs=2, join=True)
+
+
+def _worker_uneven(rank, world, port):
+    """Global batch 5 over 2 ranks: shards of 3 and 2 images -- the short shard is padded to the largest (pad_to), the padding dropped after."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        G, K = 5, 4
+        gen = torch.Generator().manual_seed(7)
+        S, Cc, Bx = torch.rand(G, K, generator=gen), torch.randint(1, 81, (G, K), generator=gen), torch.rand(G, K, 4, generator=gen) * 640
+        N = torch.tensor([4, 0, 2, 1, 3], dtype=torch.int32)
+        lo, hi = shard_batch(G, rank, world)
+        pad = max(h - l for l, h in (shard_batch(G, r, world) for r in range(world)))
+        got = unpad_gathered(gather_detections(S[lo:hi], Cc[lo:hi], Bx[lo:hi], N[lo:hi], pad_to=pad), G, world)
+        assert torch.equal(got[0], S) and torch.equal(got[1], Cc) and torch.equal(got[2], Bx) and torch.equal(got[3], N)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_detections_uneven_shards_gloo_world2():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker_uneven, args=(2, port), nprocs=2, join=True)
 
 
 # ---------------------------------------------------------------------------------------------- bench.py's own launcher
