@@ -299,13 +299,30 @@ def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.T
     Cin, Cout = x.shape[1], w_packed.shape[0]
     out_rows = y.shape[0]
     prec = getattr(w_packed, "_fd_prec", 0)
-    if prec:             # f16 operands (AMP): the library's own tile choice (the tuned table holds fp32 timings), no split-K
-        ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift,
-                      res=_r(res) if res is not None else None, act=act, res_mask=res_mask, precision=prec)()
-        return
     KT = (Cin // 32) * k * k
     hw = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
     key = f"B{segs.batch}|{hw}|{Cin}>{Cout}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{Cin}|ycs{Cout}"   # (mask / add: same cost)
+    if prec:
+        # f16 operands (AMP): own table entries ("f16|" keys, timed by `FD_AUTOTUNE=1 FD_AMP=1 python tools/tune_train.py`); a miss takes the
+        # library's tile choice (the fp32 heuristic would name single-buffer tiles the f16 kernel is not built for), or is timed with FD_AUTOTUNE=1
+        key = "f16|" + key
+        code = _TILE_CACHE.get(key)
+        if code is None:
+            code = ops._tune_table().get(key)
+            if code is None and ops._TUNE_MODE != "0":
+                nb = _lib.lib().fd_conv_workspace_bytes(out_rows, Cout, ops.KSPLIT_MAX)
+                ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device) if 0 < nb <= 256 * 1024 * 1024 else None
+                probe = ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift,
+                                      res=_r(res) if res is not None else None, act=act, workspace=ws, res_mask=res_mask, precision=prec)
+                code = ops.autotune_conv(probe, key, out_rows, Cout, KT)
+            code = _TILE_CACHE[key] = int(code or 0)
+        ws = None
+        if (code >> 8) > 1:
+            ws = torch.empty(_lib.lib().fd_conv_workspace_bytes(out_rows, Cout, code >> 8) // 4, dtype=torch.float32, device=x.device)
+        ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift,
+                      res=_r(res) if res is not None else None, act=act, res_mask=res_mask, precision=prec, tile=code & 0xFF,
+                      ksplit=max(1, code >> 8), workspace=ws)()
+        return
     code = _TILE_CACHE.get(key)
     ws = None
     if code is None or (code >> 8) > 1:

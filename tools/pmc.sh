@@ -6,7 +6,7 @@ tag=${1:-r01}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc_$tag
 mkdir -p $out
-run() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $out/$1 -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-step > $out/$1.log 2>&1 || (tail -5 $out/$1.log; exit 1); }
+run() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $out/$1 -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-fast-mode > $out/$1.log 2>&1 || (tail -5 $out/$1.log; exit 1); }
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
 run sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32"

@@ -1,5 +1,6 @@
 """Time the conv tiles of the training step's shapes (forward + data-gradient launches, B=16 512x512, HISFCOS and FCOS)
-and merge them into tuned/gfx950_tiles.json.  usage (GPU box): FD_AUTOTUNE=1 python tools/tune_train.py"""
+and merge them into tuned/gfx950_tiles.json.  usage (GPU box): FD_AUTOTUNE=1 python tools/tune_train.py
+FD_AMP=1: the same step under torch.autocast(float16) -- times the f16-operand launches ("f16|" keys)."""
 import os, sys
 os.environ.setdefault("FD_AUTOTUNE", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,8 +21,10 @@ for mk in (lambda: HalfInvertedStageFCOS([512, 1024, 2048], 20, 256), lambda: FC
     gt = torch.cat([c - s / 2, c + s / 2], -1).clamp(0, 511)
     labels = torch.randint(1, 21, (B, 8), device=dev)
     gen = FCOSGenTargets([8, 16, 32, 64, 128], [[-1, 32], [32, 96], [96, 192], [192, 384], [384, 9999999]])
-    out = model(x)
-    FCOSLoss("giou")([out, gen([out, gt, labels])])[-1].backward()
+    with torch.autocast("cuda", dtype=torch.float16, enabled=os.environ.get("FD_AMP") == "1"):
+        out = model(x)
+        loss = FCOSLoss("giou")([out, gen([out, gt, labels])])[-1]
+    loss.backward()
     torch.cuda.synchronize()
     del model, out
 print("table entries:", before, "->", len(ops._tune_table()))
