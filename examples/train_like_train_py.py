@@ -7,7 +7,8 @@
 Same objects and call order as the reference: HalfInvertedStageFCOS([512, 1024, 2048], 20, 256), FCOSGenTargets,
 FCOSLoss('giou'), SGD, DistributedDataParallel(find_unused_parameters=True), autocast + GradScaler, linear warm-up.
 In model.train() the forward is an autograd graph of HIP kernels (train_ops.py); target assignment and the losses are HIP
-kernels; the HIP nodes keep computing in fp32 under autocast.
+kernels; under autocast the dense convolutions run on the f16 MFMA with fp32 accumulation (forward, data and weight gradients:
+the reference's AMP arithmetic), normalisation and losses in fp32; under DDP the FPN's BatchNorms are SyncBatchNorm on the HIP statistics path.
 """
 import argparse
 import os
@@ -42,6 +43,7 @@ def main():
                                 limit_range=[[-1, 64], [64, 128], [128, 256], [256, 512], [512, 999999]])   # train.py:98
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)       # train.py:101
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)                                 # train.py:103
     LR_INIT, WARMUP_STEPS = 1e-3, 501
     optimizer = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=LR_INIT, momentum=0.9, weight_decay=1e-4)
     scaler = torch.amp.GradScaler("cuda", enabled=args.amp)                                         # train.py:133
