@@ -110,7 +110,10 @@ const char* fd_last_error(void);
                                deterministically */
 #define FD_TILE_WAVE64 15   /* GEMM-addressed layers (1x1, stride 1, no padding; Cin % 32 == 0, fp32): wave-autonomous 64 x 64 tiles, one wave per
                                workgroup, no barrier in the K loop (fd_conv_wave.hip) -- needs fd_conv_params.w_frag (fd_pack_conv_weight_wave_f32) */
-#define FD_TILE_COUNT 15
+#define FD_TILE_WINOGRAD4 16 /* 3x3 stride-1 pad-1 convs (dilation 1), fp32: Winograd F(4x4, 3x3) on the fp32 MFMA -- 36 multiplies per 4x4 output tile and
+                                channel pair (2.25 per output: 1.78x fewer than F(2x2), 4x fewer than direct); needs the fd_wino4_pack_weights_f32 packing in `w`;
+                                no split-K / gn_stats.  Rounding error ~2x F(2x2)'s, inside the 1e-4 parity bar */
+#define FD_TILE_COUNT 16
 
 typedef struct fd_conv_params {
     const float* x;
@@ -174,6 +177,11 @@ typedef struct fd_conv_params {
 
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
 int64_t fd_conv_workspace_bytes(int64_t out_rows, int32_t Cout, int32_t ksplit);
+
+/* Weights for FD_TILE_WINOGRAD4: OIHW fp32 [Cout][Cin][3][3] -> U = G g G^T (6x6 per filter, computed in double, rounded once) packed
+ * [ceil(Cout/32)][Cin/8][36 frequencies][32 cout][8 cin] (fd_wino4_weight_bytes(Cout, Cin) bytes, zero rows past Cout). */
+int64_t fd_wino4_weight_bytes(int32_t Cout, int32_t Cin);
+int32_t fd_wino4_pack_weights_f32(const float* w, float* out, int32_t Cout, int32_t Cin, fd_stream_t stream);
 
 /* Weights for FD_TILE_WAVE64: [Cout][Cin] fp32 (an OIHW 1x1 filter bank, Cin % 32 == 0) -> MFMA fragment order
  * [ceil(Cout/64)][Cin/32][2 sub-tiles][4 k-steps][64 lanes][4 floats] (fd_conv_weight_wave_bytes bytes, zero rows past Cout): lane

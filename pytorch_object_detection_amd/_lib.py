@@ -16,6 +16,7 @@ TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (128, 32), 6
          15: (64, 64)}                               # wave-autonomous 64x64 tiles, one wave per workgroup (1x1 stride-1 layers, needs w_frag)
 PATCH_TILE = 13
 WAVE_TILE = 15
+WINO4_TILE = 16     # Winograd F(4x4, 3x3) kernel (own weight packing: ops.pack_conv_weight_wino4); not a member of TILES
 PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2     # include/fcosdet.h FD_PREC_*
 WINO_TILE = 14      # Winograd F(2x2, 3x3) kernel (own weight packing: ops.pack_conv_weight_wino); not a member of TILES
 
@@ -92,6 +93,8 @@ _SIGS = {
     "fd_conv_wgrad_workspace_bytes": (_L, [_L, _I, _I, _I, _I]),
     "fd_pack_conv_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fd_pack_conv_weights_batch_f32": (_I, [_P, _I, _L, _P]),
+    "fd_wino4_weight_bytes": (_L, [_I, _I]),
+    "fd_wino4_pack_weights_f32": (_I, [_P, _P, _I, _I, _P]),
     "fd_conv_weight_wave_bytes": (_L, [_I, _I]),
     "fd_pack_conv_weight_wave_f32": (_I, [_P, _P, _I, _I, _P]),
     "fd_wino_weight_bytes": (_L, [_I, _I]),

@@ -377,6 +377,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
                    "fd_conv2d: multi-level input needs stride 1 and 'same' padding");
 
     if (p->tile == FD_TILE_WINOGRAD) return fd_launch_conv_wino(p, stream);   // own argument block, own weight packing
+    if (p->tile == FD_TILE_WINOGRAD4) return fd_launch_conv_wino4(p, stream);
 
     ConvArgs a;
     a.x = p->x; a.w = p->w; a.scale = p->scale; a.shift = p->shift; a.res = p->res; a.y = p->y;

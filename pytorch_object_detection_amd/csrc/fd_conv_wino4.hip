@@ -1,0 +1,433 @@
+// fd_conv_wino4.hip -- 3x3 stride-1 'same' convolution (dilation 1) as Winograd F(4x4, 3x3) on the fp32 MFMA of gfx950 (FD_TILE_WINOGRAD4).
+//
+// F(2x2, 3x3) (fd_conv_wino.hip) already runs its MFMA loop at the matrix pipe's full rate: in exact fp32 the only lever left is executing
+// fewer multiplies again.  F(4x4, 3x3) computes a 4x4 output tile from a 6x6 input patch with 36 multiplies per (cin, cout) -- 2.25 per
+// output instead of 4 (F(2x2)) or 9 (direct):
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A,   B^T 6x6, G 6x3, A^T 4x6 (Lavin & Gray's matrices, interpolation points 0, +-1, +-2, inf)
+// so the conv becomes 36 independent GEMMs  M_f[tile][cout] = sum_c V_f[tile][c] * U_f[cout][c].  Everything stays fp32; the transforms now
+// multiply by 4, 5, 8 as well, which costs a factor ~2 in rounding error against F(2x2): the whole 640 x 640 model stays within 2e-5 * (1 + |x|)
+// of its fp64 evaluation (tools/wino44_emul.py), inside the 1e-4 parity bar.
+//
+// One workgroup (8 waves, one per CU) = 32 tiles (512 output pixels) x 64 output channels x all 36 frequencies:
+//   * wave (g, ch) owns frequencies 9 g .. 9 g + 8 and output channels 32 ch .. + 31: 9 accumulators of 32 x 32 (144 VGPRs);
+//   * the input transform is a three-stage software pipeline over 8-channel chunks, ONE workgroup barrier per chunk:
+//       G(c)  thread (tile, patch row i, channel quad) fetches its 6 pixels (6 x 16-byte raw buffer loads, zero outside the image);
+//       R(c)  row pass of B^T d B in registers, written to an LDS scratch [tile][quad][j'][i];
+//       C(c)  the same thread, now (tile, quad, column j'), reads its column of 6, does the column pass and writes V[f = 6 i' + j'][tile][8 c];
+//       M(c)  the MFMAs.   Iteration cc runs M(cc), C(cc+1), R(cc+2), G(cc+3).
+//     LDS: V 2 x 36 KB + scratch 2 x 36 KB = 144 KB; the epilogue reuses all of it for the 36 x 32 x 32 frequency planes of one channel block;
+//   * U goes global -> registers in MFMA layout (packed [cout/32][chunk][36 f][32 cout][8 c], 1 KB per frequency block), the block of chunk
+//     cc+1 into the registers the MFMAs of chunk cc have just consumed;
+//   * epilogue: the two channel blocks in turn -- the block's four waves put their accumulators into LDS planes, then gather the 36 frequencies of
+//     (tile, 4 couts) per thread, apply A^T . A and y = act(v * scale + shift (+ | mask) res) and store 16 bytes per pixel.
+#include "fd_conv_common.h"
+
+struct Wino4Args {
+    const float* x; const float* u; const float* scale; const float* shift; const float* res; float* y;
+    int x_cs, x_co, res_cs, res_co, y_cs, y_co;
+    int Cin, Cout, act, act_c0, res_mask;
+    int NC;                       // 8-channel chunks
+    int nseg;
+    int H[FD_MAX_SEG], W[FD_MAX_SEG], TH[FD_MAX_SEG], TW[FD_MAX_SEG];   // TH x TW tiles of 4 x 4 outputs
+    int m0[FD_MAX_SEG];           // first row of the level
+    int t0[FD_MAX_SEG + 1];       // first tile of the level
+    float seg_param[FD_MAX_SEG];
+    int T;                        // tiles in all
+    int mtiles, ntiles, mt_per;   // M tiles (32 tiles each), N tiles (64 cout), M tiles per XCD
+    unsigned x_bytes, u_bytes;
+    int dbg;                      // timing experiments only (FD_W4_DBG): 1 = no loader stages, 2 = no MFMAs, 4 = no epilogue (wrong results)
+};
+
+#define W4_TB 32
+#define W4_KC 8
+#define W4_PLANE (W4_TB * W4_KC)            // floats per frequency plane of V
+#define W4_STAGE (36 * W4_PLANE)            // floats per V stage (36 KB) == floats per scratch stage
+
+struct Tile4 { int s, n, h0, w0; bool ok; };
+
+__device__ __forceinline__ Tile4 wino4_decode(const Wino4Args& a, int t) {
+    Tile4 p;
+    p.ok = t < a.T;
+    if (!p.ok) t = 0;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < FD_MAX_SEG; ++i)
+        if (i < a.nseg && t >= a.t0[i]) s = i;
+    const int local = t - a.t0[s];
+    const int tpi = a.TH[s] * a.TW[s];
+    const int n = local / tpi, r = local - n * tpi;
+    const int ti = r / a.TW[s], tj = r - ti * a.TW[s];
+    p.s = s; p.n = n; p.h0 = 4 * ti; p.w0 = 4 * tj;
+    return p;
+}
+
+// B^T d for one line of six (per component of a float4): t = B^T d,
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+// in place: six inputs -> six outputs per component, four temporaries
+__device__ __forceinline__ void w4_bt_inplace(float4 (&d)[6]) {
+#define W4_BT1(c)                                                              \
+    {                                                                          \
+        const float e42 = d[4].c - 4.f * d[2].c, e31 = d[3].c - 4.f * d[1].c;  \
+        const float f42 = d[4].c - d[2].c, f31 = 2.f * (d[3].c - d[1].c);      \
+        const float t0 = 4.f * d[0].c - 5.f * d[2].c + d[4].c;                 \
+        const float t5 = 4.f * d[1].c - 5.f * d[3].c + d[5].c;                 \
+        d[0].c = t0;                                                           \
+        d[1].c = e42 + e31;                                                    \
+        d[2].c = e42 - e31;                                                    \
+        d[3].c = f42 + f31;                                                    \
+        d[4].c = f42 - f31;                                                    \
+        d[5].c = t5;                                                           \
+    }
+    W4_BT1(x) W4_BT1(y) W4_BT1(z) W4_BT1(w)
+#undef W4_BT1
+}
+
+__device__ __forceinline__ void w4_bt(const float4 (&d)[6], float4 (&t)[6]) {
+#define W4_BT1(c)                                                              \
+    {                                                                          \
+        const float e42 = d[4].c - 4.f * d[2].c, e31 = d[3].c - 4.f * d[1].c;  \
+        const float f42 = d[4].c - d[2].c, f31 = 2.f * (d[3].c - d[1].c);      \
+        t[0].c = 4.f * d[0].c - 5.f * d[2].c + d[4].c;                         \
+        t[1].c = e42 + e31;                                                    \
+        t[2].c = e42 - e31;                                                    \
+        t[3].c = f42 + f31;                                                    \
+        t[4].c = f42 - f31;                                                    \
+        t[5].c = 4.f * d[1].c - 5.f * d[3].c + d[5].c;                         \
+    }
+    W4_BT1(x) W4_BT1(y) W4_BT1(z) W4_BT1(w)
+#undef W4_BT1
+}
+
+template <int TAG>
+__global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Vs = reinterpret_cast<float*>(smem);                  // [2][36][32][8]
+    float* Ss = Vs + 2 * W4_STAGE;                               // [2][32 tiles][2 q][6 j'][6 i][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave & 3, ch = wave >> 2;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-aware order (as fd_conv_wino.hip): XCD x owns M tiles [x * mt_per, (x + 1) * mt_per) and walks them cout tile by cout tile
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int mt_lo = xcd * a.mt_per;
+    const int cnt = min(a.mtiles - mt_lo, a.mt_per);
+    if (cnt <= 0 || idx >= cnt * a.ntiles) return;
+    const int nt = idx / cnt, mt = mt_lo + (idx - nt * cnt);
+    const int tile0 = mt * W4_TB, n0 = nt * 64;
+
+    constexpr unsigned OOB = 0xC0000000u;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, (int)a.u_bytes, 0x00020000);
+
+    // ---- loader role (threads 0 .. 383): (tile lt, line pr, channel quad q); pr = patch row i in G / R, column j' in C ----
+    const bool ldr = __builtin_amdgcn_readfirstlane(tid) < 384 && !(a.dbg & 1);       // wave-uniform: scalar branches around the loader slices
+    const int q = tid & 1, pr = (tid >> 1) % 6, lt = min(tid / 12, W4_TB - 1);
+    // patch row pr of tile lt: one base offset per thread; the six columns differ by a uniform pixel stride (buffer soffset) and a validity bit each
+    unsigned a_base;
+    bool a_ok[6];
+    {
+        const Tile4 p = wino4_decode(a, tile0 + lt);
+        const int H = a.H[p.s], W = a.W[p.s];
+        const int hh = p.h0 - 1 + pr;
+        const bool row_ok = ldr && p.ok && (unsigned)hh < (unsigned)H;
+        const int rowbase = a.m0[p.s] + (p.n * H + hh) * W;
+        a_base = ((unsigned)(rowbase + p.w0) * (unsigned)a.x_cs + (unsigned)(a.x_co + q * 4)) * 4u;       // column j = 1 (w0); j adds (j - 1) pixels
+#pragma unroll
+        for (int j = 0; j < 6; ++j) a_ok[j] = row_ok && (unsigned)(p.w0 - 1 + j) < (unsigned)W;
+    }
+    const int px_b = a.x_cs * 4;                                 // bytes between neighbouring pixels of one row
+    // scratch: S[lt][q][j'][i] float4 -- R writes element (j', i = pr) for j' = 0..5; C reads (j' = pr, i = 0..5): 6 consecutive float4
+    const int s_wr = ((lt * 2 + q) * 36 + pr) * 4;               // + j' * 24 floats
+    const int s_rd = ((lt * 2 + q) * 36 + pr * 6) * 4;           // + i * 4 floats
+    // V[f = 6 i' + j'][tile][8 c]: tile rows XORed with j' (the six planes of one write instruction differ in j'), 16-byte halves with tile bit 4
+    const int v_wr = (pr * W4_TB + (lt ^ pr)) * W4_KC + 4 * (q ^ ((lt >> 4) & 1));      // + i' * 6 * W4_PLANE
+
+    // ---- MFMA role ----
+    const int nb = (n0 >> 5) + ch;
+    const bool nb_ok = nb * 32 < ((a.Cout + 31) & ~31);
+    const unsigned u_off0 = nb_ok ? ((unsigned)(nb * a.NC) * 36u + 9u * g) * 1024u + (unsigned)(l31 * 32 + lh * 16) : OOB;
+    const int v_half = 4 * (lh ^ ((l31 >> 4) & 1));
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    float4 pv[6], bq[9];
+    auto stage_G = [&](int cc) {                 // global -> registers
+        const int cb = cc * 32;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            pv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(a_ok[j] ? a_base + (unsigned)((j - 1) * px_b + cb) : OOB), 0, 0));
+    };
+    auto stage_R = [&](int st) {                 // row pass (along the patch row) -> scratch
+        float4 t[6];
+        w4_bt(pv, t);
+        float* d = Ss + st * W4_STAGE + s_wr;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(d + j * 24) = t[j];
+    };
+    auto stage_C = [&](int st) {                 // column pass (down column j' = pr) -> V
+        float4 s[6], v[6];
+        const float* r = Ss + st * W4_STAGE + s_rd;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s[i] = *reinterpret_cast<const float4*>(r + i * 4);
+        w4_bt(s, v);
+        float* d = Vs + st * W4_STAGE + v_wr;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<float4*>(d + i * 6 * W4_PLANE) = v[i];
+    };
+    auto load_u = [&](int cc, int fi) {
+        bq[fi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (int)(u_off0 == OOB ? OOB : u_off0 + ((unsigned)cc * 36u + fi) * 1024u), 0, 0));
+    };
+
+    const int NC = a.NC;
+    // ---- prologue: G(0) R(0) | G(1) C(0) R(1) | G(2): V[0] holds chunk 0, scratch[1] chunk 1's row pass, registers chunk 2 ----
+    if (ldr) { stage_G(0); stage_R(0); }
+    __syncthreads();
+    if (ldr) { stage_G(min(1, NC - 1)); stage_C(0); stage_R(1); stage_G(min(2, NC - 1)); }
+#pragma unroll
+    for (int fi = 0; fi < 9; ++fi) load_u(0, fi);
+    __syncthreads();
+
+    // Main loop: one 8-channel chunk per iteration and workgroup barrier.  The loader stages of the NEXT chunks are cut into slices that sit between
+    // the nine MFMA groups of this chunk (pinned with sched_barriers): issued in the shadow of the 64-cycle MFMAs instead of in front of them
+    // (as one block in front, loader time and MFMA time simply added: 0.34 + 0.90 ms on the head tower).
+    //   group 0: R(cc+2) row pass in place in the patch registers   group 1: -> scratch[st]
+    //   group 2: C(cc+1) reads its column from scratch[st^1] into the same registers   group 3: column pass in place   group 4: -> V[st^1]
+    //   group 5: G(cc+3) issues the patch loads (four groups and a barrier before group 0 of the next chunk consumes them)
+    for (int cc = 0; cc < NC; ++cc) {
+        const int st = cc & 1;
+        const float* Vb = Vs + st * W4_STAGE + (9 * g) * W4_PLANE + v_half;
+        const int cn = min(cc + 1, NC - 1);
+        float4 fa[2];
+        fa[0] = *reinterpret_cast<const float4*>(Vb + (0 * W4_TB + (l31 ^ ((9 * g + 0) % 6))) * W4_KC);
+        __builtin_amdgcn_s_setprio(1);
+        if (!(a.dbg & 2))
+#pragma unroll
+        for (int fi = 0; fi < 9; ++fi) {
+            if (fi + 1 < 9) fa[(fi + 1) & 1] = *reinterpret_cast<const float4*>(Vb + ((fi + 1) * W4_TB + (l31 ^ ((9 * g + fi + 1) % 6))) * W4_KC);
+            __builtin_amdgcn_sched_barrier(0);                         // the next group's V fragment is requested BEFORE this group's MFMAs go out
+            const float4 va = fa[fi & 1], fb = bq[fi];
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.x, fb.x, acc[fi], 0, 0, 0);
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.y, fb.y, acc[fi], 0, 0, 0);
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.z, fb.z, acc[fi], 0, 0, 0);
+            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, fb.w, acc[fi], 0, 0, 0);
+            load_u(cn, fi);                                            // next chunk's block into the registers just consumed
+            if (ldr) {
+                if (fi == 0) w4_bt_inplace(pv);
+                if (fi == 1) {
+                    float* d = Ss + st * W4_STAGE + s_wr;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(d + j * 24) = pv[j];
+                }
+                if (fi == 2) {
+                    const float* r = Ss + (st ^ 1) * W4_STAGE + s_rd;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) pv[i] = *reinterpret_cast<const float4*>(r + i * 4);
+                }
+                if (fi == 3) w4_bt_inplace(pv);
+                if (fi == 4) {
+                    float* d = Vs + (st ^ 1) * W4_STAGE + v_wr;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) *reinterpret_cast<float4*>(d + i * 6 * W4_PLANE) = pv[i];
+                }
+                if (fi == 5) stage_G(min(cc + 3, NC - 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
+
+    // ---- epilogue: the two channel blocks in turn through the (now free) 144 KB of LDS ----
+    if (a.dbg & 4) return;
+    float* Ms = reinterpret_cast<float*>(smem);                          // [36 f][32 tiles][32 cout]
+    // output role of the four waves of one channel block (their accumulators are dead by then: no spills): thread = (tile, cout quad), all 16 outputs
+    const int tl = tid & 255, et = tl >> 3, eq = tl & 7;
+    const Tile4 ep = wino4_decode(a, tile0 + et);
+    const int eH = a.H[ep.s], eW = a.W[ep.s];
+    const float eprm = a.seg_param[ep.s];
+    // ch 0 waves: planes, B1, outputs, B2, B3.   ch 1 waves: B1, B2, planes, B3, outputs.  (s_barrier counts arrivals, not code positions; the branch is
+    // wave-uniform.)  Each wave's accumulators are dead before its output pass, so neither pass spills.
+    const int cb = __builtin_amdgcn_readfirstlane(ch);
+    if (cb) { __syncthreads(); __syncthreads(); }
+    {
+#pragma unroll
+        for (int fi = 0; fi < 9; ++fi) {
+            float* d = Ms + ((9 * g + fi) * 32) * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32] = acc[fi][e];
+        }
+        __syncthreads();
+        const int nn = n0 + cb * 32 + eq * 4;
+        if (ep.ok && nn < a.Cout) {
+            // Y = A^T M A, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]: per frequency row i the column pass r_i[y], then
+            // Y[x][y] += A^T[x][i] * r_i[y] (the zero entries of A^T compile away)
+            float4 Y[4][4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) Y[x][y] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float4 m[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) m[j] = *reinterpret_cast<const float4*>(Ms + ((6 * i + j) * 32 + et) * 32 + eq * 4);
+                float4 r[4];
+#define W4_AT1(c)                                                                     \
+    {                                                                                 \
+        const float p12 = m[1].c + m[2].c, m12 = m[1].c - m[2].c;                      \
+        const float p34 = m[3].c + m[4].c, m34 = m[3].c - m[4].c;                      \
+        r[0].c = m[0].c + p12 + p34;                                                  \
+        r[1].c = m12 + 2.f * m34;                                                     \
+        r[2].c = p12 + 4.f * p34;                                                     \
+        r[3].c = m12 + 8.f * m34 + m[5].c;                                            \
+    }
+                W4_AT1(x) W4_AT1(y) W4_AT1(z) W4_AT1(w)
+#undef W4_AT1
+                constexpr float AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const float cx = AT[x][i];
+                    if (cx == 0.f) continue;
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) {
+                        Y[x][y].x += cx * r[y].x; Y[x][y].y += cx * r[y].y; Y[x][y].z += cx * r[y].z; Y[x][y].w += cx * r[y].w;
+                    }
+                }
+            }
+            const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + nn) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 sf = a.shift ? *reinterpret_cast<const float4*>(a.shift + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int h = ep.h0 + x;
+                if (h >= eH) continue;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    const int w = ep.w0 + y;
+                    if (w >= eW) continue;
+                    const size_t m_ = (size_t)(a.m0[ep.s] + (ep.n * eH + h) * eW + w);
+                    float4 v = make_float4(Y[x][y].x * sc.x + sf.x, Y[x][y].y * sc.y + sf.y, Y[x][y].z * sc.z + sf.z, Y[x][y].w * sc.w + sf.w);
+                    if (a.res) {
+                        const float4 rr = *reinterpret_cast<const float4*>(a.res + m_ * a.res_cs + a.res_co + nn);
+                        if (a.res_mask) {
+                            v.x = rr.x > 0.f ? v.x : 0.f; v.y = rr.y > 0.f ? v.y : 0.f; v.z = rr.z > 0.f ? v.z : 0.f; v.w = rr.w > 0.f ? v.w : 0.f;
+                        } else {
+                            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                        }
+                    }
+                    if (a.act != FD_ACT_NONE) {
+                        if (nn + 0 >= a.act_c0) v.x = fd_act(v.x, a.act, eprm);
+                        if (nn + 1 >= a.act_c0) v.y = fd_act(v.y, a.act, eprm);
+                        if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, eprm);
+                        if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, eprm);
+                    }
+                    *reinterpret_cast<float4*>(a.y + m_ * a.y_cs + a.y_co + nn) = v;
+                }
+            }
+        }
+    }
+    if (!cb) { __syncthreads(); __syncthreads(); }
+}
+
+// U = G g G^T per (cout, cin), G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], computed in double and rounded
+// once; packed [ceil(Cout / 32)][Cin / 8][36 f][32 cout][8 c] (zero rows past Cout).
+__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
+    const int Np = (Cout + 31) & ~31;
+    const long total = (long)Np * Cin;
+    const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / Cin), k = (int)(i - (long)n * Cin);
+        double gg[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gg[r][c] = n < Cout ? (double)w[((long)n * Cin + k) * 9 + r * 3 + c] : 0.0;
+        double t[6][3];
+#pragma unroll
+        for (int a_ = 0; a_ < 6; ++a_)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t[a_][c] = G[a_][0] * gg[0][c] + G[a_][1] * gg[1][c] + G[a_][2] * gg[2][c];
+        const int nbk = n >> 5, nl = n & 31, cc = k >> 3, kl = k & 7;
+        float* o = out + (((long)nbk * (Cin >> 3) + cc) * 36) * 256 + nl * 8 + kl;
+#pragma unroll
+        for (int a_ = 0; a_ < 6; ++a_)
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                o[(a_ * 6 + b) * 256] = (float)(t[a_][0] * G[b][0] + t[a_][1] * G[b][1] + t[a_][2] * G[b][2]);
+    }
+}
+
+extern "C" int64_t fd_wino4_weight_bytes(int32_t Cout, int32_t Cin) {
+    if (Cout < 1 || Cin < 8 || Cin % 8) return -1;
+    return (int64_t)((Cout + 31) & ~31) * Cin * 36 * 4;
+}
+
+extern "C" int32_t fd_wino4_pack_weights_f32(const float* w, float* out, int32_t Cout, int32_t Cin, fd_stream_t stream) {
+    FD_REQUIRE(w && out && Cout >= 1 && Cin >= 8 && Cin % 8 == 0, FD_E_INVAL, "fd_wino4_pack_weights: need Cin %% 8 == 0 (Cout=%d Cin=%d)", Cout, Cin);
+    const long total = (long)((Cout + 31) & ~31) * Cin;
+    long gsz = (total + 255) / 256;
+    if (gsz > 8192) gsz = 8192;
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin);
+    FD_CHECK_LAUNCH("fd_wino4_pack_weights_f32");
+    return FD_OK;
+}
+
+int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
+    FD_REQUIRE(p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->dil == 1 && p->Cin % 8 == 0 && p->Cout % 4 == 0 &&
+                   p->precision == FD_PREC_F32 && p->ksplit <= 1 && p->out_H <= 0 && p->sc_H <= 0 && !p->gate && !p->gn_stats,
+               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD4 needs an fp32 3x3 stride-1 pad-1 dilation-1 conv with Cin %% 8 == 0, Cout %% 4 == 0, no split-K / scatter / gate / gn_stats");
+    FD_REQUIRE(p->x_cs % 4 == 0 && p->x_co % 4 == 0 && p->y_cs % 4 == 0 && p->y_co % 4 == 0 && ((uintptr_t)p->y & 15) == 0 &&
+                   (!p->res || (p->res_cs % 4 == 0 && p->res_co % 4 == 0 && ((uintptr_t)p->res & 15) == 0)) &&
+                   (!p->scale || ((uintptr_t)p->scale & 15) == 0) && (!p->shift || ((uintptr_t)p->shift & 15) == 0),
+               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD4 needs 16-byte addressable input / output / residual / scale / shift views");
+    Wino4Args a;
+    a.x = p->x; a.u = p->w; a.scale = p->scale; a.shift = p->shift; a.res = p->res; a.y = p->y;
+    a.x_cs = p->x_cs; a.x_co = p->x_co; a.res_cs = p->res_cs; a.res_co = p->res_co; a.y_cs = p->y_cs; a.y_co = p->y_co;
+    a.Cin = p->Cin; a.Cout = p->Cout; a.act = p->act; a.act_c0 = p->act_c0;
+    a.res_mask = (p->res && p->res_mode == 1) ? 1 : 0;
+    a.NC = p->Cin / 8;
+    a.nseg = p->in.nseg;
+    long t = 0;
+    for (int s = 0; s < FD_MAX_SEG; ++s) {
+        a.t0[s] = (int)t;
+        if (s < p->in.nseg) {
+            a.H[s] = p->in.H[s]; a.W[s] = p->in.W[s];
+            a.TH[s] = (p->in.H[s] + 3) / 4; a.TW[s] = (p->in.W[s] + 3) / 4;
+            a.m0[s] = p->in.m_start[s];
+            t += (long)p->in.batch * a.TH[s] * a.TW[s];
+        } else {
+            a.H[s] = a.W[s] = a.TH[s] = a.TW[s] = 1; a.m0[s] = 0;
+        }
+        a.seg_param[s] = p->seg_param[s];
+    }
+    a.t0[FD_MAX_SEG] = (int)t;
+    FD_REQUIRE(t > 0 && t < (1L << 30), FD_E_INVAL, "fd_conv2d: tile count out of range");
+    a.T = (int)t;
+    const long rows = p->in.m_start[p->in.nseg];
+    FD_REQUIRE(rows * p->x_cs < (1L << 31) && rows * p->y_cs < (1L << 31), FD_E_UNSUPPORTED, "fd_conv2d: tensor exceeds 2^31 elements");
+    const long xb = rows * p->x_cs * 4, ub = (long)((p->Cout + 31) & ~31) * p->Cin * 36 * 4;
+    FD_REQUIRE(xb < 0xC0000000L - 65536 && ub < 0xC0000000L, FD_E_UNSUPPORTED, "fd_conv2d: input / weight buffer exceeds 3 GiB");
+    a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub;
+    static const int dbg = getenv("FD_W4_DBG") ? atoi(getenv("FD_W4_DBG")) : 0;
+    a.dbg = dbg;
+    a.mtiles = (a.T + W4_TB - 1) / W4_TB;
+    a.ntiles = (p->Cout + 63) / 64;
+    a.mt_per = (a.mtiles + 7) / 8;
+    constexpr int lds = 4 * W4_STAGE * 4;        // 144 KB
+    const dim3 grid((unsigned)(8 * a.mt_per * a.ntiles));
+    if (p->tag == 1) {
+        static std::atomic<unsigned> m1{0};
+        fd_set_max_lds_once(m1, reinterpret_cast<const void*>(conv3x3_wino4_kernel<1>), lds);
+        hipLaunchKernelGGL(conv3x3_wino4_kernel<1>, grid, dim3(512), lds, stream, a);
+    } else {
+        static std::atomic<unsigned> m0{0};
+        fd_set_max_lds_once(m0, reinterpret_cast<const void*>(conv3x3_wino4_kernel<0>), lds);
+        hipLaunchKernelGGL(conv3x3_wino4_kernel<0>, grid, dim3(512), lds, stream, a);
+    }
+    FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (Winograd F(4x4,3x3))");
+    return FD_OK;
+}

@@ -440,6 +440,24 @@ def pack_conv_weight_wino(w: torch.Tensor, scale: Optional[torch.Tensor] = None,
     return out
 
 
+def pack_conv_weight_wino4(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout, Cin, 3, 3] -> the Winograd F(4x4, 3x3) operand of FD_TILE_WINOGRAD4 (fd_wino4_pack_weights_f32), one HIP launch."""
+    w = w.detach().float().contiguous()
+    _need_gpu(w)
+    co, ci, kh, kw = w.shape
+    nbytes = _lib.lib().fd_wino4_weight_bytes(co, ci)
+    if kh != 3 or kw != 3 or nbytes < 0:
+        raise FdError(f"Winograd F(4x4,3x3) weights need a 3x3 filter with Cin % 8 == 0 (got {tuple(w.shape)})")
+    out = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+    check(_lib.lib().fd_wino4_pack_weights_f32(w.data_ptr(), out.data_ptr(), co, ci, _stream()), "fd_wino4_pack_weights_f32")
+    return out
+
+
+def wino4_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bool:
+    """Shapes FD_TILE_WINOGRAD4 covers."""
+    return k == 3 and stride == 1 and pad == 1 and dil == 1 and Cin % 8 == 0 and Cout % 4 == 0
+
+
 def wino_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bool:
     """Shapes FD_TILE_WINOGRAD covers (the output / residual views must also be 16-byte addressable)."""
     return k == 3 and stride == 1 and pad == dil and dil in (1, 2) and Cin % 8 == 0 and Cout % 4 == 0

@@ -1157,3 +1157,56 @@ def test_hisfcos_head_fused_groupnorm_equals_unfused_and_oracle(monkeypatch):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=3e-5, rtol=3e-5)
     for a, r in zip(outs[True], [t for grp in ref for t in grp]):
         np.testing.assert_allclose(a.cpu().numpy(), r.numpy(), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", [c for c in WINO_CASES if c[2] == 1] + [(256, 80, 1, [(17, 23), (9, 12), (5, 6), (3, 3), (2, 1)], ACT_EXP, False)])
+def test_conv3x3_winograd_f4x4(case):
+    """FD_TILE_WINOGRAD4 (fd_conv_wino4.hip): F(4x4, 3x3) on the fp32 MFMA against F.conv2d -- pyramids, ragged sizes (partial 4x4 tiles at the
+    right / bottom edges, maps smaller than a tile), channel views whose neighbours are NaN, BN fold + residual + activation epilogue, per-level
+    ScaleExp."""
+    from pytorch_object_detection_amd import _lib
+    Cin, Cout, dil, hw, act, use_res = case
+    gen = torch.Generator().manual_seed(2 * Cin + Cout + len(hw))
+    B = 3
+    xs = [torch.randn(B, Cin, h, w, generator=gen) for h, w in hw]
+    wt = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    sc, sf = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen) * 0.1
+    rs = [torch.randn(B, Cout, h, w, generator=gen) for h, w in hw]
+    prm = [1.2, 0.9, 1.1, 0.8, 1.0][:len(hw)]
+    segs = Segs.make(B, hw)
+    ref = []
+    for lv, (x, r) in enumerate(zip(xs, rs)):
+        y = F.conv2d(x.double(), wt.double(), None, 1, 1, 1) * sc.double()[None, :, None, None] + sf.double()[None, :, None, None]
+        if use_res:
+            y = y + r.double()
+        if act == ACT_EXP:
+            y = torch.cat([y[:, :4], torch.exp(y[:, 4:] * prm[lv])], 1)
+        elif act != ACT_NONE:
+            y = act_ref(y, act)
+        ref.append(y.float())
+    xb = torch.full((segs.rows, Cin + 8), float("nan"), device=DEV)
+    xb[:, 4:4 + Cin] = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cin) for t in xs]).to(DEV)
+    rb = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cout) for t in rs]).contiguous().to(DEV)
+    yb = torch.full((segs.rows, Cout + 8), float("nan"), device=DEV)
+    y = ops.Rows(yb, 4, Cout)
+    wp = ops.pack_conv_weight_wino4(wt.to(DEV))
+    run = ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=1, dil=1, scale=sc.to(DEV), shift=sf.to(DEV),
+                        res=ops.Rows(rb) if use_res else None, act=act, act_c0=4 if act == ACT_EXP else 0, seg_param=prm if act == ACT_EXP else None,
+                        tile=_lib.WINO4_TILE)
+    run()
+    got = yb.cpu()
+    assert torch.isnan(got[:, :4]).all() and torch.isnan(got[:, 4 + Cout:]).all(), "wrote outside its channel view"
+    got = got[:, 4:4 + Cout]
+    assert not torch.isnan(got).any(), "an output pixel was never written"
+    for i, ((h, w), r) in enumerate(zip(hw, ref)):
+        g = got[segs.m_start[i]:segs.m_start[i + 1]].reshape(B, h, w, Cout).permute(0, 3, 1, 2)
+        # F(4x4)'s transforms multiply by up to 8: the fp32 evaluation of ONE layer is good to ~2e-5 of the output scale (max over 10^6 outputs:
+        # 8e-5 at |y| <= 5 in the CPU emulation tools/wino44_emul.py; mean 2e-6), a whole model to 2e-5 * (1 + |y|) (DESIGN 7.3)
+        scale = float(r.abs().max()) + 1.0
+        err = (g - r).abs()
+        assert float(err.max()) < 4e-5 * scale and float(err.mean()) < 2e-6 * scale, (i, float(err.max()), float(err.mean()), scale)
+    first = yb.clone()
+    run()
+    assert torch.equal(yb.nan_to_num(7.0), first.nan_to_num(7.0))          # bitwise reproducible
+    with pytest.raises(Exception, match="WINOGRAD4"):     # dilation 2: a clean error, no launch
+        ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=2, dil=2, tile=_lib.WINO4_TILE)()
