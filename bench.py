@@ -88,23 +88,29 @@ def pmc_traffic():
 def tower_roofline(plan, tower_flops: int, tower_ms: float) -> dict:
     """Roofline object of the dominant kernel, the fused cls_conv + reg_conv 3x3 head tower (5 levels, one launch).
     `achieved` / `frac` count the FLOPs the matrix pipe EXECUTES in the launch, over its HIP-event time, against the dense fp32-MFMA
-    peak: on the default Winograd F(2x2, 3x3) kernel that is the direct convolution's count (2 * rows * 512 * 256 * 9, SURVEY
-    section 8d) / 2.25 -- 16 multiplies per 2x2 output tile and channel pair instead of 36 -- so `frac` is a utilisation (<= 1,
+    peak: on a Winograd kernel that is the direct convolution's count (2 * rows * 512 * 256 * 9) / 4 for F(4x4, 3x3)
+    (the batch-16 default since round 3: 36 multiplies per 4x4 output tile and channel pair instead of 144) or / 2.25 for F(2x2, 3x3)
+    (16 instead of 36; FD_WINOGRAD4=0 or small batches) -- so `frac` is a utilisation (<= 1,
     comparable with the PMC MFMA-busy counter).  The algorithmic (direct-convolution) rate, which is what the layer delivers
     to the model, is reported separately as `effective_tflops` / `effective_over_peak` (may exceed 1 on the Winograd kernel)."""
-    wino = (plan.tiles.get("head.tower3x3", 0) & 0xFF) == 14
+    tile = plan.tiles.get("head.tower3x3", 0) & 0xFF
+    wino, wino4 = tile == 14, tile == 16
+    div = 4.0 if wino4 else (2.25 if wino else 1.0)
     effective = tower_flops / (tower_ms * 1e-3) / 1e12
-    executed_flops = int(tower_flops / 2.25) if wino else tower_flops
+    executed_flops = int(tower_flops / div)
     achieved = executed_flops / (tower_ms * 1e-3) / 1e12
     traffic, tsrc = pmc_traffic()
+    what = "head tower 3x3 (cls_conv+reg_conv fused, 5 levels)"
     return {"bound": "mfma",
-            "kernel": ("conv3x3_wino_kernel<TAG=1> head tower 3x3 (cls_conv+reg_conv fused, 5 levels): Winograd F(2x2,3x3), fp32"
-                       if wino else "conv_igemm_kernel<...,TAG=1> head tower 3x3 (cls_conv+reg_conv fused, 5 levels, tile id %d)"
-                       % plan.tiles.get("head.tower3x3", 0)),
+            "kernel": (f"conv3x3_wino4_kernel<TAG=1> {what}: Winograd F(4x4,3x3), fp32" if wino4 else
+                       f"conv3x3_wino_kernel<TAG=1> {what}: Winograd F(2x2,3x3), fp32" if wino else
+                       f"conv_igemm_kernel<...,TAG=1> {what}, tile id {tile}"),
             "instruction": "v_mfma_f32_32x32x2_f32", "achieved": round(achieved, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic, "traffic_source": tsrc,
-            "flops_basis": ("executed on the matrix pipe = direct-convolution FLOPs / 2.25 (Winograd F(2x2,3x3))" if wino
+            "flops_basis": ("executed on the matrix pipe = direct-convolution FLOPs / 4 (Winograd F(4x4,3x3): 36 multiplies per 4x4 output tile "
+                            "and channel pair instead of 144)" if wino4 else
+                            "executed on the matrix pipe = direct-convolution FLOPs / 2.25 (Winograd F(2x2,3x3))" if wino
                             else "executed = algorithmic (direct convolution)"),
             "flops_per_launch": executed_flops, "algorithmic_flops_per_launch": tower_flops, "avg_launch_ms": round(tower_ms, 4),
             "effective_tflops": round(effective, 2), "effective_over_peak": round(effective / PEAK_F32_MFMA_TFLOPS, 4)}
@@ -114,7 +120,7 @@ def family_rooflines(plan, x, reps: int = 5) -> dict:
     """Per kernel-family rooflines from the plan's own HIP-event step times (one batch in flight, one stream, median of `reps`
     passes, taken AFTER the timed region): family FLOPs / family time / peak.  `roofline_1x1` is the dominant family BY TIME
     (the GEMM-addressed 1x1 convs: bottleneck conv1 / conv3 / downsample, FPN laterals, head pointwise); executed = algorithmic
-    there.  For the Winograd family the executed count is algorithmic / 2.25."""
+    there.  For the Winograd family the executed count is algorithmic / 4 (F(4x4, 3x3) launches) or / 2.25 (F(2x2, 3x3)), per launch."""
     plan.image_ref[0] = x
     for _ in range(2):
         plan.run()
@@ -134,12 +140,12 @@ def family_rooflines(plan, x, reps: int = 5) -> dict:
     for i in range(n):
         info = plan.step_info.get(i)
         key = info["family"] if info else "other (HBM-bound passes, stem, post-process excluded)"
-        f = fam.setdefault(key, {"ms": 0.0, "flops": 0, "launches": 0})
-        f["ms"] += med[i]; f["flops"] += plan.step_flops.get(i, 0) if info else 0; f["launches"] += 1
+        f = fam.setdefault(key, {"ms": 0.0, "flops": 0, "executed": 0.0, "launches": 0})
+        fl = plan.step_flops.get(i, 0) if info else 0
+        f["ms"] += med[i]; f["flops"] += fl; f["executed"] += fl / (info.get("mfma_div", 1.0) if info else 1.0); f["launches"] += 1
     out = {"total_ms_one_batch_in_flight": round(sum(med), 3)}
     for key, f in fam.items():
-        div = 2.25 if key == "winograd3x3" else 1.0
-        tf = f["flops"] / div / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
+        tf = f["executed"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
         out[key] = {"ms": round(f["ms"], 3), "launches": f["launches"], "algorithmic_gflop": round(f["flops"] / 1e9, 1),
                     "executed_tflops": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
     return out

@@ -201,7 +201,13 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
             (res is None or (res.cs % 4 == 0 and res.co % 4 == 0))):
         wino, wino_ks = ops.wino_choice(segs, Cin, co, dil)
         wino = wino or tag == 1                   # (the head tower -- the roofline kernel -- always runs the Winograd kernel)
-    if wino:
+    # F(4x4, 3x3) where its cost model beats F(2x2, 3x3): exact-fp32 plans only, dilation 1, no split-K / gate / statistics epilogue
+    wino4 = (plan.winograd and gate is None and gn_stats is None and ops.wino4_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0
+             and (res is None or (res.cs % 4 == 0 and res.co % 4 == 0)) and ops.wino4_choice(segs, Cin, co))
+    if wino4:
+        wino, wino_ks = True, 1
+        wp = ops.pack_conv_weight_wino4(_dev(w, dev))
+    elif wino:
         wp = ops.pack_conv_weight_wino(_dev(w, dev))
     else:
         wp = ops.pack_conv_weight_f16x3(_dev(w, dev)) if split else ops.pack_conv_weight(_dev(w, dev))
@@ -234,13 +240,13 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     call = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                          shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param, tag=tag,
                          precision=1 if split else 0, workspace=ws.buf if ws is not None else None,
-                         tile=_lib.WINO_TILE if wino else 0, ksplit=wino_ks if wino else 1, gate=gate, w_frag=wfrag,
+                         tile=(_lib.WINO4_TILE if wino4 else _lib.WINO_TILE) if wino else 0, ksplit=wino_ks if wino else 1, gate=gate, w_frag=wfrag,
                          gate_b=gate_b, gate_act=gate_act, gn_stats=gn_stats, gn_groups=gn_groups)
     plan.add(name, call)
     if ws is not None:
         plan.pool.put(ws)
     if wino:
-        plan.tiles[name] = _lib.WINO_TILE | ((wino_ks if wino_ks > 1 else 0) << 8)
+        plan.tiles[name] = _lib.WINO4_TILE if wino4 else (_lib.WINO_TILE | ((wino_ks if wino_ks > 1 else 0) << 8))
     elif gate is not None:
         plan.tiles[name] = 0                 # (the library picks the tile of a gated conv)
     elif plan.autotune:
@@ -257,7 +263,9 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     plan.flops += 2 * out.rows * co * Cin * k * k
     plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k
     plan.step_info[len(plan.steps) - 1] = {"k": k, "stride": stride, "dil": dil, "Cin": Cin, "Cout": co, "rows": out.rows,
-                                           "family": "winograd3x3" if wino else ("1x1" if k == 1 else f"direct{k}x{k}")}
+                                           "family": "winograd3x3" if wino else ("1x1" if k == 1 else f"direct{k}x{k}"),
+                                           # multiplies saved on the matrix pipe: F(4x4,3x3) 36 per 16 outputs, F(2x2,3x3) 16 per 4, direct 9 per output
+                                           "mfma_div": 4.0 if wino4 else (2.25 if wino else 1.0)}
     return out
 
 

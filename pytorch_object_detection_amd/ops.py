@@ -458,6 +458,31 @@ def wino4_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bo
     return k == 3 and stride == 1 and pad == 1 and dil == 1 and Cin % 8 == 0 and Cout % 4 == 0
 
 
+# FD_WINOGRAD4: "1" (default) = layers the F(4x4, 3x3) kernel covers run on it where wino4_choice's cost model says it beats F(2x2, 3x3);
+# "0" = never (the round-2 plans); "force" = wherever it applies (tests exercise the kernel inside whole models this way)
+WINO4_MODE = os.environ.get("FD_WINOGRAD4", "1")
+
+
+def wino4_tiles(segs: Segs) -> int:
+    """4x4 output tiles FD_TILE_WINOGRAD4 enumerates: per level and image ceil(H/4) x ceil(W/4)."""
+    return sum(segs.batch * (-(-h // 4)) * (-(-w // 4)) for h, w in segs.level_hw())
+
+
+def wino4_choice(segs: Segs, Cin: int, Cout: int) -> bool:
+    """F(4x4, 3x3) instead of F(2x2, 3x3)?  One F(4x4) workgroup owns 32 tiles x 64 couts and a whole CU (144 KB of LDS, 2 x 256-register
+    waves per SIMD), so its time goes in ROUNDS of 256 workgroups:
+      t_w4 = ceil(workgroups / 256) * (3.0 us * Cin / 8 + 20 us)
+    (fitted to the in-plan step times of profiles/r03w_layer_times_w4.tsv at batch 16: head tower 0.98 ms in 9 rounds, layer3.conv2 0.128 in 1,
+    layer2.conv2 0.157 in 2; layer1.conv2 -- 0.206 ms in 4 rounds of 8 chunks, against 0.18 ms -- is where the fixed prologue + epilogue cost loses).  It has no split-K and no row-statistics epilogue: maps with few tiles (batch 1, layer4) stay on F(2x2) / direct."""
+    if WINO4_MODE == "0":
+        return False
+    if WINO4_MODE == "force":
+        return True
+    wgs = -(-wino4_tiles(segs) // 32) * -(-Cout // 64)
+    t4 = -(-wgs // 256) * (3.0 * (Cin // 8) + 20.0)
+    return t4 < 0.95 * _wino_times(segs, Cin, Cout, 1, True)[0]
+
+
 def wino_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bool:
     """Shapes FD_TILE_WINOGRAD covers (the output / residual views must also be 16-byte addressable)."""
     return k == 3 and stride == 1 and pad == dil and dil in (1, 2) and Cin % 8 == 0 and Cout % 4 == 0
@@ -481,6 +506,12 @@ def wino_choice(segs: Segs, Cin: int, Cout: int, dil: int, allow_split: bool = T
       t_direct   = max(21 us [narrow Cout <= 96: no split-K there, 1.9 us per K-tile], FLOPs / 95 TFLOP/s)"""
     if WINO_FORCE:
         return True, 1
+    best_t, best_ks, t_d = _wino_times(segs, Cin, Cout, dil, allow_split)[1:]
+    return best_t < t_d, best_ks
+
+
+def _wino_times(segs: Segs, Cin: int, Cout: int, dil: int, allow_split: bool):
+    """The cost model of wino_choice: (min(t_wino, t_direct), t_wino at its best split, that split, t_direct), microseconds."""
     T = wino_tiles(segs, dil)
     mt = -(-T // 32)
     nch = 4 if (Cout % 128 == 0 and Cout >= 256 and mt * (Cout // 128) >= 192) else 2      # as fd_launch_conv_wino chooses
@@ -497,7 +528,7 @@ def wino_choice(segs: Segs, Cin: int, Cout: int, dil: int, allow_split: bool = T
     flops = 2.0 * segs.rows * max(Cout, 32) * Cin * 9
     floor = 1.9 * (-(-Cin // 32) * 9) if Cout <= 96 else 21.0
     t_d = max(floor, flops / 95e12 * 1e6)
-    return best_t < t_d, best_ks
+    return min(best_t, t_d), best_t, best_ks, t_d
 
 
 def wino_preferred(segs: Segs, Cin: int, Cout: int, dil: int) -> bool:

@@ -88,12 +88,17 @@ def test_tiny_fcos_fpn_head_golden(golden):
         np.testing.assert_allclose(reg[i].cpu().numpy(), g[f"reg{i}"], **TOL)
 
 
-@pytest.mark.parametrize("prec", ["f32", "f32-winograd-everywhere", "f16x3", "mixed"])
+@pytest.mark.parametrize("prec", ["f32", "f32-winograd-everywhere", "f32-winograd4-everywhere", "f16x3", "mixed"])
 @pytest.mark.parametrize("shape", [(2, 128, 128), (1, 256, 192)])
 def test_full_hisfcos_vs_oracle(shape, prec, monkeypatch):
+    from pytorch_object_detection_amd import ops as _ops
+    monkeypatch.setattr(_ops, "WINO4_MODE", "0")   # (the cost model keeps F(4x4) off maps this small anyway; pinned so the legs below are what they say)
     if prec == "f32-winograd-everywhere":      # small maps normally go to the direct kernel (ops.wino_preferred): force the Winograd
-        from pytorch_object_detection_amd import ops as _ops    # kernel onto every 3x3 stride-1 layer, tiny levels and all
-        monkeypatch.setattr(_ops, "WINO_FORCE", True)
+        monkeypatch.setattr(_ops, "WINO_FORCE", True)           # kernel onto every 3x3 stride-1 layer, tiny levels and all
+        prec = "f32"
+    if prec == "f32-winograd4-everywhere":     # F(4x4, 3x3) on every dilation-1 3x3 stride-1 layer (the batch-16 bench plan's choice, forced
+        monkeypatch.setattr(_ops, "WINO_FORCE", True)           # onto the small maps of this test), F(2x2) on the dilated ones
+        monkeypatch.setattr(_ops, "WINO4_MODE", "force")
         prec = "f32"
     torch.manual_seed(0)
     B, H, W = shape
@@ -247,7 +252,9 @@ def test_full_size_batch16_is_per_image_independent():
         oi = model(x[i:i + 1].contiguous())
         for g_full, g_one in zip(full, oi):
             for tf, to in zip(g_full, g_one):
-                np.testing.assert_allclose(tf[i:i + 1].cpu().numpy(), to.cpu().numpy(), atol=2e-5, rtol=2e-5)
+                # (the batch-16 plan runs its wide 3x3 layers on Winograd F(4x4, 3x3), the single-image plan on F(2x2) / the direct kernel:
+                # different exact-fp32 algorithms, so the bound is the conv tolerance of the parity tests, not a summation-order one)
+                np.testing.assert_allclose(tf[i:i + 1].cpu().numpy(), to.cpu().numpy(), **TOL)
         si, ci, bi, ni = head.detect_padded(oi)
         k = int(ni[0])
         assert k == int(n[i])

@@ -23,7 +23,8 @@ def load(d):
 def longest_conv(rows):
     # the roofline kernel = the head-tower launch, which runs under its own symbol (TAG = 1): the Winograd kernel
     # conv3x3_wino_kernel<1, ..> (default) or, with FD_WINOGRAD=0, conv_igemm_kernel<..., 1, false>
-    conv = [v for v in rows if "conv3x3_wino_kernel<1" in v["name"]] or [v for v in rows if "conv_igemm_kernel" in v["name"]]
+    conv = ([v for v in rows if "conv3x3_wino4_kernel<1" in v["name"]] or [v for v in rows if "conv3x3_wino_kernel<1" in v["name"]]
+            or [v for v in rows if "conv_igemm_kernel" in v["name"]])
     top = max(conv, key=lambda v: v["dur_ns"])
     same = [v for v in conv if v["name"] == top["name"] and v["grid"] == top["grid"] and v["dur_ns"] > 0.7 * top["dur_ns"]]
     return same

@@ -1,4 +1,4 @@
-"""One Winograd launch shape, a few launches (for rocprofv3 --pmc passes): python3 tools/wino_one.py [tower|l3|l1]"""
+"""One Winograd launch shape, a few launches (for rocprofv3 --pmc passes): python3 tools/wino_one.py [tower|l3|l1|hb3] [2|4]   (F(2x2) / F(4x4))"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_object_detection_amd import ops, _lib
@@ -12,7 +12,9 @@ segs = Segs.make(B, hw)
 x = ops.Rows(torch.randn(segs.rows, Cin, device=dev))
 y = ops.new_rows(segs.rows, Cout, dev)
 w = torch.randn(Cout, Cin, 3, 3, device=dev) / (Cin * 9) ** 0.5
-call = ops.conv_call(x, segs, ops.pack_conv_weight_wino(w), y, Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, tile=_lib.WINO_TILE)
+f4 = len(sys.argv) > 2 and sys.argv[2] == "4"
+call = ops.conv_call(x, segs, ops.pack_conv_weight_wino4(w) if f4 else ops.pack_conv_weight_wino(w), y, Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil,
+                     tile=_lib.WINO4_TILE if f4 else _lib.WINO_TILE)
 for _ in range(6):
     call()
 torch.cuda.synchronize()
