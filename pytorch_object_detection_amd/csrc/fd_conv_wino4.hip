@@ -21,12 +21,14 @@
 //   * epilogue: the two channel blocks in turn -- the block's four waves put their accumulators into LDS planes, then gather the 36 frequencies of
 //     (tile, 4 couts) per thread, apply A^T . A and y = act(v * scale + shift (+ | mask) res) and store 16 bytes per pixel.
 #include "fd_conv_common.h"
+#include <type_traits>
 
 struct Wino4Args {
     const float* x; const float* u; const float* scale; const float* shift; const float* res; float* y;
     int x_cs, x_co, res_cs, res_co, y_cs, y_co;
     int Cin, Cout, act, act_c0, res_mask;
     int NC;                       // 8-channel chunks
+    int dil;                      // 1, or 2: four parity classes (ph, pw) per image, each a dense conv on the sub-grid h = 2 hs + ph, w = 2 ws + pw
     int nseg;
     int H[FD_MAX_SEG], W[FD_MAX_SEG], TH[FD_MAX_SEG], TW[FD_MAX_SEG];   // TH x TW tiles of 4 x 4 outputs
     int m0[FD_MAX_SEG];           // first row of the level
@@ -41,9 +43,11 @@ struct Wino4Args {
 #define W4_TB 32
 #define W4_KC 8
 #define W4_PLANE (W4_TB * W4_KC)            // floats per frequency plane of V
-#define W4_STAGE (36 * W4_PLANE)            // floats per V stage (36 KB) == floats per scratch stage
+#define W4_STAGE (36 * W4_PLANE)            // floats per V stage (36 KB)
+#define W4_SBLK 37                          // float4s per (tile, channel quad) block of the scratch: 36 + 1, odd, so that 64 lanes = 64 blocks never share a bank
+#define W4_SSTAGE (64 * W4_SBLK * 4)        // floats per scratch stage (37 KB)
 
-struct Tile4 { int s, n, h0, w0; bool ok; };
+struct Tile4 { int s, n, h0, w0, ph, pw; bool ok; };     // h0, w0: first output of the tile in sub-grid coordinates
 
 __device__ __forceinline__ Tile4 wino4_decode(const Wino4Args& a, int t) {
     Tile4 p;
@@ -54,10 +58,12 @@ __device__ __forceinline__ Tile4 wino4_decode(const Wino4Args& a, int t) {
     for (int i = 1; i < FD_MAX_SEG; ++i)
         if (i < a.nseg && t >= a.t0[i]) s = i;
     const int local = t - a.t0[s];
-    const int tpi = a.TH[s] * a.TW[s];
-    const int n = local / tpi, r = local - n * tpi;
+    const int tpc = a.TH[s] * a.TW[s], tpi = tpc * a.dil * a.dil;
+    const int n = local / tpi, rc = local - n * tpi;
+    const int cls = rc / tpc, r = rc - cls * tpc;
     const int ti = r / a.TW[s], tj = r - ti * a.TW[s];
     p.s = s; p.n = n; p.h0 = 4 * ti; p.w0 = 4 * tj;
+    p.ph = cls / a.dil; p.pw = cls - p.ph * a.dil;
     return p;
 }
 
@@ -102,7 +108,7 @@ template <int TAG>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Vs = reinterpret_cast<float*>(smem);                  // [2][36][32][8]
-    float* Ss = Vs + 2 * W4_STAGE;                               // [2][32 tiles][2 q][6 j'][6 i][4]
+    float* Ss = Vs + 2 * W4_STAGE;                               // [2][32 tiles][2 q] blocks of W4_SBLK float4: [6 j'][6 i] + pad
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = wave & 3, ch = wave >> 2;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -121,24 +127,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
 
     // ---- loader role (threads 0 .. 383): (tile lt, line pr, channel quad q); pr = patch row i in G / R, column j' in C ----
     const bool ldr = __builtin_amdgcn_readfirstlane(tid) < 384 && !(a.dbg & 1);       // wave-uniform: scalar branches around the loader slices
-    const int q = tid & 1, pr = (tid >> 1) % 6, lt = min(tid / 12, W4_TB - 1);
+    // one line pr per WAVE, (tile, quad) per lane: every scratch / V instruction of a wave then walks 64 different blocks at one in-block offset
+    const int q = tid & 1, lt = (tid >> 1) & 31, pr = min(tid >> 6, 5);
     // patch row pr of tile lt: one base offset per thread; the six columns differ by a uniform pixel stride (buffer soffset) and a validity bit each
     unsigned a_base;
     bool a_ok[6];
     {
         const Tile4 p = wino4_decode(a, tile0 + lt);
         const int H = a.H[p.s], W = a.W[p.s];
-        const int hh = p.h0 - 1 + pr;
+        const int hh = (p.h0 - 1 + pr) * a.dil + p.ph;           // (negative exactly when the sub-grid row is)
         const bool row_ok = ldr && p.ok && (unsigned)hh < (unsigned)H;
         const int rowbase = a.m0[p.s] + (p.n * H + hh) * W;
-        a_base = ((unsigned)(rowbase + p.w0) * (unsigned)a.x_cs + (unsigned)(a.x_co + q * 4)) * 4u;       // column j = 1 (w0); j adds (j - 1) pixels
+        a_base = ((unsigned)(rowbase + p.w0 * a.dil + p.pw) * (unsigned)a.x_cs + (unsigned)(a.x_co + q * 4)) * 4u;    // column j = 1; j adds (j - 1) * dil pixels
 #pragma unroll
-        for (int j = 0; j < 6; ++j) a_ok[j] = row_ok && (unsigned)(p.w0 - 1 + j) < (unsigned)W;
+        for (int j = 0; j < 6; ++j) a_ok[j] = row_ok && (unsigned)((p.w0 - 1 + j) * a.dil + p.pw) < (unsigned)W;
     }
-    const int px_b = a.x_cs * 4;                                 // bytes between neighbouring pixels of one row
+    const int px_b = a.x_cs * 4 * a.dil;                         // bytes between neighbouring patch pixels of one row
     // scratch: S[lt][q][j'][i] float4 -- R writes element (j', i = pr) for j' = 0..5; C reads (j' = pr, i = 0..5): 6 consecutive float4
-    const int s_wr = ((lt * 2 + q) * 36 + pr) * 4;               // + j' * 24 floats
-    const int s_rd = ((lt * 2 + q) * 36 + pr * 6) * 4;           // + i * 4 floats
+    const int s_wr = ((lt * 2 + q) * W4_SBLK + pr) * 4;          // + j' * 24 floats
+    const int s_rd = ((lt * 2 + q) * W4_SBLK + pr * 6) * 4;      // + i * 4 floats
     // V[f = 6 i' + j'][tile][8 c]: tile rows XORed with j' (the six planes of one write instruction differ in j'), 16-byte halves with tile bit 4
     const int v_wr = (pr * W4_TB + (lt ^ pr)) * W4_KC + 4 * (q ^ ((lt >> 4) & 1));      // + i' * 6 * W4_PLANE
 
@@ -164,13 +171,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     auto stage_R = [&](int st) {                 // row pass (along the patch row) -> scratch
         float4 t[6];
         w4_bt(pv, t);
-        float* d = Ss + st * W4_STAGE + s_wr;
+        float* d = Ss + st * W4_SSTAGE + s_wr;
 #pragma unroll
         for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(d + j * 24) = t[j];
     };
     auto stage_C = [&](int st) {                 // column pass (down column j' = pr) -> V
         float4 s[6], v[6];
-        const float* r = Ss + st * W4_STAGE + s_rd;
+        const float* r = Ss + st * W4_SSTAGE + s_rd;
 #pragma unroll
         for (int i = 0; i < 6; ++i) s[i] = *reinterpret_cast<const float4*>(r + i * 4);
         w4_bt(s, v);
@@ -197,6 +204,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     //   group 0: R(cc+2) row pass in place in the patch registers   group 1: -> scratch[st]
     //   group 2: C(cc+1) reads its column from scratch[st^1] into the same registers   group 3: column pass in place   group 4: -> V[st^1]
     //   group 5: G(cc+3) issues the patch loads (four groups and a barrier before group 0 of the next chunk consumes them)
+    // The loop exists twice, for the loader waves and for the two waves without a loader role: s_waitcnt counts are in-order counts, and where the
+    // two paths joined after every slice the compiler had to assume the shorter queue -- the loader waves then waited for their own slice's LDS
+    // traffic before every MFMA group.
+    auto main_loop = [&](auto ldr_c) {
+    constexpr bool LDR = decltype(ldr_c)::value;
     for (int cc = 0; cc < NC; ++cc) {
         const int st = cc & 1;
         const float* Vb = Vs + st * W4_STAGE + (9 * g) * W4_PLANE + v_half;
@@ -215,15 +227,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
             acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.z, fb.z, acc[fi], 0, 0, 0);
             acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, fb.w, acc[fi], 0, 0, 0);
             load_u(cn, fi);                                            // next chunk's block into the registers just consumed
-            if (ldr) {
+            if constexpr (LDR) {
                 if (fi == 0) w4_bt_inplace(pv);
                 if (fi == 1) {
-                    float* d = Ss + st * W4_STAGE + s_wr;
+                    float* d = Ss + st * W4_SSTAGE + s_wr;
 #pragma unroll
                     for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(d + j * 24) = pv[j];
                 }
                 if (fi == 2) {
-                    const float* r = Ss + (st ^ 1) * W4_STAGE + s_rd;
+                    const float* r = Ss + (st ^ 1) * W4_SSTAGE + s_rd;
 #pragma unroll
                     for (int i = 0; i < 6; ++i) pv[i] = *reinterpret_cast<const float4*>(r + i * 4);
                 }
@@ -240,6 +252,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
+    };
+    if (ldr) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
 
     // ---- epilogue: the two channel blocks in turn through the (now free) 144 KB of LDS ----
     if (a.dbg & 4) return;
@@ -302,11 +317,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
             const float4 sf = a.shift ? *reinterpret_cast<const float4*>(a.shift + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                const int h = ep.h0 + x;
+                const int h = (ep.h0 + x) * a.dil + ep.ph;
                 if (h >= eH) continue;
 #pragma unroll
                 for (int y = 0; y < 4; ++y) {
-                    const int w = ep.w0 + y;
+                    const int w = (ep.w0 + y) * a.dil + ep.pw;
                     if (w >= eW) continue;
                     const size_t m_ = (size_t)(a.m0[ep.s] + (ep.n * eH + h) * eW + w);
                     float4 v = make_float4(Y[x][y].x * sc.x + sf.x, Y[x][y].y * sc.y + sf.y, Y[x][y].z * sc.z + sf.z, Y[x][y].w * sc.w + sf.w);
@@ -377,9 +392,9 @@ extern "C" int32_t fd_wino4_pack_weights_f32(const float* w, float* out, int32_t
 }
 
 int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
-    FD_REQUIRE(p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->dil == 1 && p->Cin % 8 == 0 && p->Cout % 4 == 0 &&
+    FD_REQUIRE(p->KH == 3 && p->KW == 3 && p->stride == 1 && (p->dil == 1 || p->dil == 2) && p->pad == p->dil && p->Cin % 8 == 0 && p->Cout % 4 == 0 &&
                    p->precision == FD_PREC_F32 && p->ksplit <= 1 && p->out_H <= 0 && p->sc_H <= 0 && !p->gate && !p->gn_stats,
-               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD4 needs an fp32 3x3 stride-1 pad-1 dilation-1 conv with Cin %% 8 == 0, Cout %% 4 == 0, no split-K / scatter / gate / gn_stats");
+               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD4 needs an fp32 3x3 stride-1 'same' conv of dilation 1 or 2 with Cin %% 8 == 0, Cout %% 4 == 0, no split-K / scatter / gate / gn_stats");
     FD_REQUIRE(p->x_cs % 4 == 0 && p->x_co % 4 == 0 && p->y_cs % 4 == 0 && p->y_co % 4 == 0 && ((uintptr_t)p->y & 15) == 0 &&
                    (!p->res || (p->res_cs % 4 == 0 && p->res_co % 4 == 0 && ((uintptr_t)p->res & 15) == 0)) &&
                    (!p->scale || ((uintptr_t)p->scale & 15) == 0) && (!p->shift || ((uintptr_t)p->shift & 15) == 0),
@@ -390,15 +405,16 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
     a.Cin = p->Cin; a.Cout = p->Cout; a.act = p->act; a.act_c0 = p->act_c0;
     a.res_mask = (p->res && p->res_mode == 1) ? 1 : 0;
     a.NC = p->Cin / 8;
+    a.dil = p->dil;
     a.nseg = p->in.nseg;
     long t = 0;
     for (int s = 0; s < FD_MAX_SEG; ++s) {
         a.t0[s] = (int)t;
         if (s < p->in.nseg) {
             a.H[s] = p->in.H[s]; a.W[s] = p->in.W[s];
-            a.TH[s] = (p->in.H[s] + 3) / 4; a.TW[s] = (p->in.W[s] + 3) / 4;
+            a.TH[s] = ((p->in.H[s] + p->dil - 1) / p->dil + 3) / 4; a.TW[s] = ((p->in.W[s] + p->dil - 1) / p->dil + 3) / 4;   // per parity class
             a.m0[s] = p->in.m_start[s];
-            t += (long)p->in.batch * a.TH[s] * a.TW[s];
+            t += (long)p->in.batch * p->dil * p->dil * a.TH[s] * a.TW[s];
         } else {
             a.H[s] = a.W[s] = a.TH[s] = a.TW[s] = 1; a.m0[s] = 0;
         }
@@ -417,7 +433,7 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
     a.mtiles = (a.T + W4_TB - 1) / W4_TB;
     a.ntiles = (p->Cout + 63) / 64;
     a.mt_per = (a.mtiles + 7) / 8;
-    constexpr int lds = 4 * W4_STAGE * 4;        // 144 KB
+    constexpr int lds = (2 * W4_STAGE + 2 * W4_SSTAGE) * 4;        // 146 KB
     const dim3 grid((unsigned)(8 * a.mt_per * a.ntiles));
     if (p->tag == 1) {
         static std::atomic<unsigned> m1{0};

@@ -203,7 +203,7 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         wino = wino or tag == 1                   # (the head tower -- the roofline kernel -- always runs the Winograd kernel)
     # F(4x4, 3x3) where its cost model beats F(2x2, 3x3): exact-fp32 plans only, dilation 1, no split-K / gate / statistics epilogue
     wino4 = (plan.winograd and gate is None and gn_stats is None and ops.wino4_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0
-             and (res is None or (res.cs % 4 == 0 and res.co % 4 == 0)) and ops.wino4_choice(segs, Cin, co))
+             and (res is None or (res.cs % 4 == 0 and res.co % 4 == 0)) and ops.wino4_choice(segs, Cin, co, dil))
     if wino4:
         wino, wino_ks = True, 1
         wp = ops.pack_conv_weight_wino4(_dev(w, dev))

@@ -455,7 +455,7 @@ def pack_conv_weight_wino4(w: torch.Tensor) -> torch.Tensor:
 
 def wino4_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bool:
     """Shapes FD_TILE_WINOGRAD4 covers."""
-    return k == 3 and stride == 1 and pad == 1 and dil == 1 and Cin % 8 == 0 and Cout % 4 == 0
+    return k == 3 and stride == 1 and pad == dil and dil in (1, 2) and Cin % 8 == 0 and Cout % 4 == 0
 
 
 # FD_WINOGRAD4: "1" (default) = layers the F(4x4, 3x3) kernel covers run on it where wino4_choice's cost model says it beats F(2x2, 3x3);
@@ -463,12 +463,12 @@ def wino4_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bo
 WINO4_MODE = os.environ.get("FD_WINOGRAD4", "1")
 
 
-def wino4_tiles(segs: Segs) -> int:
-    """4x4 output tiles FD_TILE_WINOGRAD4 enumerates: per level and image ceil(H/4) x ceil(W/4)."""
-    return sum(segs.batch * (-(-h // 4)) * (-(-w // 4)) for h, w in segs.level_hw())
+def wino4_tiles(segs: Segs, dil: int = 1) -> int:
+    """4x4 output tiles FD_TILE_WINOGRAD4 enumerates: per level, image and dilation parity class ceil(ceil(H/dil)/4) x ceil(ceil(W/dil)/4)."""
+    return sum(segs.batch * dil * dil * (-(-(-(-h // dil)) // 4)) * (-(-(-(-w // dil)) // 4)) for h, w in segs.level_hw())
 
 
-def wino4_choice(segs: Segs, Cin: int, Cout: int) -> bool:
+def wino4_choice(segs: Segs, Cin: int, Cout: int, dil: int = 1) -> bool:
     """F(4x4, 3x3) instead of F(2x2, 3x3)?  One F(4x4) workgroup owns 32 tiles x 64 couts and a whole CU (144 KB of LDS, 2 x 256-register
     waves per SIMD), so its time goes in ROUNDS of 256 workgroups:
       t_w4 = ceil(workgroups / 256) * (3.0 us * Cin / 8 + 20 us)
@@ -478,9 +478,9 @@ def wino4_choice(segs: Segs, Cin: int, Cout: int) -> bool:
         return False
     if WINO4_MODE == "force":
         return True
-    wgs = -(-wino4_tiles(segs) // 32) * -(-Cout // 64)
+    wgs = -(-wino4_tiles(segs, dil) // 32) * -(-Cout // 64)
     t4 = -(-wgs // 256) * (3.0 * (Cin // 8) + 20.0)
-    return t4 < 0.95 * _wino_times(segs, Cin, Cout, 1, True)[0]
+    return t4 < 0.95 * _wino_times(segs, Cin, Cout, dil, True)[0]
 
 
 def wino_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bool:

@@ -1159,11 +1159,12 @@ def test_hisfcos_head_fused_groupnorm_equals_unfused_and_oracle(monkeypatch):
         np.testing.assert_allclose(a.cpu().numpy(), r.numpy(), atol=1e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("case", [c for c in WINO_CASES if c[2] == 1] + [(256, 80, 1, [(17, 23), (9, 12), (5, 6), (3, 3), (2, 1)], ACT_EXP, False)])
+@pytest.mark.parametrize("case", WINO_CASES + [(256, 80, 1, [(17, 23), (9, 12), (5, 6), (3, 3), (2, 1)], ACT_EXP, False),
+                                            (64, 64, 2, [(21, 18), (7, 9)], ACT_NONE, False)])      # dilation 2, odd sizes: ragged parity classes
 def test_conv3x3_winograd_f4x4(case):
     """FD_TILE_WINOGRAD4 (fd_conv_wino4.hip): F(4x4, 3x3) on the fp32 MFMA against F.conv2d -- pyramids, ragged sizes (partial 4x4 tiles at the
-    right / bottom edges, maps smaller than a tile), channel views whose neighbours are NaN, BN fold + residual + activation epilogue, per-level
-    ScaleExp."""
+    right / bottom edges, maps smaller than a tile), dilation 2 (four parity classes per image), channel views whose neighbours are NaN, BN fold +
+    residual + activation epilogue, per-level ScaleExp."""
     from pytorch_object_detection_amd import _lib
     Cin, Cout, dil, hw, act, use_res = case
     gen = torch.Generator().manual_seed(2 * Cin + Cout + len(hw))
@@ -1176,7 +1177,7 @@ def test_conv3x3_winograd_f4x4(case):
     segs = Segs.make(B, hw)
     ref = []
     for lv, (x, r) in enumerate(zip(xs, rs)):
-        y = F.conv2d(x.double(), wt.double(), None, 1, 1, 1) * sc.double()[None, :, None, None] + sf.double()[None, :, None, None]
+        y = F.conv2d(x.double(), wt.double(), None, 1, dil, dil) * sc.double()[None, :, None, None] + sf.double()[None, :, None, None]
         if use_res:
             y = y + r.double()
         if act == ACT_EXP:
@@ -1190,7 +1191,7 @@ def test_conv3x3_winograd_f4x4(case):
     yb = torch.full((segs.rows, Cout + 8), float("nan"), device=DEV)
     y = ops.Rows(yb, 4, Cout)
     wp = ops.pack_conv_weight_wino4(wt.to(DEV))
-    run = ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=1, dil=1, scale=sc.to(DEV), shift=sf.to(DEV),
+    run = ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, scale=sc.to(DEV), shift=sf.to(DEV),
                         res=ops.Rows(rb) if use_res else None, act=act, act_c0=4 if act == ACT_EXP else 0, seg_param=prm if act == ACT_EXP else None,
                         tile=_lib.WINO4_TILE)
     run()
@@ -1208,5 +1209,5 @@ def test_conv3x3_winograd_f4x4(case):
     first = yb.clone()
     run()
     assert torch.equal(yb.nan_to_num(7.0), first.nan_to_num(7.0))          # bitwise reproducible
-    with pytest.raises(Exception, match="WINOGRAD4"):     # dilation 2: a clean error, no launch
-        ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=2, dil=2, tile=_lib.WINO4_TILE)()
+    with pytest.raises(Exception, match="WINOGRAD4"):     # dilation 3: a clean error, no launch
+        ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=3, dil=3, tile=_lib.WINO4_TILE)()
