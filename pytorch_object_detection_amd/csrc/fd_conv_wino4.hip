@@ -18,8 +18,9 @@
 //     LDS: V 2 x 36 KB + scratch 2 x 36 KB = 144 KB; the epilogue reuses all of it for the 36 x 32 x 32 frequency planes of one channel block;
 //   * U goes global -> registers in MFMA layout (packed [cout/32][chunk][36 f][32 cout][8 c], 1 KB per frequency block), the block of chunk
 //     cc+1 into the registers the MFMAs of chunk cc have just consumed;
-//   * epilogue: the two channel blocks in turn -- the block's four waves put their accumulators into LDS planes, then gather the 36 frequencies of
-//     (tile, 4 couts) per thread, apply A^T . A and y = act(v * scale + shift (+ | mask) res) and store 16 bytes per pixel.
+//   * epilogue: the two halves of the 32 tiles in turn -- all waves put that half of their accumulators into LDS planes, then every thread gathers the
+//     36 frequencies of (tile, 4 couts), applies A^T . A for two of the four output rows and y = act(v * scale + shift (+ | mask) res) and stores
+//     16 bytes per pixel.
 #include "fd_conv_common.h"
 #include <type_traits>
 
@@ -256,40 +257,44 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     if (ldr) main_loop(std::true_type{});
     else main_loop(std::false_type{});
 
-    // ---- epilogue: the two channel blocks in turn through the (now free) 144 KB of LDS ----
+    // ---- epilogue: two halves of the 32 tiles in turn through the (now free) LDS, both channel blocks and all eight waves at once ----
+    // Accumulator rows 0..15 are registers e = 0..7 of every f32x16, rows 16..31 registers 8..15: half h is dead in the register file once written, so
+    // the output pass of half 0 runs beside 72 live accumulator registers only (the whole-tile variant spilled, the block-by-block one idled four waves).
     if (a.dbg & 4) return;
-    float* Ms = reinterpret_cast<float*>(smem);                          // [36 f][32 tiles][32 cout]
-    // output role of the four waves of one channel block (their accumulators are dead by then: no spills): thread = (tile, cout quad), all 16 outputs
-    const int tl = tid & 255, et = tl >> 3, eq = tl & 7;
-    const Tile4 ep = wino4_decode(a, tile0 + et);
-    const int eH = a.H[ep.s], eW = a.W[ep.s];
-    const float eprm = a.seg_param[ep.s];
-    // ch 0 waves: planes, B1, outputs, B2, B3.   ch 1 waves: B1, B2, planes, B3, outputs.  (s_barrier counts arrivals, not code positions; the branch is
-    // wave-uniform.)  Each wave's accumulators are dead before its output pass, so neither pass spills.
-    const int cb = __builtin_amdgcn_readfirstlane(ch);
-    if (cb) { __syncthreads(); __syncthreads(); }
-    {
+    float* Ms = reinterpret_cast<float*>(smem);                          // [2 ch][36 f][16 tiles][32 cout]
+    // output role: thread = (channel block, row pair of the 4 x 4 outputs, tile of the half, cout quad)
+    int te = tid;
+    asm volatile("" : "+v"(te));                                         // (opaque: nothing of the output role is computed, and kept in registers, ahead of the main loop)
+    const int ech = te >> 8, eh = (te >> 7) & 1, et = (te >> 3) & 15, eq = te & 7;
+    const int nn = n0 + ech * 32 + eq * 4;
+    const float4 sc = (a.scale && nn < a.Cout) ? *reinterpret_cast<const float4*>(a.scale + nn) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sf = (a.shift && nn < a.Cout) ? *reinterpret_cast<const float4*>(a.shift + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();                                          // (the output pass of half 0 has read its planes)
 #pragma unroll
         for (int fi = 0; fi < 9; ++fi) {
-            float* d = Ms + ((9 * g + fi) * 32) * 32 + l31;
+            float* d = Ms + ((ch * 36 + 9 * g + fi) * 16) * 32 + l31;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) d[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32] = acc[fi][e];
+            for (int e = 0; e < 8; ++e) d[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32] = acc[fi][8 * h + e];
         }
         __syncthreads();
-        const int nn = n0 + cb * 32 + eq * 4;
+        const Tile4 ep = wino4_decode(a, tile0 + 16 * h + et);
+        const int eH = a.H[ep.s], eW = a.W[ep.s];
+        const float eprm = a.seg_param[ep.s];
         if (ep.ok && nn < a.Cout) {
             // Y = A^T M A, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]: per frequency row i the column pass r_i[y], then
-            // Y[x][y] += A^T[x][i] * r_i[y] (the zero entries of A^T compile away)
-            float4 Y[4][4];
+            // Y[x][y] += A^T[x][i] * r_i[y] for this thread's two rows x = 2 eh, 2 eh + 1 (eh is wave-uniform; the zero entries of A^T cost nothing)
+            float4 Y[2][4];
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+            for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int y = 0; y < 4; ++y) Y[x][y] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 float4 m[6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) m[j] = *reinterpret_cast<const float4*>(Ms + ((6 * i + j) * 32 + et) * 32 + eq * 4);
+                for (int j = 0; j < 6; ++j) m[j] = *reinterpret_cast<const float4*>(Ms + ((ech * 36 + 6 * i + j) * 16 + et) * 32 + eq * 4);
                 float4 r[4];
 #define W4_AT1(c)                                                                     \
     {                                                                                 \
@@ -303,27 +308,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                 W4_AT1(x) W4_AT1(y) W4_AT1(z) W4_AT1(w)
 #undef W4_AT1
                 constexpr float AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const float cx = AT[x][i];
-                    if (cx == 0.f) continue;
+                const float c0 = eh ? AT[2][i] : AT[0][i], c1 = eh ? AT[3][i] : AT[1][i];
+                if (AT[0][i] != 0.f || AT[2][i] != 0.f) {
 #pragma unroll
                     for (int y = 0; y < 4; ++y) {
-                        Y[x][y].x += cx * r[y].x; Y[x][y].y += cx * r[y].y; Y[x][y].z += cx * r[y].z; Y[x][y].w += cx * r[y].w;
+                        Y[0][y].x += c0 * r[y].x; Y[0][y].y += c0 * r[y].y; Y[0][y].z += c0 * r[y].z; Y[0][y].w += c0 * r[y].w;
+                    }
+                }
+                if (AT[1][i] != 0.f || AT[3][i] != 0.f) {
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) {
+                        Y[1][y].x += c1 * r[y].x; Y[1][y].y += c1 * r[y].y; Y[1][y].z += c1 * r[y].z; Y[1][y].w += c1 * r[y].w;
                     }
                 }
             }
-            const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + nn) : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float4 sf = a.shift ? *reinterpret_cast<const float4*>(a.shift + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int h = (ep.h0 + x) * a.dil + ep.ph;
-                if (h >= eH) continue;
+            for (int x = 0; x < 2; ++x) {
+                const int hh = (ep.h0 + 2 * eh + x) * a.dil + ep.ph;
+                if (hh >= eH) continue;
 #pragma unroll
                 for (int y = 0; y < 4; ++y) {
                     const int w = (ep.w0 + y) * a.dil + ep.pw;
                     if (w >= eW) continue;
-                    const size_t m_ = (size_t)(a.m0[ep.s] + (ep.n * eH + h) * eW + w);
+                    const size_t m_ = (size_t)(a.m0[ep.s] + (ep.n * eH + hh) * eW + w);
                     float4 v = make_float4(Y[x][y].x * sc.x + sf.x, Y[x][y].y * sc.y + sf.y, Y[x][y].z * sc.z + sf.z, Y[x][y].w * sc.w + sf.w);
                     if (a.res) {
                         const float4 rr = *reinterpret_cast<const float4*>(a.res + m_ * a.res_cs + a.res_co + nn);
@@ -344,7 +351,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
             }
         }
     }
-    if (!cb) { __syncthreads(); __syncthreads(); }
 }
 
 // U = G g G^T per (cout, cin), G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], computed in double and rounded
