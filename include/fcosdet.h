@@ -180,8 +180,10 @@ int64_t fd_conv_workspace_bytes(int64_t out_rows, int32_t Cout, int32_t ksplit);
 
 /* Weights for FD_TILE_WINOGRAD4: OIHW fp32 [Cout][Cin][3][3] -> U = G g G^T (6x6 per filter, computed in double, rounded once) packed
  * [ceil(Cout/32)][Cin/8][36 frequencies][32 cout][8 cin] (fd_wino4_weight_bytes(Cout, Cin) bytes, zero rows past Cout). */
-int64_t fd_wino4_weight_bytes(int32_t Cout, int32_t Cin);
-int32_t fd_wino4_pack_weights_f32(const float* w, float* out, int32_t Cout, int32_t Cin, fd_stream_t stream);
+int64_t fd_wino4_weight_bytes(int32_t N, int32_t K);
+/* mode 0: forward weights (N = Cout, K = Cin).  mode 1: data-gradient weights (N = Cin, K = Cout: taps flipped, channel roles swapped,
+ * times scale[Cout] when given) -- as fd_wino_pack_weights_f32. */
+int32_t fd_wino4_pack_weights_f32(const float* w, const float* scale, float* out, int32_t Cout, int32_t Cin, int32_t mode, fd_stream_t stream);
 
 /* Weights for FD_TILE_WAVE64: [Cout][Cin] fp32 (an OIHW 1x1 filter bank, Cin % 32 == 0) -> MFMA fragment order
  * [ceil(Cout/64)][Cin/32][2 sub-tiles][4 k-steps][64 lanes][4 floats] (fd_conv_weight_wave_bytes bytes, zero rows past Cout): lane
@@ -241,7 +243,7 @@ typedef struct fd_pack_job {
     const float* w;      /* [Cout][Cin][KH][KW] */
     const float* scale;  /* [Cout] or NULL (mode 1 only) */
     float* out;
-    int32_t Cout, Cin, KH, KW, mode, reserved; /* mode: 0 / 1 (| 4) as fd_pack_conv_weight_f32; 2 / 3 = the Winograd packing of fd_wino_pack_weights_f32 (mode 0 / 1), 3x3 only */
+    int32_t Cout, Cin, KH, KW, mode, reserved; /* mode: 0 / 1 (| 4) as fd_pack_conv_weight_f32; 2 / 3 = the Winograd packing of fd_wino_pack_weights_f32 (mode 0 / 1), 8 / 9 = that of fd_wino4_pack_weights_f32; 3x3 only */
 } fd_pack_job;
 int32_t fd_pack_conv_weights_batch_f32(const fd_pack_job* jobs_dev, int32_t n_jobs, int64_t max_elems, fd_stream_t stream);
 

@@ -94,7 +94,7 @@ _SIGS = {
     "fd_pack_conv_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fd_pack_conv_weights_batch_f32": (_I, [_P, _I, _L, _P]),
     "fd_wino4_weight_bytes": (_L, [_I, _I]),
-    "fd_wino4_pack_weights_f32": (_I, [_P, _P, _I, _I, _P]),
+    "fd_wino4_pack_weights_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fd_conv_weight_wave_bytes": (_L, [_I, _I]),
     "fd_pack_conv_weight_wave_f32": (_I, [_P, _P, _I, _I, _P]),
     "fd_wino_weight_bytes": (_L, [_I, _I]),

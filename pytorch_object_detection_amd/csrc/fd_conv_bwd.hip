@@ -410,6 +410,15 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const fd_pack_jo
         }
         return;
     }
+    if (j.mode == 8 || j.mode == 9) {       // F(4x4, 3x3) packing (fd_conv_wino4.hip): mode 8 = forward, 9 = data-gradient weights
+        const int N = j.mode == 8 ? j.Cout : j.Cin, K = j.mode == 8 ? j.Cin : j.Cout;
+        const long total = (long)((N + 31) & ~31) * K;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int n = (int)(i / K), k = (int)(i - (long)n * K);
+            fd_wino4_pack_one(j.w, j.scale, j.out, N, K, j.mode - 8, n, k);
+        }
+        return;
+    }
     const int taps = j.KH * j.KW;
     const int K = (j.mode & 1) ? j.Cout : j.Cin;
     const long total = (long)j.Cout * j.Cin * taps;

@@ -92,6 +92,39 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + (
 // split-f16 planes: rows of 32 halves (64 B); c8 = 16-byte chunk (8 halves) 0..3, XOR-swizzled by (row>>2)&3
 __device__ __forceinline__ int lds_off_h(int row, int c8) { return row * 32 + ((c8 ^ ((row >> 2) & 3)) << 3); }
 
+// F(4x4, 3x3) weight transform of one (n, k) filter (fd_conv_wino4.hip): U = G g G^T, G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6;
+// 1/24 -1/12 1/6; 0 0 1], computed in double and rounded once; packed [ceil(N / 32)][K / 8][36 f][32 n][8 k] (zero rows past N).
+// mode 0: n = cout, k = cin of w [Cout][Cin][3][3].  mode 1 (data gradient): n = cin, k = cout, taps flipped, times scale[cout].
+__device__ __forceinline__ void fd_wino4_pack_one(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
+                                                  int N, int K, int mode, int n, int k) {
+    const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    double gg[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = 0.0;
+            if (n < N) {
+                if (mode == 0) v = w[((long)n * K + k) * 9 + r * 3 + c];
+                else v = (double)w[((long)k * N + n) * 9 + (2 - r) * 3 + (2 - c)] * (scale ? (double)scale[k] : 1.0);
+            }
+            gg[r][c] = v;
+        }
+    double t[6][3];
+#pragma unroll
+    for (int a_ = 0; a_ < 6; ++a_)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[a_][c] = G[a_][0] * gg[0][c] + G[a_][1] * gg[1][c] + G[a_][2] * gg[2][c];
+    const int nbk = n >> 5, nl = n & 31, cc = k >> 3, kl = k & 7;
+    float* o = out + (((long)nbk * (K >> 3) + cc) * 36) * 256 + nl * 8 + kl;
+#pragma unroll
+    for (int a_ = 0; a_ < 6; ++a_)
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+            o[(a_ * 6 + b) * 256] = (float)(t[a_][0] * G[b][0] + t[a_][1] * G[b][1] + t[a_][2] * G[b][2]);
+}
+
 // Winograd F(2x2, 3x3) weight transform of ONE (n, k) filter: U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], computed in double
 // and rounded once, written to the [ceil(N / 32)][K / 8][16 f][32 n][8 k] packing of fd_conv_wino.hip (frequencies 12..15 negated: the
 // kernel forms patch row 3 of B^T d B with the opposite sign).  mode 0: g = w[n][k] (N = Cout, K = Cin).  mode 1 (data-gradient

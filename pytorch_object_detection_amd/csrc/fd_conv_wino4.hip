@@ -353,46 +353,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     }
 }
 
-// U = G g G^T per (cout, cin), G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], computed in double and rounded
-// once; packed [ceil(Cout / 32)][Cin / 8][36 f][32 cout][8 c] (zero rows past Cout).
-__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
-    const int Np = (Cout + 31) & ~31;
-    const long total = (long)Np * Cin;
-    const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+// U = G g G^T per filter (fd_wino4_pack_one, fd_conv_common.h): one (n, k) filter per thread.
+__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
+                                                         int N, int K, int mode) {
+    const long total = (long)((N + 31) & ~31) * K;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int n = (int)(i / Cin), k = (int)(i - (long)n * Cin);
-        double gg[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gg[r][c] = n < Cout ? (double)w[((long)n * Cin + k) * 9 + r * 3 + c] : 0.0;
-        double t[6][3];
-#pragma unroll
-        for (int a_ = 0; a_ < 6; ++a_)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) t[a_][c] = G[a_][0] * gg[0][c] + G[a_][1] * gg[1][c] + G[a_][2] * gg[2][c];
-        const int nbk = n >> 5, nl = n & 31, cc = k >> 3, kl = k & 7;
-        float* o = out + (((long)nbk * (Cin >> 3) + cc) * 36) * 256 + nl * 8 + kl;
-#pragma unroll
-        for (int a_ = 0; a_ < 6; ++a_)
-#pragma unroll
-            for (int b = 0; b < 6; ++b)
-                o[(a_ * 6 + b) * 256] = (float)(t[a_][0] * G[b][0] + t[a_][1] * G[b][1] + t[a_][2] * G[b][2]);
+        const int n = (int)(i / K), k = (int)(i - (long)n * K);
+        fd_wino4_pack_one(w, scale, out, N, K, mode, n, k);
     }
 }
 
-extern "C" int64_t fd_wino4_weight_bytes(int32_t Cout, int32_t Cin) {
-    if (Cout < 1 || Cin < 8 || Cin % 8) return -1;
-    return (int64_t)((Cout + 31) & ~31) * Cin * 36 * 4;
+extern "C" int64_t fd_wino4_weight_bytes(int32_t N, int32_t K) {
+    if (N < 1 || K < 8 || K % 8) return -1;
+    return (int64_t)((N + 31) & ~31) * K * 36 * 4;
 }
 
-extern "C" int32_t fd_wino4_pack_weights_f32(const float* w, float* out, int32_t Cout, int32_t Cin, fd_stream_t stream) {
-    FD_REQUIRE(w && out && Cout >= 1 && Cin >= 8 && Cin % 8 == 0, FD_E_INVAL, "fd_wino4_pack_weights: need Cin %% 8 == 0 (Cout=%d Cin=%d)", Cout, Cin);
-    const long total = (long)((Cout + 31) & ~31) * Cin;
+extern "C" int32_t fd_wino4_pack_weights_f32(const float* w, const float* scale, float* out, int32_t Cout, int32_t Cin, int32_t mode, fd_stream_t stream) {
+    FD_REQUIRE(w && out && Cout >= 1 && Cin >= 1 && (mode == 0 || mode == 1), FD_E_INVAL, "fd_wino4_pack_weights: bad arguments");
+    const int N = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+    FD_REQUIRE(K % 8 == 0, FD_E_UNSUPPORTED, "fd_wino4_pack_weights: the reduction width (%d) must be a multiple of 8", K);
+    const long total = (long)((N + 31) & ~31) * K;
     long gsz = (total + 255) / 256;
     if (gsz > 8192) gsz = 8192;
-    hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin);
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, w, scale, out, N, K, mode);
     FD_CHECK_LAUNCH("fd_wino4_pack_weights_f32");
     return FD_OK;
 }

@@ -440,16 +440,21 @@ def pack_conv_weight_wino(w: torch.Tensor, scale: Optional[torch.Tensor] = None,
     return out
 
 
-def pack_conv_weight_wino4(w: torch.Tensor) -> torch.Tensor:
-    """OIHW [Cout, Cin, 3, 3] -> the Winograd F(4x4, 3x3) operand of FD_TILE_WINOGRAD4 (fd_wino4_pack_weights_f32), one HIP launch."""
+def pack_conv_weight_wino4(w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False) -> torch.Tensor:
+    """OIHW [Cout, Cin, 3, 3] -> the Winograd F(4x4, 3x3) operand of FD_TILE_WINOGRAD4 (fd_wino4_pack_weights_f32), one HIP launch;
+    dgrad=True: the flipped / transposed weights of the data-gradient conv (N = Cin, K = Cout) times an optional per-Cout scale."""
     w = w.detach().float().contiguous()
-    _need_gpu(w)
+    _need_gpu(w, scale)
     co, ci, kh, kw = w.shape
-    nbytes = _lib.lib().fd_wino4_weight_bytes(co, ci)
-    if kh != 3 or kw != 3 or nbytes < 0:
-        raise FdError(f"Winograd F(4x4,3x3) weights need a 3x3 filter with Cin % 8 == 0 (got {tuple(w.shape)})")
+    if kh != 3 or kw != 3:
+        raise FdError("Winograd weights need a 3x3 filter")
+    n, k = (ci, co) if dgrad else (co, ci)
+    nbytes = _lib.lib().fd_wino4_weight_bytes(n, k)
+    if nbytes < 0:
+        raise FdError(f"Winograd weights need a reduction width that is a multiple of 8 (got {k})")
     out = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
-    check(_lib.lib().fd_wino4_pack_weights_f32(w.data_ptr(), out.data_ptr(), co, ci, _stream()), "fd_wino4_pack_weights_f32")
+    check(_lib.lib().fd_wino4_pack_weights_f32(w.data_ptr(), scale.data_ptr() if (scale is not None and dgrad) else None,
+                                               out.data_ptr(), co, ci, 1 if dgrad else 0, _stream()), "fd_wino4_pack_weights_f32")
     return out
 
 

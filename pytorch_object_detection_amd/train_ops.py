@@ -195,8 +195,9 @@ class _PackCache:
         self.table = None           # (signature, device tensor of fd_pack_job, max_elems)
 
     @staticmethod
-    def _key(w, scale, dgrad, wino=False, f16=False):
-        return (w.data_ptr(), tuple(w.shape), bool(dgrad), scale.data_ptr() if (scale is not None and dgrad) else 0, (2 if f16 else 0) + (1 if wino else 0))
+    def _key(w, scale, dgrad, wino=0, f16=False):       # wino: 0 = direct kernel's packing, 1 = Winograd F(2x2, 3x3), 2 = Winograd F(4x4, 3x3)
+        return (w.data_ptr(), tuple(w.shape), bool(dgrad), scale.data_ptr() if (scale is not None and dgrad) else 0,
+                (2 if f16 else 0) + (1 if int(wino) == 1 else 0) + (8 if int(wino) == 2 else 0))
 
     @staticmethod
     def _pack_now(w, scale, dgrad, wino, f16=False):
@@ -204,13 +205,14 @@ class _PackCache:
             out = ops.pack_conv_weight_hip(w, scale, dgrad, f16)
             out._fd_prec = _lib.PREC_F16 if f16 else _lib.PREC_F32
             return out
-        out = ops.pack_conv_weight_wino(w, scale, dgrad)
+        out = ops.pack_conv_weight_wino4(w, scale, dgrad) if int(wino) == 2 else ops.pack_conv_weight_wino(w, scale, dgrad)
         out._fd_wino = (w.shape[1] if dgrad else w.shape[0])       # marks the Winograd packing for _conv_launch (value = output channels)
+        out._fd_wino_tile = _lib.WINO4_TILE if int(wino) == 2 else _lib.WINO_TILE
         return out
 
-    def get(self, w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False, wino: bool = False, f16: bool = False) -> torch.Tensor:
-        """Packed weights for the conv kernel: the direct kernel's layout, or (wino=True, 3x3 stride-1 'same' layers) the Winograd
-        F(2x2, 3x3) packing of fd_conv_wino.hip; dgrad=True = the flipped / transposed / BN-scaled weights of the data gradient."""
+    def get(self, w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False, wino: int = 0, f16: bool = False) -> torch.Tensor:
+        """Packed weights for the conv kernel: the direct kernel's layout, or (3x3 stride-1 'same' layers) the Winograd packing -- wino=1: F(2x2, 3x3)
+        of fd_conv_wino.hip, wino=2: F(4x4, 3x3) of fd_conv_wino4.hip; dgrad=True = the flipped / transposed / BN-scaled weights of the data gradient."""
         import weakref
         if isinstance(w, nn.Parameter) and w.is_contiguous():
             self.params[w.data_ptr()] = weakref.ref(w)
@@ -230,7 +232,10 @@ class _PackCache:
         if e[4] != w._version:                                            # changed since the last refresh: re-pack in place
             co, ci, kh, kw = w.shape
             sp = scale.data_ptr() if (scale is not None and dgrad) else None
-            if wino:
+            if int(wino) == 2:
+                ops.check(_lib.lib().fd_wino4_pack_weights_f32(w.data_ptr(), sp, e[3].data_ptr(), co, ci, 1 if dgrad else 0, ops._stream()),
+                          "fd_wino4_pack_weights_f32")
+            elif wino:
                 ops.check(_lib.lib().fd_wino_pack_weights_f32(w.data_ptr(), sp, e[3].data_ptr(), co, ci, 1 if dgrad else 0, ops._stream()),
                           "fd_wino_pack_weights_f32")
             else:
@@ -262,7 +267,8 @@ class _PackCache:
             for j, (key, e) in zip(jobs, live.items()):
                 co, ci, kh, kw = key[1]
                 j.w, j.scale, j.out = key[0], (e[1].data_ptr() if (e[1] is not None and e[2]) else None), e[3].data_ptr()
-                j.Cout, j.Cin, j.KH, j.KW, j.mode = co, ci, kh, kw, (2 if key[4] & 1 else 0) + (1 if e[2] else 0) + (4 if key[4] & 2 else 0)
+                j.Cout, j.Cin, j.KH, j.KW, j.mode = co, ci, kh, kw, ((8 if key[4] & 8 else 2 if key[4] & 1 else 0) + (1 if e[2] else 0)
+                                                                     + (4 if key[4] & 2 else 0))
                 mx = max(mx, co * ci * kh * kw)
             raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).clone()
             dev = next(iter(live.values()))[3].device
@@ -276,12 +282,17 @@ class _PackCache:
 PACKS = _PackCache()
 
 
-def _wino(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int, segs: Segs, prec: int = 0) -> bool:
-    """3x3 stride-1 'same' layers run on the Winograd kernel -- forward (Cin -> Cout) and, with the channel roles swapped, data
+def _wino(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int, segs: Segs, prec: int = 0) -> int:
+    """3x3 stride-1 'same' layers run on a Winograd kernel -- forward (Cin -> Cout) and, with the channel roles swapped, data
     gradient -- unless FD_WINOGRAD=0 (the switch of the inference plans) or the map is so small that the direct kernel's split-K
-    wins (ops.wino_preferred, the rule of the inference plans)."""
+    wins (ops.wino_preferred, the rule of the inference plans).  Returns PACKS.get's `wino`: 0 = direct, 1 = F(2x2, 3x3), 2 = F(4x4, 3x3)
+    (ops.wino4_choice, the rule of the inference plans)."""
     from . import engine
-    return prec == 0 and engine.WINOGRAD and ops.wino_ok(Cin, Cout, k, stride, pad, dil) and ops.wino_preferred(segs, Cin, Cout, dil)
+    if prec != 0 or not engine.WINOGRAD:
+        return 0
+    if ops.wino4_ok(Cin, Cout, k, stride, pad, dil) and ops.wino4_choice(segs, Cin, Cout, dil):
+        return 2
+    return 1 if (ops.wino_ok(Cin, Cout, k, stride, pad, dil) and ops.wino_preferred(segs, Cin, Cout, dil)) else 0
 
 _TILE_CACHE: dict = {}
 
@@ -294,7 +305,7 @@ def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.T
     wino_cout = getattr(w_packed, "_fd_wino", 0)
     if wino_cout:        # the Winograd packing (PACKS.get(..., wino=True)): fd_conv_wino.hip, no tile choice
         ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=x.shape[1], Cout=wino_cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
-                      shift=shift, res=_r(res) if res is not None else None, act=act, res_mask=res_mask, tile=_lib.WINO_TILE)()
+                      shift=shift, res=_r(res) if res is not None else None, act=act, res_mask=res_mask, tile=getattr(w_packed, "_fd_wino_tile", _lib.WINO_TILE))()
         return
     Cin, Cout = x.shape[1], w_packed.shape[0]
     out_rows = y.shape[0]

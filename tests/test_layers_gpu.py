@@ -1211,3 +1211,26 @@ def test_conv3x3_winograd_f4x4(case):
     assert torch.equal(yb.nan_to_num(7.0), first.nan_to_num(7.0))          # bitwise reproducible
     with pytest.raises(Exception, match="WINOGRAD4"):     # dilation 3: a clean error, no launch
         ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=3, dil=3, tile=_lib.WINO4_TILE)()
+
+
+def test_winograd_f4x4_data_gradient_packing():
+    """ops.pack_conv_weight_wino4(dgrad=True): the data gradient of a 3x3 stride-1 conv as a FD_TILE_WINOGRAD4 launch on dY with the flipped /
+    transposed weights times the per-Cout scale of a folded BatchNorm (what train_ops.PACKS hands _conv_launch), against conv_transpose2d."""
+    from pytorch_object_detection_amd import _lib
+    gen = torch.Generator().manual_seed(77)
+    B, Cin, Cout, hw = 2, 64, 96, [(19, 14), (6, 5)]
+    wt = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    sc = torch.rand(Cout, generator=gen) + 0.5
+    dys = [torch.randn(B, Cout, h, w, generator=gen) for h, w in hw]
+    segs = Segs.make(B, hw)
+    dyb = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cout) for t in dys]).contiguous().to(DEV)
+    dxb = torch.full((segs.rows, Cin), float("nan"), device=DEV)
+    wp = ops.pack_conv_weight_wino4(wt.to(DEV), sc.to(DEV), dgrad=True)
+    ops.conv_call(ops.Rows(dyb), segs, wp, ops.Rows(dxb), Cin=Cout, Cout=Cin, k=3, pad=1, dil=1, tile=_lib.WINO4_TILE)()
+    got = dxb.cpu()
+    for i, ((h, w), dy) in enumerate(zip(hw, dys)):
+        ref = F.conv_transpose2d(dy.double() * sc.double()[None, :, None, None], wt.double(), None, 1, 1).float()
+        g = got[segs.m_start[i]:segs.m_start[i + 1]].reshape(B, h, w, Cin).permute(0, 3, 1, 2)
+        scale = float(ref.abs().max()) + 1.0
+        err = (g - ref).abs()
+        assert float(err.max()) < 4e-5 * scale and float(err.mean()) < 2e-6 * scale, (i, float(err.max()), float(err.mean()))

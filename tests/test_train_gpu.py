@@ -15,15 +15,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("wino", [False, True], ids=["direct", "winograd"])
+@pytest.mark.parametrize("wino", [False, True, 4], ids=["direct", "winograd", "winograd-f4x4"])
 def test_train_step_matches_oracle_autograd(wino, monkeypatch):
     """wino=False: every dense conv on the direct kernel (bit-for-bit an fp32 fma chain).  wino=True (the default, FD_WINOGRAD=1): the
     3x3 stride-1 layers -- forward and data gradient -- on the Winograd F(2x2, 3x3) kernel (fp32 too, another rounding).  Same bars.
     Measured on MI355X (tools/train_dev_stats.py, this seed): Winograd path -- all 145 gradients within 5e-6 of their maximum; direct
     path -- 128 of 145 at rounding level, 17 (biases upstream of one flipped ReLU mask element) with a median deviation of 1e-4 .. 3e-4."""
     from pytorch_object_detection_amd import engine, ops
-    monkeypatch.setattr(engine, "WINOGRAD", wino)
-    monkeypatch.setattr(ops, "WINO_FORCE", wino)       # (at 128 x 128 the size rule would send every layer to the direct kernel)
+    monkeypatch.setattr(engine, "WINOGRAD", bool(wino))
+    monkeypatch.setattr(ops, "WINO_FORCE", bool(wino))       # (at 128 x 128 the size rule would send every layer to the direct kernel)
+    # wino=4: forward and data gradient of every 3x3 stride-1 layer on Winograd F(4x4, 3x3) (the choice of the batch-16 training step for its wide
+    # maps, ops.wino4_choice, forced onto these small ones; its flipped / transposed / BN-scaled data-gradient packing comes from PACKS)
+    monkeypatch.setattr(ops, "WINO4_MODE", "force" if wino == 4 else "0")
     torch.manual_seed(0)
     model = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256)
     gen = torch.Generator().manual_seed(1)
