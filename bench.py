@@ -113,7 +113,10 @@ def tower_roofline(plan, tower_flops: int, tower_ms: float) -> dict:
                             "executed on the matrix pipe = direct-convolution FLOPs / 2.25 (Winograd F(2x2,3x3))" if wino
                             else "executed = algorithmic (direct convolution)"),
             "flops_per_launch": executed_flops, "algorithmic_flops_per_launch": tower_flops, "avg_launch_ms": round(tower_ms, 4),
-            "effective_tflops": round(effective, 2), "effective_over_peak": round(effective / PEAK_F32_MFMA_TFLOPS, 4)}
+            "effective_tflops": round(effective, 2), "effective_over_peak": round(effective / PEAK_F32_MFMA_TFLOPS, 4),
+            "note": ("F(4x4,3x3) executes 1.78x fewer MFMAs than the F(2x2,3x3) launch it replaced (FD_WINOGRAD4=0: 1.27 ms, frac 0.72) and is 1.30x faster: "
+                     "`frac` (matrix-pipe utilisation) fell because each MFMA now has 1.78x the input-transform work beside it on a power-capped chip; the "
+                     "layer's delivered rate is `effective_tflops` (DESIGN 4.1d, profiles/r03z_wino4_breakdown.txt)") if wino4 else None}
 
 
 def family_rooflines(plan, x, reps: int = 5) -> dict:
