@@ -147,14 +147,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     // scratch: S[lt][q][j'][i] float4 -- R writes element (j', i = pr) for j' = 0..5; C reads (j' = pr, i = 0..5): 6 consecutive float4
     const int s_wr = ((lt * 2 + q) * W4_SBLK + pr) * 4;          // + j' * 24 floats
     const int s_rd = ((lt * 2 + q) * W4_SBLK + pr * 6) * 4;      // + i * 4 floats
-    // V[f = 6 i' + j'][tile][8 c]: tile rows XORed with j' (the six planes of one write instruction differ in j'), 16-byte halves with tile bit 4
-    const int v_wr = (pr * W4_TB + (lt ^ pr)) * W4_KC + 4 * (q ^ ((lt >> 4) & 1));      // + i' * 6 * W4_PLANE
+    // V[f = 6 i' + j'][tile][8 c], plain: with one patch line per wave both the writes (64 lanes = one plane) and the MFMA reads are conflict-free
+    const int v_wr = (pr * W4_TB + lt) * W4_KC + 4 * q;          // + i' * 6 * W4_PLANE.  (A wave's 64 lanes = the 64 float4s of one plane: no bank is hit twice.)
 
     // ---- MFMA role ----
     const int nb = (n0 >> 5) + ch;
     const bool nb_ok = nb * 32 < ((a.Cout + 31) & ~31);
     const unsigned u_off0 = nb_ok ? ((unsigned)(nb * a.NC) * 36u + 9u * g) * 1024u + (unsigned)(l31 * 32 + lh * 16) : OOB;
-    const int v_half = 4 * (lh ^ ((l31 >> 4) & 1));
+    const int v_half = 4 * lh;
 
     f32x16 acc[9];
 #pragma unroll
@@ -208,26 +208,28 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     // The loop exists twice, for the loader waves and for the two waves without a loader role: s_waitcnt counts are in-order counts, and where the
     // two paths joined after every slice the compiler had to assume the shorter queue -- the loader waves then waited for their own slice's LDS
     // traffic before every MFMA group.
-    auto main_loop = [&](auto ldr_c) {
+    auto main_loop = [&](auto ldr_c, auto mm_c) {
     constexpr bool LDR = decltype(ldr_c)::value;
+    constexpr bool MM = decltype(mm_c)::value;         // false: this wave's 32-cout block lies past Cout (Cout % 64 in 1..32): no U loads, no MFMAs, only its loader role
     for (int cc = 0; cc < NC; ++cc) {
         const int st = cc & 1;
         const float* Vb = Vs + st * W4_STAGE + (9 * g) * W4_PLANE + v_half;
         const int cn = min(cc + 1, NC - 1);
         float4 fa[2];
-        fa[0] = *reinterpret_cast<const float4*>(Vb + (0 * W4_TB + (l31 ^ ((9 * g + 0) % 6))) * W4_KC);
+        if constexpr (MM) fa[0] = *reinterpret_cast<const float4*>(Vb + (0 * W4_TB + l31) * W4_KC);
         __builtin_amdgcn_s_setprio(1);
-        if (!(a.dbg & 2))
 #pragma unroll
         for (int fi = 0; fi < 9; ++fi) {
-            if (fi + 1 < 9) fa[(fi + 1) & 1] = *reinterpret_cast<const float4*>(Vb + ((fi + 1) * W4_TB + (l31 ^ ((9 * g + fi + 1) % 6))) * W4_KC);
-            __builtin_amdgcn_sched_barrier(0);                         // the next group's V fragment is requested BEFORE this group's MFMAs go out
-            const float4 va = fa[fi & 1], fb = bq[fi];
-            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.x, fb.x, acc[fi], 0, 0, 0);
-            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.y, fb.y, acc[fi], 0, 0, 0);
-            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.z, fb.z, acc[fi], 0, 0, 0);
-            acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, fb.w, acc[fi], 0, 0, 0);
-            load_u(cn, fi);                                            // next chunk's block into the registers just consumed
+            if constexpr (MM) {
+                if (fi + 1 < 9) fa[(fi + 1) & 1] = *reinterpret_cast<const float4*>(Vb + ((fi + 1) * W4_TB + l31) * W4_KC);
+                __builtin_amdgcn_sched_barrier(0);                     // the next group's V fragment is requested BEFORE this group's MFMAs go out
+                const float4 va = fa[fi & 1], fb = bq[fi];
+                acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.x, fb.x, acc[fi], 0, 0, 0);
+                acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.y, fb.y, acc[fi], 0, 0, 0);
+                acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.z, fb.z, acc[fi], 0, 0, 0);
+                acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, fb.w, acc[fi], 0, 0, 0);
+                load_u(cn, fi);                                        // next chunk's block into the registers just consumed
+            }
             if constexpr (LDR) {
                 if (fi == 0) w4_bt_inplace(pv);
                 if (fi == 1) {
@@ -254,8 +256,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
         __syncthreads();
     }
     };
-    if (ldr) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
+    const bool mm = __builtin_amdgcn_readfirstlane((int)nb_ok) != 0 && !(a.dbg & 2);
+    if (ldr) { if (mm) main_loop(std::true_type{}, std::true_type{}); else main_loop(std::true_type{}, std::false_type{}); }
+    else     { if (mm) main_loop(std::false_type{}, std::true_type{}); else main_loop(std::false_type{}, std::false_type{}); }
 
     // ---- epilogue: two halves of the 32 tiles in turn through the (now free) LDS, both channel blocks and all eight waves at once ----
     // Accumulator rows 0..15 are registers e = 0..7 of every f32x16, rows 16..31 registers 8..15: half h is dead in the register file once written, so
