@@ -70,7 +70,8 @@ __device__ __forceinline__ Tile4 wino4_decode(const Wino4Args& a, int t) {
 
 // B^T d for one line of six (per component of a float4): t = B^T d,
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-// in place: six inputs -> six outputs per component, four temporaries
+// in place: six inputs -> six outputs per component, four temporaries.  (Tried: the same on float2 halves with inline constants only --
+// 4 d0 - 5 d2 + d4 as 4 (d0 - d2) + (d4 - d2) -- 26 fewer VALU operations, no faster, one more rounding per output: dropped.)
 __device__ __forceinline__ void w4_bt_inplace(float4 (&d)[6]) {
 #define W4_BT1(c)                                                              \
     {                                                                          \
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
         for (int i = 0; i < 6; ++i) *reinterpret_cast<float4*>(d + i * 6 * W4_PLANE) = v[i];
     };
     auto load_u = [&](int cc, int fi) {
-        bq[fi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (int)(u_off0 == OOB ? OOB : u_off0 + ((unsigned)cc * 36u + fi) * 1024u), 0, 0));
+        // per-lane part in the vector offset (OOB for a block past Cout: zeros), the chunk / frequency part in the scalar offset: no VALU per load
+        bq[fi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (int)u_off0, (cc * 36 + fi) * 1024, 0));
     };
 
     const int NC = a.NC;

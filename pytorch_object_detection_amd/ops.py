@@ -466,6 +466,7 @@ def wino4_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bo
 # FD_WINOGRAD4: "1" (default) = layers the F(4x4, 3x3) kernel covers run on it where wino4_choice's cost model says it beats F(2x2, 3x3);
 # "0" = never (the round-2 plans); "force" = wherever it applies (tests exercise the kernel inside whole models this way)
 WINO4_MODE = os.environ.get("FD_WINOGRAD4", "1")
+_W4_FIXED_US = float(os.environ.get("FD_WINOGRAD4_FIXED_US", "12"))       # the cost model's per-workgroup prologue + epilogue term (experiments)
 
 
 def wino4_tiles(segs: Segs, dil: int = 1) -> int:
@@ -476,15 +477,16 @@ def wino4_tiles(segs: Segs, dil: int = 1) -> int:
 def wino4_choice(segs: Segs, Cin: int, Cout: int, dil: int = 1) -> bool:
     """F(4x4, 3x3) instead of F(2x2, 3x3)?  One F(4x4) workgroup owns 32 tiles x 64 couts and a whole CU (144 KB of LDS, 2 x 256-register
     waves per SIMD), so its time goes in ROUNDS of 256 workgroups:
-      t_w4 = ceil(workgroups / 256) * (3.0 us * Cin / 8 + 20 us)
-    (fitted to the in-plan step times of profiles/r03w_layer_times_w4.tsv at batch 16: head tower 0.98 ms in 9 rounds, layer3.conv2 0.128 in 1,
-    layer2.conv2 0.157 in 2; layer1.conv2 -- 0.206 ms in 4 rounds of 8 chunks, against 0.18 ms -- is where the fixed prologue + epilogue cost loses).  It has no split-K and no row-statistics epilogue: maps with few tiles (batch 1, layer4) stay on F(2x2) / direct."""
+      t_w4 = ceil(workgroups / 256) * (3.0 us * Cin / 8 + 12 us)
+    (fitted to the in-plan step times of profiles/r03y_layer_times_w4*.tsv at batch 16: head tower 0.94 ms in 9 rounds, layer3.conv2 0.118 in 1,
+    layer2.conv2 0.150 in 2, layer1.conv2 0.179 in 4 -- against 0.182 on F(2x2): the break-even case).  It has no split-K and no row-statistics
+    epilogue: maps with few tiles (batch 1, layer4: 104 workgroups for 256 CUs) stay on F(2x2) / direct."""
     if WINO4_MODE == "0":
         return False
     if WINO4_MODE == "force":
         return True
     wgs = -(-wino4_tiles(segs, dil) // 32) * -(-Cout // 64)
-    t4 = -(-wgs // 256) * (3.0 * (Cin // 8) + 20.0)
+    t4 = -(-wgs // 256) * (3.0 * (Cin // 8) + _W4_FIXED_US)
     return t4 < 0.95 * _wino_times(segs, Cin, Cout, dil, True)[0]
 
 
