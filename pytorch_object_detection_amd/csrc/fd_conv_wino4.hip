@@ -124,7 +124,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     const int tile0 = mt * W4_TB, n0 = nt * 64;
 
     constexpr unsigned OOB = 0xC0000000u;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
+    // The input resource starts ONE patch pixel before the tensor: the six columns of a patch row are then column j = 1's byte offset (per lane, or OOB)
+    // plus the non-negative scalar offset j * px_b + chunk -- no VALU per load.  (Nothing below a.x is touched: column 0 of a row at w0 = 0 is masked.)
+    const int px_b = a.x_cs * 4 * a.dil;                         // bytes between neighbouring patch pixels of one row
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x - px_b), (short)0, (int)(a.x_bytes + (unsigned)px_b), 0x00020000);
     const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, (int)a.u_bytes, 0x00020000);
 
     // ---- loader role (threads 0 .. 383): (tile lt, line pr, channel quad q); pr = patch row i in G / R, column j' in C ----
@@ -132,19 +135,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     // one line pr per WAVE, (tile, quad) per lane: every scratch / V instruction of a wave then walks 64 different blocks at one in-block offset
     const int q = tid & 1, lt = (tid >> 1) & 31, pr = min(tid >> 6, 5);
     // patch row pr of tile lt: one base offset per thread; the six columns differ by a uniform pixel stride (buffer soffset) and a validity bit each
-    unsigned a_base;
-    bool a_ok[6];
+    unsigned a_off[6];                                           // a_base where the column is inside the image, OOB elsewhere
     {
         const Tile4 p = wino4_decode(a, tile0 + lt);
         const int H = a.H[p.s], W = a.W[p.s];
         const int hh = (p.h0 - 1 + pr) * a.dil + p.ph;           // (negative exactly when the sub-grid row is)
         const bool row_ok = ldr && p.ok && (unsigned)hh < (unsigned)H;
         const int rowbase = a.m0[p.s] + (p.n * H + hh) * W;
-        a_base = ((unsigned)(rowbase + p.w0 * a.dil + p.pw) * (unsigned)a.x_cs + (unsigned)(a.x_co + q * 4)) * 4u;    // column j = 1; j adds (j - 1) * dil pixels
+        const unsigned a_base = ((unsigned)(rowbase + p.w0 * a.dil + p.pw) * (unsigned)a.x_cs + (unsigned)(a.x_co + q * 4)) * 4u;    // column j = 1
 #pragma unroll
-        for (int j = 0; j < 6; ++j) a_ok[j] = row_ok && (unsigned)((p.w0 - 1 + j) * a.dil + p.pw) < (unsigned)W;
+        for (int j = 0; j < 6; ++j) a_off[j] = (row_ok && (unsigned)((p.w0 - 1 + j) * a.dil + p.pw) < (unsigned)W) ? a_base : OOB;
     }
-    const int px_b = a.x_cs * 4 * a.dil;                         // bytes between neighbouring patch pixels of one row
     // scratch: S[lt][q][j'][i] float4 -- R writes element (j', i = pr) for j' = 0..5; C reads (j' = pr, i = 0..5): 6 consecutive float4
     const int s_wr = ((lt * 2 + q) * W4_SBLK + pr) * 4;          // + j' * 24 floats
     const int s_rd = ((lt * 2 + q) * W4_SBLK + pr * 6) * 4;      // + i * 4 floats
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
         const int cb = cc * 32;
 #pragma unroll
         for (int j = 0; j < 6; ++j)
-            pv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(a_ok[j] ? a_base + (unsigned)((j - 1) * px_b + cb) : OOB), 0, 0));
+            pv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)a_off[j], j * px_b + cb, 0));
     };
     auto stage_R = [&](int st) {                 // row pass (along the patch row) -> scratch
         float4 t[6];
