@@ -477,7 +477,7 @@ def wino4_tiles(segs: Segs, dil: int = 1) -> int:
 def wino4_choice(segs: Segs, Cin: int, Cout: int, dil: int = 1) -> bool:
     """F(4x4, 3x3) instead of F(2x2, 3x3)?  One F(4x4) workgroup owns 32 tiles x 64 couts and a whole CU (144 KB of LDS, 2 x 256-register
     waves per SIMD), so its time goes in ROUNDS of 256 workgroups:
-      t_w4 = ceil(workgroups / 256) * (3.0 us * Cin / 8 + 12 us)
+      t_w4 = ceil(workgroups / 256) * ((1.0 + 2.0 * live) us * Cin / 8 + 12 us)      live = the fraction of the workgroups' 32-cout blocks below Cout
     (fitted to the in-plan step times of profiles/r03y_layer_times_w4*.tsv at batch 16: head tower 0.94 ms in 9 rounds, layer3.conv2 0.118 in 1,
     layer2.conv2 0.150 in 2, layer1.conv2 0.179 in 4 -- against 0.182 on F(2x2): the break-even case).  It has no split-K and no row-statistics
     epilogue: maps with few tiles (batch 1, layer4: 104 workgroups for 256 CUs) stay on F(2x2) / direct."""
@@ -486,7 +486,9 @@ def wino4_choice(segs: Segs, Cin: int, Cout: int, dil: int = 1) -> bool:
     if WINO4_MODE == "force":
         return True
     wgs = -(-wino4_tiles(segs, dil) // 32) * -(-Cout // 64)
-    t4 = -(-wgs // 256) * (3.0 * (Cin // 8) + _W4_FIXED_US)
+    # a workgroup's two 32-cout blocks: the waves of a block past Cout skip their MFMAs (Cout = 80: 3 of 4 blocks live, Cout = 8: 1 of 2)
+    live = -(-Cout // 32) / (2.0 * -(-Cout // 64))
+    t4 = -(-wgs // 256) * ((1.0 + 2.0 * live) * (Cin // 8) + _W4_FIXED_US)
     return t4 < 0.95 * _wino_times(segs, Cin, Cout, dil, True)[0]
 
 
