@@ -112,7 +112,7 @@ const char* fd_last_error(void);
                                workgroup, no barrier in the K loop (fd_conv_wave.hip) -- needs fd_conv_params.w_frag (fd_pack_conv_weight_wave_f32) */
 #define FD_TILE_WINOGRAD4 16 /* 3x3 stride-1 'same' convs (dilation 1 or 2), fp32: Winograd F(4x4, 3x3) on the fp32 MFMA -- 36 multiplies per 4x4 output tile and
                                 channel pair (2.25 per output: 1.78x fewer than F(2x2), 4x fewer than direct); needs the fd_wino4_pack_weights_f32 packing in `w`;
-                                no split-K / gate / gn_stats.  Rounding error ~2x F(2x2)'s, inside the 1e-4 parity bar */
+                                ksplit as FD_TILE_WINOGRAD; no gate / gn_stats.  Rounding error ~2x F(2x2)'s, inside the 1e-4 parity bar */
 #define FD_TILE_COUNT 16
 
 typedef struct fd_conv_params {

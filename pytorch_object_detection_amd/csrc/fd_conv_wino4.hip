@@ -29,6 +29,8 @@ struct Wino4Args {
     int x_cs, x_co, res_cs, res_co, y_cs, y_co;
     int Cin, Cout, act, act_c0, res_mask;
     int NC;                       // 8-channel chunks
+    int nc_per;                   // chunks per split-K slice (blockIdx.y = slice; NC when split-K is off)
+    long slice_stride;            // floats between the slices' raw partial outputs in the workspace (split-K), else 0
     int dil;                      // 1, or 2: four parity classes (ph, pw) per image, each a dense conv on the sub-grid h = 2 hs + ph, w = 2 ws + pw
     int nseg;
     int H[FD_MAX_SEG], W[FD_MAX_SEG], TH[FD_MAX_SEG], TW[FD_MAX_SEG];   // TH x TW tiles of 4 x 4 outputs
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     if (cnt <= 0 || idx >= cnt * a.ntiles) return;
     const int nt = idx / cnt, mt = mt_lo + (idx - nt * cnt);
     const int tile0 = mt * W4_TB, n0 = nt * 64;
+    const int c0 = blockIdx.y * a.nc_per;                        // split-K: first chunk of this slice
 
     constexpr unsigned OOB = 0xC0000000u;
     // The input resource starts ONE patch pixel before the tensor: the six columns of a patch row are then column j = 1's byte offset (per lane, or OOB)
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
 
     float4 pv[6], bq[9];
     auto stage_G = [&](int cc) {                 // global -> registers
-        const int cb = cc * 32;
+        const int cb = (c0 + cc) * 32;
 #pragma unroll
         for (int j = 0; j < 6; ++j)
             pv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)a_off[j], j * px_b + cb, 0));
@@ -190,10 +193,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     };
     auto load_u = [&](int cc, int fi) {
         // per-lane part in the vector offset (OOB for a block past Cout: zeros), the chunk / frequency part in the scalar offset: no VALU per load
-        bq[fi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (int)u_off0, (cc * 36 + fi) * 1024, 0));
+        bq[fi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (int)u_off0, ((c0 + cc) * 36 + fi) * 1024, 0));
     };
 
-    const int NC = a.NC;
+    const int NC = min(a.NC, c0 + a.nc_per) - c0;               // this slice's chunks [c0, c0 + NC)
     // ---- prologue: G(0) R(0) | G(1) C(0) R(1) | G(2): V[0] holds chunk 0, scratch[1] chunk 1's row pass, registers chunk 2 ----
     if (ldr) { stage_G(0); stage_R(0); }
     __syncthreads();
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                         if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, eprm);
                         if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, eprm);
                     }
-                    *reinterpret_cast<float4*>(a.y + m_ * a.y_cs + a.y_co + nn) = v;
+                    *reinterpret_cast<float4*>(a.y + (size_t)blockIdx.y * a.slice_stride + m_ * a.y_cs + a.y_co + nn) = v;
                 }
             }
         }
@@ -388,8 +391,8 @@ extern "C" int32_t fd_wino4_pack_weights_f32(const float* w, const float* scale,
 
 int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
     FD_REQUIRE(p->KH == 3 && p->KW == 3 && p->stride == 1 && (p->dil == 1 || p->dil == 2) && p->pad == p->dil && p->Cin % 8 == 0 && p->Cout % 4 == 0 &&
-                   p->precision == FD_PREC_F32 && p->ksplit <= 1 && p->out_H <= 0 && p->sc_H <= 0 && !p->gate && !p->gn_stats,
-               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD4 needs an fp32 3x3 stride-1 'same' conv of dilation 1 or 2 with Cin %% 8 == 0, Cout %% 4 == 0, no split-K / scatter / gate / gn_stats");
+                   p->precision == FD_PREC_F32 && p->out_H <= 0 && p->sc_H <= 0 && !p->gate && !p->gn_stats,
+               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD4 needs an fp32 3x3 stride-1 'same' conv of dilation 1 or 2 with Cin %% 8 == 0, Cout %% 4 == 0, no scatter / gate / gn_stats");
     FD_REQUIRE(p->x_cs % 4 == 0 && p->x_co % 4 == 0 && p->y_cs % 4 == 0 && p->y_co % 4 == 0 && ((uintptr_t)p->y & 15) == 0 &&
                    (!p->res || (p->res_cs % 4 == 0 && p->res_co % 4 == 0 && ((uintptr_t)p->res & 15) == 0)) &&
                    (!p->scale || ((uintptr_t)p->scale & 15) == 0) && (!p->shift || ((uintptr_t)p->shift & 15) == 0),
@@ -429,7 +432,39 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
     a.ntiles = (p->Cout + 63) / 64;
     a.mt_per = (a.mtiles + 7) / 8;
     constexpr int lds = (2 * W4_STAGE + 2 * W4_SSTAGE) * 4;        // 146 KB
-    const dim3 grid((unsigned)(8 * a.mt_per * a.ntiles));
+    a.nc_per = a.NC; a.slice_stride = 0;
+    const int ksplit = p->ksplit > 1 ? p->ksplit : 1;
+    ConvArgs o = {};
+    int ldw = 0; long slab = 0;
+    if (ksplit > 1) {
+        // split-K (maps with too few tiles to fill 256 CUs, e.g. layer4's 20 x 20): the chunk loop is divided over `ksplit` workgroups per tile, raw
+        // partial outputs (the output transform is linear) go to the workspace, the direct kernel's combine launch adds the slabs in slice order and
+        // applies the epilogue (deterministic) -- as FD_TILE_WINOGRAD
+        FD_REQUIRE(ksplit <= 64 && a.NC >= 2 * ksplit, FD_E_INVAL, "fd_conv2d: ksplit=%d needs 1 < ksplit <= min(64, Cin / 16 = %d)", ksplit, a.NC / 2);
+        ldw = (p->Cout + 3) & ~3;
+        slab = rows * ldw;
+        FD_REQUIRE(p->workspace && ((uintptr_t)p->workspace & 15) == 0 && p->workspace_bytes >= (int64_t)ksplit * slab * 4, FD_E_INVAL,
+                   "fd_conv2d: split-K needs a 16-byte aligned workspace of fd_conv_workspace_bytes() bytes");
+        a.nc_per = (a.NC + ksplit - 1) / ksplit;
+        o.scale = p->scale; o.shift = p->shift; o.res = p->res; o.y = p->y;
+        o.res_cs = p->res_cs; o.res_co = p->res_co; o.y_cs = p->y_cs; o.y_co = p->y_co;
+        o.Cout = p->Cout; o.act = p->act; o.act_c0 = p->act_c0; o.M = (int)rows; o.nseg = p->in.nseg;
+        o.res_mask = (p->res && p->res_mode == 1) ? 1 : 0;
+        for (int sg = 0; sg <= FD_MAX_SEG; ++sg) o.m_out[sg] = p->in.m_start[sg < p->in.nseg ? sg : p->in.nseg];
+        for (int sg = 0; sg < FD_MAX_SEG; ++sg) { o.seg_param[sg] = p->seg_param[sg]; o.Ho[sg] = o.Wo[sg] = 1; }
+        o.sc_on = 0;
+        a.y = (float*)p->workspace; a.y_cs = ldw; a.y_co = 0; a.slice_stride = slab;
+        a.scale = a.shift = a.res = nullptr; a.act = FD_ACT_NONE; a.res_mask = 0;
+    }
+    const int nslice = (a.NC + a.nc_per - 1) / a.nc_per;
+    const dim3 grid((unsigned)(8 * a.mt_per * a.ntiles), (unsigned)nslice);
+    if (ksplit > 1) {
+        static std::atomic<unsigned> ms{0};
+        fd_set_max_lds_once(ms, reinterpret_cast<const void*>(conv3x3_wino4_kernel<0>), lds);
+        hipLaunchKernelGGL(conv3x3_wino4_kernel<0>, grid, dim3(512), lds, stream, a);
+        FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (Winograd F(4x4,3x3), split-K)");
+        return fd_launch_splitk_reduce(o, (const float*)p->workspace, nslice, ldw, slab, stream);
+    }
     if (p->tag == 1) {
         static std::atomic<unsigned> m1{0};
         fd_set_max_lds_once(m1, reinterpret_cast<const void*>(conv3x3_wino4_kernel<1>), lds);

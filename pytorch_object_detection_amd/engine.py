@@ -201,11 +201,13 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
             (res is None or (res.cs % 4 == 0 and res.co % 4 == 0))):
         wino, wino_ks = ops.wino_choice(segs, Cin, co, dil)
         wino = wino or tag == 1                   # (the head tower -- the roofline kernel -- always runs the Winograd kernel)
-    # F(4x4, 3x3) where its cost model beats F(2x2, 3x3): exact-fp32 plans only, dilation 1, no split-K / gate / statistics epilogue
-    wino4 = (plan.winograd and gate is None and gn_stats is None and ops.wino4_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0
-             and (res is None or (res.cs % 4 == 0 and res.co % 4 == 0)) and ops.wino4_choice(segs, Cin, co, dil))
+    # F(4x4, 3x3) where its cost model beats F(2x2, 3x3) / the direct kernel: exact-fp32 plans only, no gate / statistics epilogue
+    wino4, w4_ks = False, 1
+    if (plan.winograd and gate is None and gn_stats is None and ops.wino4_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0
+            and (res is None or (res.cs % 4 == 0 and res.co % 4 == 0))):
+        wino4, w4_ks = ops.wino4_choice(segs, Cin, co, dil)
     if wino4:
-        wino, wino_ks = True, 1
+        wino, wino_ks = True, w4_ks
         wp = ops.pack_conv_weight_wino4(_dev(w, dev))
     elif wino:
         wp = ops.pack_conv_weight_wino(_dev(w, dev))
@@ -246,7 +248,7 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     if ws is not None:
         plan.pool.put(ws)
     if wino:
-        plan.tiles[name] = _lib.WINO4_TILE if wino4 else (_lib.WINO_TILE | ((wino_ks if wino_ks > 1 else 0) << 8))
+        plan.tiles[name] = (_lib.WINO4_TILE if wino4 else _lib.WINO_TILE) | ((wino_ks if wino_ks > 1 else 0) << 8)
     elif gate is not None:
         plan.tiles[name] = 0                 # (the library picks the tile of a gated conv)
     elif plan.autotune:

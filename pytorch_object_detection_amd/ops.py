@@ -474,22 +474,29 @@ def wino4_tiles(segs: Segs, dil: int = 1) -> int:
     return sum(segs.batch * dil * dil * (-(-(-(-h // dil)) // 4)) * (-(-(-(-w // dil)) // 4)) for h, w in segs.level_hw())
 
 
-def wino4_choice(segs: Segs, Cin: int, Cout: int, dil: int = 1) -> bool:
-    """F(4x4, 3x3) instead of F(2x2, 3x3)?  One F(4x4) workgroup owns 32 tiles x 64 couts and a whole CU (144 KB of LDS, 2 x 256-register
-    waves per SIMD), so its time goes in ROUNDS of 256 workgroups:
-      t_w4 = ceil(workgroups / 256) * ((1.0 + 2.0 * live) us * Cin / 8 + 12 us)      live = the fraction of the workgroups' 32-cout blocks below Cout
-    (fitted to the in-plan step times of profiles/r03y_layer_times_w4*.tsv at batch 16: head tower 0.94 ms in 9 rounds, layer3.conv2 0.118 in 1,
-    layer2.conv2 0.150 in 2, layer1.conv2 0.179 in 4 -- against 0.182 on F(2x2): the break-even case).  It has no split-K and no row-statistics
-    epilogue: maps with few tiles (batch 1, layer4: 104 workgroups for 256 CUs) stay on F(2x2) / direct."""
+def wino4_choice(segs: Segs, Cin: int, Cout: int, dil: int = 1, allow_split: bool = True) -> Tuple[bool, int]:
+    """(F(4x4, 3x3) instead of F(2x2, 3x3) / the direct kernel?, its split-K factor).  One F(4x4) workgroup owns 32 tiles x 64 couts and a whole CU
+    (146 KB of LDS, 2 x 256-register waves per SIMD), so its time goes in ROUNDS of 256 workgroups:
+      t_w4(ks) = ceil(ks * workgroups / 256) * ((1.0 + 2.0 * live) us * Cin / 8 / ks + 12 us)  [+ 10 us for the combine launch, ks > 1]
+    live = the fraction of the workgroups' 32-cout blocks below Cout (the waves of a dead block skip their MFMAs).  Fitted to the in-plan step
+    times of profiles/r03y_layer_times_w4*.tsv at batch 16: head tower 0.94 ms in 9 rounds, layer3.conv2 0.118 in 1, layer2.conv2 0.150 in 2,
+    layer1.conv2 0.179 in 4 -- against 0.182 on F(2x2): the break-even case.  Split-K (layer4's 20 x 20 maps: 104 workgroups for 256 CUs) halves
+    the chunk loop per workgroup where that fills the chip; there is no row-statistics epilogue (add_conv keeps those launches on F(2x2))."""
     if WINO4_MODE == "0":
-        return False
+        return False, 1
     if WINO4_MODE == "force":
-        return True
+        return True, 1
     wgs = -(-wino4_tiles(segs, dil) // 32) * -(-Cout // 64)
-    # a workgroup's two 32-cout blocks: the waves of a block past Cout skip their MFMAs (Cout = 80: 3 of 4 blocks live, Cout = 8: 1 of 2)
     live = -(-Cout // 32) / (2.0 * -(-Cout // 64))
-    t4 = -(-wgs // 256) * ((1.0 + 2.0 * live) * (Cin // 8) + _W4_FIXED_US)
-    return t4 < 0.95 * _wino_times(segs, Cin, Cout, dil, True)[0]
+    nc = Cin // 8
+    best_t, best_ks = None, 1
+    for ks in ((1, 2, 4) if allow_split else (1,)):
+        if ks > 1 and nc < 8 * ks:
+            break
+        t = -(-wgs * ks // 256) * ((1.0 + 2.0 * live) * nc / ks + _W4_FIXED_US) + (10.0 if ks > 1 else 0.0)
+        if best_t is None or t < best_t * 0.9:
+            best_t, best_ks = t, ks
+    return best_t < 0.95 * _wino_times(segs, Cin, Cout, dil, allow_split)[0], best_ks
 
 
 def wino_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bool:

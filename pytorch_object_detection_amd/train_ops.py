@@ -290,7 +290,7 @@ def _wino(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int, segs: Se
     from . import engine
     if prec != 0 or not engine.WINOGRAD:
         return 0
-    if ops.wino4_ok(Cin, Cout, k, stride, pad, dil) and ops.wino4_choice(segs, Cin, Cout, dil):
+    if ops.wino4_ok(Cin, Cout, k, stride, pad, dil) and ops.wino4_choice(segs, Cin, Cout, dil, allow_split=False)[0]:      # (no workspace here)
         return 2
     return 1 if (ops.wino_ok(Cin, Cout, k, stride, pad, dil) and ops.wino_preferred(segs, Cin, Cout, dil)) else 0
 

@@ -1209,6 +1209,16 @@ def test_conv3x3_winograd_f4x4(case):
     first = yb.clone()
     run()
     assert torch.equal(yb.nan_to_num(7.0), first.nan_to_num(7.0))          # bitwise reproducible
+    if Cin >= 32:        # split-K (maps with few tiles): raw partial outputs per slice -> workspace -> the combine launch applies the epilogue
+        ws = torch.empty(2 * segs.rows * ((Cout + 3) & ~3), dtype=torch.float32, device=DEV)
+        yb2 = torch.full((segs.rows, Cout + 8), float("nan"), device=DEV)
+        ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(yb2, 4, Cout), Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, scale=sc.to(DEV), shift=sf.to(DEV),
+                      res=ops.Rows(rb) if use_res else None, act=act, act_c0=4 if act == ACT_EXP else 0, seg_param=prm if act == ACT_EXP else None,
+                      tile=_lib.WINO4_TILE, ksplit=2, workspace=ws)()
+        a2, a1 = yb2[:, 4:4 + Cout].cpu(), first[:, 4:4 + Cout].cpu()
+        assert torch.isnan(yb2[:, :4]).all() and not torch.isnan(a2).any()
+        tol = 2e-5 * (float(a1.abs().max()) + 1.0)
+        assert float((a2 - a1).abs().max()) < tol, float((a2 - a1).abs().max())       # same products, another summation order
     with pytest.raises(Exception, match="WINOGRAD4"):     # dilation 3: a clean error, no launch
         ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=3, dil=3, tile=_lib.WINO4_TILE)()
 
