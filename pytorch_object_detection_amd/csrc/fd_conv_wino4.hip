@@ -168,15 +168,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
     float4 pv[6], bq[9];
-    auto stage_G = [&](int cc) {                 // global -> registers
+    auto load_G = [&](float4 (&dst)[6], int cc) {                 // global -> registers
         const int cb = (c0 + cc) * 32;
 #pragma unroll
         for (int j = 0; j < 6; ++j)
-            pv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)a_off[j], j * px_b + cb, 0));
+            dst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)a_off[j], j * px_b + cb, 0));
     };
-    auto stage_R = [&](int st) {                 // row pass (along the patch row) -> scratch
+    auto stage_G = [&](int cc) { load_G(pv, cc); };
+    auto row_pass = [&](const float4 (&src)[6], int st) {          // row pass (along the patch row) -> scratch
         float4 t[6];
-        w4_bt(pv, t);
+        w4_bt(src, t);
         float* d = Ss + st * W4_SSTAGE + s_wr;
 #pragma unroll
         for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(d + j * 24) = t[j];
@@ -197,12 +198,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     };
 
     const int NC = min(a.NC, c0 + a.nc_per) - c0;               // this slice's chunks [c0, c0 + NC)
-    // ---- prologue: G(0) R(0) | G(1) C(0) R(1) | G(2): V[0] holds chunk 0, scratch[1] chunk 1's row pass, registers chunk 2 ----
-    if (ldr) { stage_G(0); stage_R(0); }
-    __syncthreads();
-    if (ldr) { stage_G(min(1, NC - 1)); stage_C(0); stage_R(1); stage_G(min(2, NC - 1)); }
+    // ---- prologue: the patch rows of chunks 0, 1, 2 are requested together (ONE global round trip, not three: the accumulators are not live yet,
+    // registers are plenty), then R(0) R(1) | C(0): V[0] holds chunk 0, scratch[1] chunk 1's row pass, the patch registers chunk 2 ----
+    {
+        float4 p0[6], p1[6];
+        if (ldr) { load_G(p0, 0); load_G(p1, min(1, NC - 1)); stage_G(min(2, NC - 1)); }
 #pragma unroll
-    for (int fi = 0; fi < 9; ++fi) load_u(0, fi);
+        for (int fi = 0; fi < 9; ++fi) load_u(0, fi);
+        if (ldr) { row_pass(p0, 0); row_pass(p1, 1); }
+    }
+    __syncthreads();
+    if (ldr) stage_C(0);
     __syncthreads();
 
     // Main loop: one 8-channel chunk per iteration and workgroup barrier.  The loader stages of the NEXT chunks are cut into slices that sit between
