@@ -235,6 +235,42 @@ def test_uint8_input_matches_normalised_float_input():
         assert torch.equal(u, v)
 
 
+def test_full_size_batch16_f4x4_plan_matches_f2x2_plan(monkeypatch):
+    """BASELINE configs[1] at full size: the batch-16 plan as shipped (Winograd F(4x4, 3x3) on the layers its cost model picks -- the head tower, cls_logits,
+    cnt_reg, the wide trunk / FPN layers incl. the dilated ones, layer4 with split-K) against the same model with FD_WINOGRAD4=0 (every 3x3 stride-1 layer
+    on F(2x2) / the direct kernel: the plan the per-layer and oracle tests of rounds 1-2 pinned).  Conv tolerance of the parity tests; same detections."""
+    from pytorch_object_detection_amd import ops as _ops
+    torch.manual_seed(31)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 80, 256).eval()
+    randomize_norms(model, 32)
+    model.to(DEV)
+    x = torch.randn(16, 3, 640, 640, device=DEV)
+    head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
+    def plan_tiles():
+        built = next(iter(model._plans.values()))[1]
+        for obj in (built if isinstance(built, tuple) else (built,)):
+            if hasattr(obj, "tiles") and hasattr(obj, "steps"):
+                return dict(obj.tiles)
+        raise AssertionError("no engine.Plan in the model's plan cache")
+    out4 = [[t.clone() for t in grp] for grp in model(x)]
+    tiles = plan_tiles()
+    on4 = [n for n, t in tiles.items() if (t & 0xFF) == 16]
+    assert "head.tower3x3" in on4 and len(on4) >= 12, on4                       # the shipped rule really put F(4x4) on the wide layers
+    assert any((tiles[n] >> 8) > 1 for n in on4), "no split-K F(4x4) launch in the batch-16 plan"
+    d4 = head.detect_padded([[t.clone() for t in grp] for grp in out4])
+    monkeypatch.setattr(_ops, "WINO4_MODE", "0")
+    model.invalidate_plans()
+    out2 = model(x)
+    tiles2 = plan_tiles()
+    assert not any((t & 0xFF) == 16 for t in tiles2.values())
+    for g4, g2 in zip(out4, out2):
+        for a, b in zip(g4, g2):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), **TOL)
+    d2 = head.detect_padded(out2)
+    n4, n2 = d4[3].cpu().numpy(), d2[3].cpu().numpy()
+    assert np.abs(n4 - n2).max() <= 2, (n4, n2)       # (a candidate at the 0.05 score threshold may fall on either side of it)
+
+
 def test_full_size_batch16_is_per_image_independent():
     """BASELINE configs[1] at full size (B=16, 640x640, 80 classes) through a size-independent property: every image of
     the batch gives the outputs and detections it gives alone (frozen BN, per-sample GroupNorm / SE, per-image
