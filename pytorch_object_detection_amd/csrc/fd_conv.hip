@@ -18,7 +18,7 @@
 // GNS: the epilogue also writes the row-group statistics of the stored output (fd_conv_params.gn_stats; one- and two-sub-tile tiles only).
 // H1 (with SPLIT): single-plane f16 -- operands rounded to f16 once, ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation: the
 // arithmetic of torch.autocast(float16) convolutions (FD_PREC_F16; the reference trains under AMP, train.py:33,175-181).
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT, bool GATE = false, bool GNS = false, bool H1 = false>
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT, bool GATE = false, bool GNS = false, bool H1 = false, bool GEMM = false>
 __global__ __launch_bounds__(WGM * WGN * 64, (TM * TN == 4) ? ((SPLIT || WGM * WGN == 8) ? 2 : (SB ? 3 : 1)) : 1)
 void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -70,6 +70,11 @@ void conv_igemm_kernel(ConvArgs a) {
             const int img = sg * a.gate_batch + (mm - a.m_out[sg]) / (a.Ho[sg] * a.Wo[sg]);
             g_row[i] = a.gate + (size_t)img * a.gate_cs + chunk * 4;
         }
+        if constexpr (GEMM) {   // compiled for 1x1 stride-1 unpadded layers with Cin % 32 == 0: a row's only address is its own, the K-tile goes in the scalar offset
+            a_off[i] = (m < a.M) ? ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) * 4u : OOB;
+            a_wcs[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = 1; a_W[i] = 1;
+            continue;
+        }
         if (a.is_gemm) {  // 1x1, stride 1, no padding: the input row IS the output row (no divisions)
             a_off[i] = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) * 4u;
             a_wcs[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = (m < a.M) ? 1 : 0; a_W[i] = 1;
@@ -106,6 +111,14 @@ void conv_igemm_kernel(ConvArgs a) {
     // consecutive kt, so (chunk, filter row, filter column) advance as counters (no divisions in the K loop).
     int ld_cc = 0, ld_r = 0, ld_q = 0;
     auto load_tile = [&](int kt) {
+        if constexpr (GEMM) {      // no per-row arithmetic: lane offsets fixed, K-tile kt = 128 bytes further along every row (scalar offset)
+            const int kb = kt * 128;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)a_off[i], kb, 0));
+#pragma unroll
+            for (int j = 0; j < BP; ++j) rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)b_off[j], kb, 0));
+            return;
+        }
         int dr, dq;          // tap displacement in input rows / columns
         unsigned dbytes;     // uniform byte displacement: column shift + channel chunk
         bool c_ok = true;    // Cin % 32 != 0 (EfficientNet widths: 24, 40, 48, 136, 144, 232 ...): the last chunk's missing
@@ -328,7 +341,7 @@ int fd_launch_splitk_reduce(const ConvArgs& orig, const float* ws, int nslice, i
     return FD_OK;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false, bool GATE = false, bool GNS = false, bool H1 = false>
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false, bool GATE = false, bool GNS = false, bool H1 = false, bool GEMM = false>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int lds_ab = (SB ? 1 : 2) * (BM + BN) * 32 * 4;
@@ -338,7 +351,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT, GATE, GNS, H1>;
+    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT, GATE, GNS, H1, GEMM>;
     static std::atomic<unsigned> attr_mask{0};       // per kernel instantiation, one bit per device
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles, (a.KT + a.kt_per - 1) / a.kt_per), dim3(NT), lds, stream, b);
@@ -580,6 +593,19 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
         if (pw && a.is_gemm && a.kt_per == a.KT && !a.gate) {
             const int rc = fd_launch_conv_pw(a, p->tile, stream);
             if (rc != FD_E_UNSUPPORTED) return rc;
+        }
+    }
+    // GEMM-addressed fp32 layers (1x1, stride 1, no padding, Cin % 32 == 0, no gate): the loader compiled without the tap / bounds arithmetic
+    static const int gemm_on = getenv("FD_CONV_GEMM") ? atoi(getenv("FD_CONV_GEMM")) : 1;
+    if (gemm_on && a.is_gemm && p->Cin % 32 == 0 && !a.gate && !a.sc_on) {
+        switch (p->tile) {
+            case FD_TILE_128x64: return launch_conv<2, 2, 2, 1, false, false, 0, false, false, false, false, true>(a, stream);
+            case FD_TILE_64x128: return launch_conv<2, 2, 1, 2, false, false, 0, false, false, false, false, true>(a, stream);
+            case FD_TILE_64x64: return launch_conv<2, 2, 1, 1, false, false, 0, false, false, false, false, true>(a, stream);
+            case FD_TILE_128x128_SB: return launch_conv<2, 2, 2, 2, false, true, 0, false, false, false, false, true>(a, stream);
+            case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true, 0, false, false, false, false, true>(a, stream);
+            case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true, 0, false, false, false, false, true>(a, stream);
+            default: break;
         }
     }
     switch (p->tile) {
