@@ -113,6 +113,13 @@ void conv_igemm_kernel(ConvArgs a) {
     auto load_tile = [&](int kt) {
         if constexpr (GEMM) {      // no per-row arithmetic: lane offsets fixed, K-tile kt = 128 bytes further along every row (scalar offset)
             const int kb = kt * 128;
+            if (GATE) {
+#pragma unroll
+                for (int i = 0; i < AP; ++i) {
+                    rg[i] = *reinterpret_cast<const float4*>(g_row[i] + kt * 32);
+                    if (a.gate_b) rgb[i] = *reinterpret_cast<const float4*>(g_row[i] + gate_bo + kt * 32);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < AP; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)a_off[i], kb, 0));
 #pragma unroll
@@ -467,7 +474,10 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
         a.gate = p->gate; a.gate_cs = p->gate_cs; a.gate_hw = p->in.H[0] * p->in.W[0];
         a.gate_b = p->gate_b; a.gate_act = p->gate_b ? p->gate_act : FD_ACT_NONE;
         // the GroupNorm-fused form (HISFCOSHead pw2): single-LDS-buffer tiles at three workgroups per CU, as the tuned table picks for the plain layer
-        if (p->gate_b && a.Cout > 64 && (long)((a.M + 63) / 64) * ((a.Cout + 127) / 128) >= 512) return launch_conv<2, 2, 1, 2, false, true, 0, false, true>(a, stream);   // 64 x 128 SB
+        if (p->gate_b && a.Cout > 64 && (long)((a.M + 63) / 64) * ((a.Cout + 127) / 128) >= 512) {   // 64 x 128 SB
+            if (p->Cin % 32 == 0 && !a.sc_on) return launch_conv<2, 2, 1, 2, false, true, 0, false, true, false, false, true>(a, stream);      // (GEMM-addressed loader)
+            return launch_conv<2, 2, 1, 2, false, true, 0, false, true>(a, stream);
+        }
         if (a.Cout <= 32) return launch_conv<4, 1, 1, 1, false, false, 0, false, true>(a, stream);      // 128 x 32
         const long m128 = (a.M + 127) / 128;
         if (a.Cout <= 64) {
@@ -579,6 +589,13 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
         }
     }
     if (a.gn_stats) {   // row-group statistics in the epilogue: dedicated instantiations of the one- / two-sub-tile tiles
+        if (a.is_gemm && p->Cin % 32 == 0 && !a.sc_on) {     // (GEMM-addressed loader for the tiles the fused head uses)
+            switch (p->tile) {
+                case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true, 0, false, false, true, false, true>(a, stream);
+                case FD_TILE_AUTO: case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true, 0, false, false, true, false, true>(a, stream);
+                default: break;
+            }
+        }
         switch (p->tile) {
             case FD_TILE_64x64: return launch_conv<2, 2, 1, 1, false, false, 0, false, false, true>(a, stream);
             case FD_TILE_128x64: return launch_conv<2, 2, 2, 1, false, false, 0, false, false, true>(a, stream);
@@ -599,6 +616,7 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
     static const int gemm_on = getenv("FD_CONV_GEMM") ? atoi(getenv("FD_CONV_GEMM")) : 1;
     if (gemm_on && a.is_gemm && p->Cin % 32 == 0 && !a.gate && !a.sc_on) {
         switch (p->tile) {
+            case FD_TILE_128x128: return launch_conv<2, 2, 2, 2, false, false, 0, false, false, false, false, true>(a, stream);
             case FD_TILE_128x64: return launch_conv<2, 2, 2, 1, false, false, 0, false, false, false, false, true>(a, stream);
             case FD_TILE_64x128: return launch_conv<2, 2, 1, 2, false, false, 0, false, false, false, false, true>(a, stream);
             case FD_TILE_64x64: return launch_conv<2, 2, 1, 1, false, false, 0, false, false, false, false, true>(a, stream);

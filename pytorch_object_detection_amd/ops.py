@@ -225,7 +225,7 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
 
 
 _TUNE_CACHE: dict = {}
-_TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_tiles.json")
+_TUNE_FILE = os.environ.get("FD_TILE_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_tiles.json")   # (FD_TILE_TABLE: A/B of two tables)
 # FD_AUTOTUNE: "0" (default) = committed table, misses use the shape heuristic (no first-call latency);
 #              "1" = time the misses on the spot; "force" = re-time everything (bench.py --save-tuning writes the table)
 _TUNE_MODE = os.environ.get("FD_AUTOTUNE", "0")
