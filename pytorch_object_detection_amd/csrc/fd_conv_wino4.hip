@@ -1,4 +1,4 @@
-// fd_conv_wino4.hip -- 3x3 stride-1 'same' convolution (dilation 1) as Winograd F(4x4, 3x3) on the fp32 MFMA of gfx950 (FD_TILE_WINOGRAD4).
+// fd_conv_wino4.hip -- 3x3 stride-1 'same' convolution (dilation 1 or 2) as Winograd F(4x4, 3x3) on the fp32 MFMA of gfx950 (FD_TILE_WINOGRAD4).
 //
 // F(2x2, 3x3) (fd_conv_wino.hip) already runs its MFMA loop at the matrix pipe's full rate: in exact fp32 the only lever left is executing
 // fewer multiplies again.  F(4x4, 3x3) computes a 4x4 output tile from a 6x6 input patch with 36 multiplies per (cin, cout) -- 2.25 per
@@ -8,19 +8,25 @@
 // multiply by 4, 5, 8 as well, which costs a factor ~2 in rounding error against F(2x2): the whole 640 x 640 model stays within 2e-5 * (1 + |x|)
 // of its fp64 evaluation (tools/wino44_emul.py), inside the 1e-4 parity bar.
 //
-// One workgroup (8 waves, one per CU) = 32 tiles (512 output pixels) x 64 output channels x all 36 frequencies:
-//   * wave (g, ch) owns frequencies 9 g .. 9 g + 8 and output channels 32 ch .. + 31: 9 accumulators of 32 x 32 (144 VGPRs);
-//   * the input transform is a three-stage software pipeline over 8-channel chunks, ONE workgroup barrier per chunk:
-//       G(c)  thread (tile, patch row i, channel quad) fetches its 6 pixels (6 x 16-byte raw buffer loads, zero outside the image);
-//       R(c)  row pass of B^T d B in registers, written to an LDS scratch [tile][quad][j'][i];
+// One workgroup (8 waves at 256 registers, one workgroup per CU) = 32 tiles (512 output pixels) x 64 output channels x all 36 frequencies:
+//   * wave (g, ch) owns frequencies 9 g .. 9 g + 8 and output channels 32 ch .. + 31: 9 accumulators of 32 x 32 (144 VGPRs); the four waves of a
+//     channel block that lies past Cout keep their loader role and skip the MFMAs;
+//   * the input transform is a three-stage software pipeline over 8-channel chunks, ONE workgroup barrier per chunk, its stages cut into slices that
+//     sit between the nine MFMA groups of the chunk (loader waves 0 .. 5: one patch line per WAVE, (tile, channel quad) per lane):
+//       G(c)  fetches the 6 pixels of its patch row (6 x 16-byte raw buffer loads, zero outside the image);
+//       R(c)  row pass of B^T d B in registers, written to an LDS scratch [tile][quad] blocks of [j'][i] (+ 1 float4 of padding: conflict-free);
 //       C(c)  the same thread, now (tile, quad, column j'), reads its column of 6, does the column pass and writes V[f = 6 i' + j'][tile][8 c];
 //       M(c)  the MFMAs.   Iteration cc runs M(cc), C(cc+1), R(cc+2), G(cc+3).
-//     LDS: V 2 x 36 KB + scratch 2 x 36 KB = 144 KB; the epilogue reuses all of it for the 36 x 32 x 32 frequency planes of one channel block;
+//     LDS: V 2 x 36 KB + scratch 2 x 37 KB = 146 KB; the epilogue reuses it for the frequency planes;
 //   * U goes global -> registers in MFMA layout (packed [cout/32][chunk][36 f][32 cout][8 c], 1 KB per frequency block), the block of chunk
-//     cc+1 into the registers the MFMAs of chunk cc have just consumed;
+//     cc+1 into the registers the MFMAs of chunk cc have just consumed; every global / LDS address is a per-lane register set up once plus a scalar
+//     or immediate offset per instruction (no address arithmetic on the VALU inside the loop);
+//   * dilation 2 = four parity classes per image (address arithmetic only); split-K = blockIdx.y slices of the chunk loop, raw partial outputs to the
+//     workspace, the direct kernel's combine launch finishes (fd_launch_splitk_reduce);
 //   * epilogue: the two halves of the 32 tiles in turn -- all waves put that half of their accumulators into LDS planes, then every thread gathers the
 //     36 frequencies of (tile, 4 couts), applies A^T . A for two of the four output rows and y = act(v * scale + shift (+ | mask) res) and stores
 //     16 bytes per pixel.
+// DESIGN 4.1d has the measurements (head tower 1.39 -> 0.92 ms against F(2x2)) and what did and did not matter on the way there.
 #include "fd_conv_common.h"
 #include <type_traits>
 
