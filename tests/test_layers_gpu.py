@@ -1244,3 +1244,46 @@ def test_winograd_f4x4_data_gradient_packing():
         scale = float(ref.abs().max()) + 1.0
         err = (g - ref).abs()
         assert float(err.max()) < 4e-5 * scale and float(err.mean()) < 2e-6 * scale, (i, float(err.max()), float(err.mean()))
+
+
+def test_winograd_f4x4_random_shapes_against_the_direct_kernel():
+    """Seeded random layer shapes (ragged pyramids, maps smaller than a tile, dilation 1 / 2, Cin any multiple of 8, Cout any multiple of 4 incl. widths whose
+    last 32-cout block is dead, split-K with an uneven last slice, residual add / ReLU mask, channel views inside wider buffers): FD_TILE_WINOGRAD4 against the
+    direct implicit-GEMM kernel (an fp32 fma chain pinned against the oracle elsewhere) on identical inputs."""
+    from pytorch_object_detection_amd import _lib
+    import random
+    rng = random.Random(20261004)
+    gen = torch.Generator().manual_seed(99)
+    for case in range(24):
+        Cin = 8 * rng.randint(1, 20)
+        Cout = 4 * rng.randint(1, 40)
+        dil = rng.choice((1, 1, 2))
+        nlev = rng.randint(1, 4)
+        hw = [(rng.randint(1, 23), rng.randint(1, 23)) for _ in range(nlev)]
+        B = rng.randint(1, 3)
+        use_res, res_mask = rng.random() < 0.4, rng.random() < 0.3
+        act = rng.choice((ACT_NONE, ACT_RELU, ACT_SILU))
+        ks = rng.choice((1, 1, 2, 3)) if Cin >= 48 else 1
+        xo, yo = 4 * rng.randint(0, 2), 4 * rng.randint(0, 2)
+        segs = Segs.make(B, hw)
+        xb = torch.full((segs.rows, Cin + xo + 4), float("nan"), device=DEV)
+        xb[:, xo:xo + Cin] = torch.randn(segs.rows, Cin, generator=gen).to(DEV)
+        wt = (torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5).to(DEV)
+        sc, sf = (torch.rand(Cout, generator=gen) + 0.5).to(DEV), (torch.randn(Cout, generator=gen) * 0.1).to(DEV)
+        rb = torch.randn(segs.rows, Cout, generator=gen).to(DEV)
+        outs = []
+        for tile, wp in ((_lib.WINO4_TILE, ops.pack_conv_weight_wino4(wt)), (0, ops.pack_conv_weight(wt))):
+            yb = torch.full((segs.rows, Cout + yo + 4), float("nan"), device=DEV)
+            ws = torch.empty(max(ks, 1) * segs.rows * ((Cout + 3) & ~3), dtype=torch.float32, device=DEV) if (ks > 1 and tile) else None
+            ops.conv_call(ops.Rows(xb, xo, Cin), segs, wp, ops.Rows(yb, yo, Cout), Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, scale=sc, shift=sf,
+                          res=ops.Rows(rb) if use_res else None, res_mask=use_res and res_mask, act=act, tile=tile,
+                          ksplit=ks if (ks > 1 and tile and Cin // 8 >= 2 * ks) else 1, workspace=ws)()
+            assert torch.isnan(yb[:, :yo]).all() and torch.isnan(yb[:, yo + Cout:]).all(), (case, "wrote outside its channel view")
+            outs.append(yb[:, yo:yo + Cout].cpu())
+        a, b = outs
+        assert not torch.isnan(a).any(), (case, "an output was never written")
+        scale = float(b.abs().max()) + 1.0
+        if use_res and res_mask:          # (a ReLU-mask residual exactly at 0 decides by sign only: identical inputs, identical masks)
+            pass
+        err = (a - b).abs()
+        assert float(err.max()) < 6e-5 * scale, (case, Cin, Cout, dil, hw, B, ks, float(err.max()), scale)
