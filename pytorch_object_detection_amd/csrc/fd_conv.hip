@@ -70,10 +70,12 @@ void conv_igemm_kernel(ConvArgs a) {
             const int img = sg * a.gate_batch + (mm - a.m_out[sg]) / (a.Ho[sg] * a.Wo[sg]);
             g_row[i] = a.gate + (size_t)img * a.gate_cs + chunk * 4;
         }
-        if constexpr (GEMM) {   // compiled for 1x1 stride-1 unpadded layers with Cin % 32 == 0: a row's only address is its own, the K-tile goes in the scalar offset
-            a_off[i] = (m < a.M) ? ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) * 4u : OOB;
-            a_wcs[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = 1; a_W[i] = 1;
-            continue;
+        if constexpr (GEMM) {   // compiled for 1x1 unpadded layers with Cin % 32 == 0: a row has ONE input address, the K-tile goes in the scalar offset
+            if (a.is_gemm) {    // stride 1: the input row is the output row
+                a_off[i] = (m < a.M) ? ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) * 4u : OOB;
+                a_wcs[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = 1; a_W[i] = 1;
+                continue;
+            }                   // strided 1x1 (the ResNet downsample convs): the decode below gives the row's address once; rows past M read zeros
         }
         if (a.is_gemm) {  // 1x1, stride 1, no padding: the input row IS the output row (no divisions)
             a_off[i] = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) * 4u;
@@ -97,6 +99,7 @@ void conv_igemm_kernel(ConvArgs a) {
         a_wcs[i] = W * a.x_cs * 4;   // bytes per input image row
         a_off[i] = ((unsigned)(a.m_in[s] + n * H * W + a_hi0[i] * W + a_wi0[i]) * (unsigned)a.x_cs +
                     (unsigned)(a.x_co + chunk * 4)) * 4u;
+        if constexpr (GEMM) { if (m >= a.M) a_off[i] = OOB; }
     }
     unsigned b_off[BP];
 #pragma unroll
@@ -614,7 +617,8 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
     }
     // GEMM-addressed fp32 layers (1x1, stride 1, no padding, Cin % 32 == 0, no gate): the loader compiled without the tap / bounds arithmetic
     static const int gemm_on = getenv("FD_CONV_GEMM") ? atoi(getenv("FD_CONV_GEMM")) : 1;
-    if (gemm_on && a.is_gemm && p->Cin % 32 == 0 && !a.gate && !a.sc_on) {
+    const bool pointwise = !stem && p->KH == 1 && p->KW == 1 && p->pad == 0;     // any stride: one input address per output row
+    if (gemm_on && pointwise && p->Cin % 32 == 0 && !a.gate && !a.sc_on) {
         switch (p->tile) {
             case FD_TILE_128x128: return launch_conv<2, 2, 2, 2, false, false, 0, false, false, false, false, true>(a, stream);
             case FD_TILE_128x64: return launch_conv<2, 2, 2, 1, false, false, 0, false, false, false, false, true>(a, stream);
