@@ -415,6 +415,10 @@ int32_t fd_dwconv3x3_gn_nhwc(const float* x, int32_t x_cs, int32_t x_co, const f
  * statistics (momentum update with the unbiased variance, as nn.BatchNorm2d). rows = batch*H*W. */
 int32_t fd_batchnorm_update_running(const void* gn_workspace, int64_t rows, int32_t C, float momentum, float eps,
                                     float* running_mean, float* running_var, fd_stream_t stream);
+/* The same with the row count in DEVICE memory (one double): nn.SyncBatchNorm's global count is the result of an all-reduce and differs
+ * per step when the ranks' batches are padded to different H x W (dataset/voc.py:141-171); reading it here costs no host synchronisation. */
+int32_t fd_batchnorm_update_running_dev(const void* gn_workspace, const double* count_dev, int32_t C, float momentum, float eps,
+                                        float* running_mean, float* running_var, fd_stream_t stream);
 
 /* nn.SyncBatchNorm in TRAINING mode (train.py:101-103: SyncBatchNorm.convert_sync_batchnorm after the DDP wrap; SURVEY 2.1 collective C3):
  * batch statistics over ALL ranks' rows.  Forward and backward are each cut in two around ONE all-reduce that the CALLER issues
@@ -426,7 +430,11 @@ int32_t fd_batchnorm_update_running(const void* gn_workspace, int64_t rows, int3
  *   backward  phase 1: sums[c], sums[C+c] = this rank's sum dz, sum dz * xhat (dz = dy * act'); dgamma / dbeta from THESE local sums
  *                      (DDP averages them with the other gradients, as torch's SyncBatchNorm does)               -> all-reduce(sums)
  *             phase 2: dx = rstd * (gamma * dz - mean_global(gamma dz) - xhat * mean_global(gamma dz xhat))
- *   `workspace` of the backward: fd_groupnorm_bwd_workspace_bytes of the same segment table.  rows = this rank's batch*H*W. */
+ *   `workspace` of the backward: fd_groupnorm_bwd_workspace_bytes of the same segment table.  rows = this rank's batch*H*W.
+ *   total_rows (phase 2): the GLOBAL row count as a host value, or <= 0: it is read on the device from sums[2C] -- the caller lets its own
+ *   row count ride behind the 2C sums of the forward all-reduce ([2C + 1] doubles) and hands the backward a [2C + 1] buffer whose last word
+ *   it copies from there (device to device): ranks whose batches are padded to different H x W (dataset/voc.py:141-171) then need no host
+ *   round trip, and no rank assumes rows * world_size. */
 int32_t fd_batchnorm_sync_fwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* gamma, const float* beta, float* y,
                                    int32_t y_cs, int32_t y_co, int64_t rows, int32_t C, float eps, int32_t act, int32_t phase,
                                    double* sums, double total_rows, void* workspace, fd_stream_t stream);

@@ -329,6 +329,31 @@ def box_nms_plus1(boxes: np.ndarray, scores: np.ndarray, thr: float = 0.5, mode:
     return keep[:k].copy()
 
 
+def box_nms_plus1_torch(boxes: torch.Tensor, scores: torch.Tensor, thr: float = 0.5, mode: str = "union") -> torch.Tensor:
+    """DataEncoder._box_nms (utills.py:221-255) as the reference runs it: a Python `while` over torch tensor ops -- areas with the "+1"
+    pixel convention, candidates walked in descending score order, the survivors of each round are those with `ovr <= thr`.  This is the
+    form whose CPU time SURVEY 8(d) quotes (104 ms at N = 1000); ref_box_nms_plus1 (postproc_ref.c) is the same rule in plain C.  Pinned to
+    the reference's own outputs by the g3 `p*` vectors (tests/test_oracle_golden.py)."""
+    if mode not in ("union", "min"):
+        raise TypeError(f"Unknown nms mode: {mode}.")
+    x1, y1, x2, y2 = boxes.unbind(1)
+    area = (x2 - x1 + 1) * (y2 - y1 + 1)
+    order = scores.sort(0, descending=True)[1]
+    kept: List[int] = []
+    while order.numel():
+        top = int(order[0])
+        kept.append(top)
+        rest = order[1:]
+        if rest.numel() == 0:
+            break
+        iw = (torch.clamp(x2[rest], max=float(x2[top])) - torch.clamp(x1[rest], min=float(x1[top])) + 1).clamp(min=0)
+        ih = (torch.clamp(y2[rest], max=float(y2[top])) - torch.clamp(y1[rest], min=float(y1[top])) + 1).clamp(min=0)
+        inter = iw * ih
+        denom = (area[top] + area[rest] - inter) if mode == "union" else area[rest].clamp(max=float(area[top]))
+        order = rest[(inter / denom) <= thr]
+    return torch.tensor(kept, dtype=torch.long)
+
+
 def pairwise_iou(a: np.ndarray, b: np.ndarray, plus_one: bool) -> np.ndarray:
     out = np.empty((len(a), len(b)), np.float32)
     clib().ref_pairwise_iou(_p(np.ascontiguousarray(a, np.float32)), _p(np.ascontiguousarray(b, np.float32)), len(a),

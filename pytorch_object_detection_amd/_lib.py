@@ -25,7 +25,15 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libfcosdet_hip.so")
 
 
 class FdError(RuntimeError):
-    pass
+    """Error of the HIP path.  `rc` is the library's numeric return code (FD_E_INVAL -1, FD_E_UNSUPPORTED -2, FD_E_LAUNCH -3) when the
+    error came out of a C-ABI call, else None (host-side contract violations)."""
+
+    def __init__(self, msg: str = "", rc=None):
+        super().__init__(msg)
+        self.rc = rc
+
+
+E_INVAL, E_UNSUPPORTED, E_LAUNCH = -1, -2, -3
 
 
 class Segs(C.Structure):
@@ -131,6 +139,7 @@ _SIGS = {
     "fd_maxpool_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fd_upsample2x_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fd_batchnorm_update_running": (_I, [_P, _L, _I, _F, _F, _P, _P, _P]),
+    "fd_batchnorm_update_running_dev": (_I, [_P, _P, _I, _F, _F, _P, _P, _P]),
     "fd_batchnorm_sync_fwd_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _L, _I, _F, _I, _I, _P, _D, _P, _P]),
     "fd_batchnorm_sync_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _L, _I, _F, _I, _I, _P, _D, _P, _P, _P]),
     "fd_fcos_decode": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, C.POINTER(Segs), C.POINTER(_I), _P, _P, _P, _P]),
@@ -176,4 +185,4 @@ def lib() -> C.CDLL:
 def check(code: int, what: str = "") -> None:
     if code != 0:
         msg = lib().fd_last_error().decode(errors="replace")
-        raise FdError(f"{what or 'libfcosdet_hip'} failed ({code}): {msg}")
+        raise FdError(f"{what or 'libfcosdet_hip'} failed ({code}): {msg}", rc=int(code))

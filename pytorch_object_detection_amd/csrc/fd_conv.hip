@@ -608,13 +608,6 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
             default: fd_set_error("fd_conv2d: gn_stats is built for tiles 64x64, 128x64(_SB), 64x128(_SB), WAVE64 and WINOGRAD (got %d)", p->tile); return FD_E_UNSUPPORTED;
         }
     }
-    {   // GEMM-addressed layers: the persistent kernel (fd_conv_pw.hip)
-        static const int pw = getenv("FD_CONV_PERSIST") ? atoi(getenv("FD_CONV_PERSIST")) : 0;
-        if (pw && a.is_gemm && a.kt_per == a.KT && !a.gate) {
-            const int rc = fd_launch_conv_pw(a, p->tile, stream);
-            if (rc != FD_E_UNSUPPORTED) return rc;
-        }
-    }
     // GEMM-addressed fp32 layers (1x1, stride 1, no padding, Cin % 32 == 0, no gate): the loader compiled without the tap / bounds arithmetic
     static const int gemm_on = getenv("FD_CONV_GEMM") ? atoi(getenv("FD_CONV_GEMM")) : 1;
     const bool pointwise = !stem && p->KH == 1 && p->KW == 1 && p->pad == 0;     // any stride: one input address per output row

@@ -44,7 +44,6 @@ int fd_launch_conv_patch(const ConvArgs& a, int tag, int split, hipStream_t stre
 // fd_conv_wino.hip: 3x3 stride-1 'same' conv as Winograd F(2x2, 3x3) (FD_TILE_WINOGRAD; p->w is the fd_wino_pack_weights_f32 packing)
 int fd_launch_conv_wino(const fd_conv_params* p, hipStream_t stream);
 // fd_conv_pw.hip: persistent kernel of the GEMM-addressed (1x1 stride-1 unpadded) layers; FD_E_UNSUPPORTED when `tile` has no instantiation
-int fd_launch_conv_pw(const ConvArgs& a, int tile, hipStream_t stream);
 // fd_conv_wino4.hip: 3x3 stride-1 pad-1 conv as Winograd F(4x4, 3x3) (FD_TILE_WINOGRAD4; p->w is the fd_wino4_pack_weights_f32 packing)
 int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream);
 // fd_conv_wave.hip: GEMM-addressed layers as wave-autonomous 64 x 64 tiles (FD_TILE_WAVE64); wfrag = fd_pack_conv_weight_wave_f32 packing

@@ -46,8 +46,14 @@ struct Wino4Args {
     int T;                        // tiles in all
     int mtiles, ntiles, mt_per;   // M tiles (32 tiles each), N tiles (64 cout), M tiles per XCD
     unsigned x_bytes, u_bytes;
-    int dbg;                      // timing experiments only (FD_W4_DBG): 1 = no loader stages, 2 = no MFMAs, 4 = no epilogue (wrong results)
+    int dbg;                      // timing builds only (-DFD_W4_TIMING + FD_W4_DBG): 1 = no loader stages, 2 = no MFMAs, 4 = no epilogue (wrong results)
 };
+// The shipped library never skips parts of the kernel: the timing switches exist only in a build compiled with -DFD_W4_TIMING (tools/pmc_wino.sh).
+#ifdef FD_W4_TIMING
+#define W4_DBG(a) ((a).dbg)
+#else
+#define W4_DBG(a) 0
+#endif
 
 #define W4_TB 32
 #define W4_KC 8
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, (int)a.u_bytes, 0x00020000);
 
     // ---- loader role (threads 0 .. 383): (tile lt, line pr, channel quad q); pr = patch row i in G / R, column j' in C ----
-    const bool ldr = __builtin_amdgcn_readfirstlane(tid) < 384 && !(a.dbg & 1);       // wave-uniform: scalar branches around the loader slices
+    const bool ldr = __builtin_amdgcn_readfirstlane(tid) < 384 && !(W4_DBG(a) & 1);       // wave-uniform: scalar branches around the loader slices
     // one line pr per WAVE, (tile, quad) per lane: every scratch / V instruction of a wave then walks 64 different blocks at one in-block offset
     const int q = tid & 1, lt = (tid >> 1) & 31, pr = min(tid >> 6, 5);
     // patch row pr of tile lt: one base offset per thread; the six columns differ by a uniform pixel stride (buffer soffset) and a validity bit each
@@ -274,14 +280,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
         __syncthreads();
     }
     };
-    const bool mm = __builtin_amdgcn_readfirstlane((int)nb_ok) != 0 && !(a.dbg & 2);
+    const bool mm = __builtin_amdgcn_readfirstlane((int)nb_ok) != 0 && !(W4_DBG(a) & 2);
     if (ldr) { if (mm) main_loop(std::true_type{}, std::true_type{}); else main_loop(std::true_type{}, std::false_type{}); }
     else     { if (mm) main_loop(std::false_type{}, std::true_type{}); else main_loop(std::false_type{}, std::false_type{}); }
 
     // ---- epilogue: two halves of the 32 tiles in turn through the (now free) LDS, both channel blocks and all eight waves at once ----
     // Accumulator rows 0..15 are registers e = 0..7 of every f32x16, rows 16..31 registers 8..15: half h is dead in the register file once written, so
     // the output pass of half 0 runs beside 72 live accumulator registers only (the whole-tile variant spilled, the block-by-block one idled four waves).
-    if (a.dbg & 4) return;
+    if (W4_DBG(a) & 4) return;
     float* Ms = reinterpret_cast<float*>(smem);                          // [2 ch][36 f][16 tiles][32 cout]
     // output role: thread = (channel block, row pair of the 4 x 4 outputs, tile of the half, cout quad)
     int te = tid;
@@ -438,8 +444,12 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
     const long xb = rows * p->x_cs * 4, ub = (long)((p->Cout + 31) & ~31) * p->Cin * 36 * 4;
     FD_REQUIRE(xb < 0xC0000000L - 65536 && ub < 0xC0000000L, FD_E_UNSUPPORTED, "fd_conv2d: input / weight buffer exceeds 3 GiB");
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub;
+#ifdef FD_W4_TIMING
     static const int dbg = getenv("FD_W4_DBG") ? atoi(getenv("FD_W4_DBG")) : 0;
     a.dbg = dbg;
+#else
+    a.dbg = 0;
+#endif
     a.mtiles = (a.T + W4_TB - 1) / W4_TB;
     a.ntiles = (p->Cout + 63) / 64;
     a.mt_per = (a.mtiles + 7) / 8;

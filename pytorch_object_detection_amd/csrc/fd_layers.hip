@@ -1039,7 +1039,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ dx, int dx_cs, int dx_co, int C, int G, float eps,
                                                             int act, SegTab tab, const double* __restrict__ fpart,
-                                                            const double* __restrict__ img_sums, double cnt_ovr) {
+                                                            const double* __restrict__ img_sums, double cnt_ovr,
+                                                            const double* __restrict__ cnt_dev = nullptr) {
     __shared__ float s_mean[1024], s_rstd[1024], s_k1[1024], s_p[1024], s_q[1024];
     __shared__ double s_ga[1024], s_gb[1024];
     const int img = blockIdx.y;
@@ -1061,7 +1062,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
         const int g = c / cg;
         double s1 = 0, s2 = 0;
         for (int k = 0; k < cg; ++k) { s1 += s_ga[g * cg + k]; s2 += s_gb[g * cg + k]; }
-        const double cnt = cnt_ovr > 0.0 ? cnt_ovr : (double)HW * cg;     // (synchronised BatchNorm: the GLOBAL row count)
+        const double cnt = cnt_dev ? *cnt_dev : (cnt_ovr > 0.0 ? cnt_ovr : (double)HW * cg);     // (synchronised BatchNorm: the GLOBAL row count, host value or device word)
         const double rstd = (double)s_rstd[c], mean = (double)s_mean[c];
         s_k1[c] = (float)(rstd * (double)gamma[c]);
         s_p[c] = (float)(-rstd * rstd * s2 / cnt);
@@ -1469,9 +1470,10 @@ extern "C" int32_t fd_se_scale_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_
 // its workspace into the running statistics the way nn.BatchNorm2d does (momentum update, unbiased variance; HISFcos.py FPN
 // BatchNorms under the reference's model.train(), train.py:151).
 __global__ __launch_bounds__(256) void bn_running_kernel(const double* __restrict__ gstat, float* __restrict__ rmean, float* __restrict__ rvar,
-                                                          int C, double count, float momentum, float eps) {
+                                                          int C, double count, float momentum, float eps, const double* __restrict__ count_dev = nullptr) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    if (count_dev) count = *count_dev;
     const double mean = gstat[2 * c], rstd = gstat[2 * c + 1];
     double var = 1.0 / (rstd * rstd) - (double)eps;          // biased batch variance the forward normalised with
     if (var < 0) var = 0;
@@ -1487,6 +1489,16 @@ extern "C" int32_t fd_batchnorm_update_running(const void* gn_workspace, int64_t
     hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gstat, running_mean, running_var, C,
                        (double)rows, momentum, eps);
     FD_CHECK_LAUNCH("fd_batchnorm_update_running");
+    return FD_OK;
+}
+
+extern "C" int32_t fd_batchnorm_update_running_dev(const void* gn_workspace, const double* count_dev, int32_t C, float momentum, float eps,
+                                                   float* running_mean, float* running_var, fd_stream_t stream) {
+    FD_REQUIRE(gn_workspace && count_dev && running_mean && running_var && C >= 1, FD_E_INVAL, "fd_batchnorm_update_running_dev: bad argument");
+    const double* gstat = (const double*)gn_workspace + (long)GN_MAXCHUNK * C * 2;
+    hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gstat, running_mean, running_var, C,
+                       0.0, momentum, eps, count_dev);
+    FD_CHECK_LAUNCH("fd_batchnorm_update_running_dev");
     return FD_OK;
 }
 
@@ -1508,6 +1520,7 @@ __global__ __launch_bounds__(256) void bn_sync_finalize_kernel(const double* __r
                                                                 double* __restrict__ gstat) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    if (count <= 0.0) count = sums[2 * C];           // the all-reduced row count riding behind the 2C sums (uneven shards: no host round trip)
     const double mean = sums[2 * c] / count;
     double var = sums[2 * c + 1] / count - mean * mean;
     if (var < 0) var = 0;
@@ -1535,7 +1548,8 @@ extern "C" int32_t fd_batchnorm_sync_fwd_nhwc(const float* x, int32_t x_cs, int3
         FD_CHECK_LAUNCH("fd_batchnorm_sync_fwd (sums)");
         return FD_OK;
     }
-    FD_REQUIRE(view_ok(y, y_cs, y_co, C) && gamma && beta && total_rows >= (double)rows, FD_E_INVAL, "fd_batchnorm_sync_fwd: phase 2 needs y, gamma, beta and the global row count");
+    FD_REQUIRE(view_ok(y, y_cs, y_co, C) && gamma && beta && (total_rows <= 0.0 || total_rows >= (double)rows), FD_E_INVAL,
+               "fd_batchnorm_sync_fwd: phase 2 needs y, gamma, beta and the global row count (host value >= rows, or <= 0: read from sums[2C] on the device)");
     hipLaunchKernelGGL(bn_sync_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)sums, total_rows, eps, C, gstat);
     FD_CHECK_LAUNCH("fd_batchnorm_sync_fwd (finalize)");
     const int ablk = (int)max((int64_t)1, min((int64_t)512, (rows * (C / 4) + 2047) / 2048));
@@ -1571,10 +1585,11 @@ extern "C" int32_t fd_batchnorm_sync_bwd_nhwc(const float* x, int32_t x_cs, int3
         FD_CHECK_LAUNCH("fd_batchnorm_sync_bwd (params)");
         return FD_OK;
     }
-    FD_REQUIRE(view_ok(dx, dx_cs, dx_co, C) && total_rows >= (double)rows, FD_E_INVAL, "fd_batchnorm_sync_bwd: phase 2 needs dx and the global row count");
+    FD_REQUIRE(view_ok(dx, dx_cs, dx_co, C) && (total_rows <= 0.0 || total_rows >= (double)rows), FD_E_INVAL,
+               "fd_batchnorm_sync_bwd: phase 2 needs dx and the global row count (host value >= rows, or <= 0: read from sums[2C] on the device)");
     const int ablk = (int)max((int64_t)1, min((int64_t)512, (rows * (C / 4) + 2047) / 2048));
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ablk, 1), dim3(256), 0, st, x, x_cs, x_co, dy, dy_cs, dy_co, gamma, beta, dx, dx_cs, dx_co, C, C, eps,
-                       act, tab, gstat, (const double*)sums, total_rows);
+                       act, tab, gstat, (const double*)sums, total_rows, total_rows <= 0.0 ? (const double*)sums + 2 * C : nullptr);
     FD_CHECK_LAUNCH("fd_batchnorm_sync_bwd (apply)");
     return FD_OK;
 }

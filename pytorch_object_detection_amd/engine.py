@@ -33,7 +33,6 @@ AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see 
 # (ops.wino_preferred: it has no split-K); "force" = wherever it applies; "0" = every conv on the direct implicit-GEMM kernel
 WINOGRAD = _os.environ.get("FD_WINOGRAD", "1") != "0"
 SE_GATE_IN_PROJECT = _os.environ.get("FD_SE_GATE_FUSED", "1") != "0"     # MBConv: SE gate applied by the project conv's loader ("0": a scaling pass)
-WAVE_RULE = tuple(int(v) for v in _os.environ["FD_WAVE_RULE"].split(",")) if _os.environ.get("FD_WAVE_RULE") else None
 GN_FUSED_TOWER = _os.environ.get("FD_GN_FUSED_TOWER", "0") == "1"   # "1": the tower's statistics from its Winograd epilogue too (measured neutral, costs the tower launch 5 %)
 GN_FUSED = _os.environ.get("FD_GN_FUSED", "1") != "0"       # "0": HISFCOSHead's GroupNorms as three-pass launches (statistics / finalise / normalise)
 WAVE_TILE = _os.environ.get("FD_WAVE_TILE", "1") != "0"       # "0": the 1x1 layers never see FD_TILE_WAVE64 (wave-autonomous tiles, fd_conv_wave.hip)
@@ -257,9 +256,6 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         if split:
             key = "f16x3|" + key
         plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co, -(-Cin // 32) * k * k, pair=plan.pair_tuned and tag != 1)
-        if wfrag is not None and WAVE_RULE and Cin <= WAVE_RULE[0] and out.rows >= WAVE_RULE[1] and gn_stats is None:
-            call.params.tile, call.params.ksplit = _lib.WAVE_TILE, 1          # (experiment knob FD_WAVE_RULE="maxCin,minRows")
-            plan.tiles[name] = _lib.WAVE_TILE
         if gn_stats is not None and (plan.tiles[name] & 0xFF) not in (0, 2, 3, 4, 8, 9, _lib.WAVE_TILE):
             call.params.tile = plan.tiles[name] = 8      # the statistics epilogue exists for the one- / two-sub-tile tiles (and WAVE64 / Winograd)
     plan.flops += 2 * out.rows * co * Cin * k * k

@@ -320,10 +320,16 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
     table = _tune_table()
 
     def apply(code: int) -> int:
-        p.tile, p.ksplit = code & 0xFF, max(1, code >> 8)
-        if p.ksplit > 1 and not p.workspace:
-            p.ksplit = 1
-        return code
+        """Install a table / heuristic / timed code on the launch and return the code ACTUALLY applied (what plan.tiles records)."""
+        tile, ks = code & 0xFF, max(1, code >> 8)
+        if tile == _lib.WAVE_TILE and not p.w_frag:
+            # the key does not say whether the caller packed the weights in MFMA fragment order (train_ops._conv_launch never does, plans built
+            # with FD_WAVE_TILE=0 neither): the wave-autonomous tile is then not available -- fall back to the library's heuristic tile
+            tile, ks = 0, 1
+        if ks > 1 and (not p.workspace or p.gn_stats):        # (split-K needs the scratch; a row-statistics epilogue has no combine launch)
+            ks = 1
+        p.tile, p.ksplit = tile, ks
+        return tile | ((ks if ks > 1 else 0) << 8)
 
     base = key
     if pair:                         # tiles chosen for throughput beside another batch: own table entries, serial ones as fallback
@@ -373,7 +379,7 @@ def autotune_conv(run: Callable[[], None], key: str, M: int, Cout: int, KT: int,
         try:
             run()  # warm
         except FdError as e:          # a tile the library has no kernel for on this layer (FD_E_UNSUPPORTED): not a candidate
-            if "(-2)" not in str(e) and "UNSUPPORTED" not in str(e).upper():
+            if e.rc != _lib.E_UNSUPPORTED:
                 raise
             continue
         t = float("inf")
@@ -466,7 +472,7 @@ def wino4_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bo
 # FD_WINOGRAD4: "1" (default) = layers the F(4x4, 3x3) kernel covers run on it where wino4_choice's cost model says it beats F(2x2, 3x3);
 # "0" = never (the round-2 plans); "force" = wherever it applies (tests exercise the kernel inside whole models this way)
 WINO4_MODE = os.environ.get("FD_WINOGRAD4", "1")
-_W4_FIXED_US = float(os.environ.get("FD_WINOGRAD4_FIXED_US", "12"))       # the cost model's per-workgroup prologue + epilogue term (experiments)
+_W4_FIXED_US = 12.0       # the cost model's per-workgroup prologue + epilogue term, microseconds (fitted; 8 moved more layers onto F(4x4) and lost: profiles/r03y_layer_times_w4_fixed8.tsv)
 
 
 def wino4_tiles(segs: Segs, dil: int = 1) -> int:
@@ -833,6 +839,16 @@ def batchnorm_update_running(gn_ws: torch.Tensor, rows: int, Cc: int, momentum: 
     _need_gpu(gn_ws, running_mean, running_var)
     check(_lib.lib().fd_batchnorm_update_running(gn_ws.data_ptr(), rows, Cc, float(momentum), float(eps), running_mean.data_ptr(),
                                                  running_var.data_ptr(), _stream()), "fd_batchnorm_update_running")
+
+
+def batchnorm_update_running_dev(gn_ws: torch.Tensor, count: torch.Tensor, Cc: int, momentum: float, eps: float, running_mean: torch.Tensor,
+                                 running_var: torch.Tensor) -> None:
+    """As batchnorm_update_running with the row count in device memory (`count`: one float64 element, e.g. the tail of SyncBatchNorm's
+    all-reduced buffer): no host round trip."""
+    _need_gpu(gn_ws, count, running_mean, running_var)
+    assert count.dtype == torch.float64 and count.numel() == 1
+    check(_lib.lib().fd_batchnorm_update_running_dev(gn_ws.data_ptr(), count.data_ptr(), Cc, float(momentum), float(eps), running_mean.data_ptr(),
+                                                     running_var.data_ptr(), _stream()), "fd_batchnorm_update_running_dev")
 
 
 # ---------------------------------------------------------------------------------------------------- post-process

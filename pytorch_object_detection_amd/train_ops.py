@@ -820,15 +820,17 @@ class _SyncBatchNormTrainRows(torch.autograd.Function):
         fn, st = _lib.lib().fd_batchnorm_sync_fwd_nhwc, ops._stream()
         ops.check(fn(x.data_ptr(), Cc, 0, None, None, None, 0, 0, rows, Cc, eps, act, 1, buf.data_ptr(), 0.0, ws.data_ptr(), st),
                   "fd_batchnorm_sync_fwd_nhwc (stats)")
-        buf[2 * Cc] = float(rows)
+        buf[2 * Cc] = float(rows)                                # this rank's row count rides behind the 2C sums (a device-side fill, no sync)
         dist.all_reduce(buf, group=group)                       # THE forward collective of this layer (C3)
-        total = float(rows) * dist.get_world_size(group) if _EVEN_SHARDS else float(buf[2 * Cc].item())
+        # The GLOBAL row count is buf[2C] AFTER the all-reduce and is read ON THE DEVICE (total_rows = -1): ranks hold different row counts
+        # whenever their batches are padded to different H x W (dataset/voc.py:141-171), so rows * world_size would be wrong -- and different
+        # on every rank -- there; no .item(), no host synchronisation.
         ops.check(fn(x.data_ptr(), Cc, 0, gm.data_ptr(), bt.data_ptr(), y.data_ptr(), Cc, 0, rows, Cc, eps, act, 2, buf.data_ptr(),
-                     C.c_double(total), ws.data_ptr(), st), "fd_batchnorm_sync_fwd_nhwc (apply)")
+                     C.c_double(-1.0), ws.data_ptr(), st), "fd_batchnorm_sync_fwd_nhwc (apply)")
         if rmean is not None and momentum is not None:
-            ops.batchnorm_update_running(ws, int(total), Cc, momentum, eps, rmean, rvar)
-        ctx.save_for_backward(x, gm, bt, ws)
-        ctx.geom = (eps, act, group, total)
+            ops.batchnorm_update_running_dev(ws, buf[2 * Cc:], Cc, momentum, eps, rmean, rvar)
+        ctx.save_for_backward(x, gm, bt, ws, buf)
+        ctx.geom = (eps, act, group)
         return y
 
     @staticmethod
@@ -836,8 +838,8 @@ class _SyncBatchNormTrainRows(torch.autograd.Function):
     def backward(ctx, gy):
         import ctypes as C
         import torch.distributed as dist
-        x, gm, bt, ws = ctx.saved_tensors
-        eps, act, group, total = ctx.geom
+        x, gm, bt, ws, buf = ctx.saved_tensors
+        eps, act, group = ctx.geom
         rows, Cc = x.shape
         g = gy.contiguous()
         gx = torch.empty_like(x)
@@ -846,18 +848,15 @@ class _SyncBatchNormTrainRows(torch.autograd.Function):
         segs = Segs.make(1, [(rows, 1)])
         nb = _lib.lib().fd_groupnorm_bwd_workspace_bytes(C.byref(segs), Cc)
         bws = torch.empty(nb // 8, dtype=torch.float64, device=x.device)
-        sums = torch.empty(2 * Cc, dtype=torch.float64, device=x.device)
+        sums = torch.empty(2 * Cc + 1, dtype=torch.float64, device=x.device)       # [sum dz | sum dz * xhat | global row count]
         fn, st = _lib.lib().fd_batchnorm_sync_bwd_nhwc, ops._stream()
         ops.check(fn(x.data_ptr(), Cc, 0, g.data_ptr(), Cc, 0, gm.data_ptr(), bt.data_ptr(), None, 0, 0, dgamma.data_ptr(), dbeta.data_ptr(),
                      rows, Cc, eps, act, 1, sums.data_ptr(), 0.0, ws.data_ptr(), bws.data_ptr(), st), "fd_batchnorm_sync_bwd_nhwc (sums)")
-        dist.all_reduce(sums, group=group)                      # THE backward collective of this layer
+        dist.all_reduce(sums[:2 * Cc], group=group)             # THE backward collective of this layer
+        sums[2 * Cc:].copy_(buf[2 * Cc:])                       # the forward's all-reduced row count, device to device
         ops.check(fn(x.data_ptr(), Cc, 0, g.data_ptr(), Cc, 0, gm.data_ptr(), bt.data_ptr(), gx.data_ptr(), Cc, 0, None, None,
-                     rows, Cc, eps, act, 2, sums.data_ptr(), C.c_double(total), ws.data_ptr(), None, st), "fd_batchnorm_sync_bwd_nhwc (apply)")
+                     rows, Cc, eps, act, 2, sums.data_ptr(), C.c_double(-1.0), ws.data_ptr(), None, st), "fd_batchnorm_sync_bwd_nhwc (apply)")
         return gx, dgamma, dbeta, None, None, None, None, None, None
-
-
-_EVEN_SHARDS = True     # every rank holds the same number of rows per layer (DDP with equal per-rank batches, train.py); False: read the
-                        # all-reduced row count back from the device (one host sync per SyncBatchNorm layer)
 
 
 def _bn_train_ok(bn: nn.Module, x: torch.Tensor) -> bool:

@@ -129,3 +129,62 @@ def test_two_rank_syncbatchnorm_on_hip_equals_the_full_batch():
         d = ((r0[n] - ref).abs() / scale).flatten()
         # gradients through ~30 batch-statistic BatchNorms are ill-conditioned (tests/test_train_gpu.py): bulk at 1e-3 of the maximum
         assert float(d.median()) < 2e-3 and float((d > 5e-2).float().mean()) < 0.02, (n, float(d.median()), float(d.max()))
+
+
+def _uneven_rows(rank_or_all):
+    """Rows of a 32-channel map per rank: rank 0 holds 2 x 16 x 16, rank 1 holds 2 x 16 x 24 -- what dataset/voc.py:141-171 produces when the
+    ranks' batches are padded to different H x W."""
+    g = torch.Generator().manual_seed(77)
+    parts = [torch.randn(2 * 16 * 16, 32, generator=g) * 1.5 + 0.3, torch.randn(2 * 16 * 24, 32, generator=g) * 0.7 - 0.2]
+    grads = [torch.randn(p.shape, generator=g) for p in parts]
+    return (parts, grads) if rank_or_all is None else (parts[rank_or_all], grads[rank_or_all])
+
+
+def _uneven_worker(rank, world, init_file, out_dir):
+    import torch.distributed as dist
+    from pytorch_object_detection_amd import train_ops
+    from pytorch_object_detection_amd._lib import ACT_SILU
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(9)
+        bn = torch.nn.SyncBatchNorm(32).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(32) + 0.5); bn.bias.copy_(torch.randn(32) * 0.1)
+        x, gy = _uneven_rows(rank)
+        x = x.to(dev).requires_grad_(True)
+        y = train_ops.batchnorm_train_rows(bn, x, ACT_SILU)
+        y.backward(gy.to(dev))
+        torch.save({"y": y.detach().cpu(), "dx": x.grad.cpu(), "dgamma": bn.weight.grad.cpu(), "dbeta": bn.bias.grad.cpu(),
+                    "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu(), "nbt": int(bn.num_batches_tracked)}, os.path.join(out_dir, f"u{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_syncbatchnorm_with_different_row_counts_per_rank():
+    """ranks whose batches are padded to different H x W hold different row counts; the global count must come out of the
+    all-reduce (read on the device), not rows * world_size.  Two ranks with 512 and 768 rows against plain BatchNorm over the 1280 rows."""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_uneven_worker, args=(2, os.path.join(tmp, "rdzv"), tmp), nprocs=2, join=True)
+        r = [torch.load(os.path.join(tmp, f"u{i}.pt")) for i in range(2)]
+    parts, grads = _uneven_rows(None)
+    torch.manual_seed(9)
+    bn = torch.nn.BatchNorm1d(32).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(32) + 0.5); bn.bias.copy_(torch.randn(32) * 0.1)
+    x = torch.cat(parts).double().requires_grad_(True)
+    y = torch.nn.functional.silu(bn(x))
+    y.backward(torch.cat(grads).double())
+    n0 = parts[0].shape[0]
+    for i, sl in enumerate((slice(0, n0), slice(n0, None))):
+        np.testing.assert_allclose(r[i]["y"].numpy(), y[sl].detach().float().numpy(), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(r[i]["dx"].numpy(), x.grad[sl].float().numpy(), rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(r[i]["rm"].numpy(), bn.running_mean.float().numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(r[i]["rv"].numpy(), bn.running_var.float().numpy(), rtol=1e-5, atol=1e-7)
+        assert r[i]["nbt"] == 1
+    # the affine gradients are per-rank sums (DDP averages them): together they are the full batch's
+    np.testing.assert_allclose((r[0]["dgamma"] + r[1]["dgamma"]).numpy(), bn.weight.grad.float().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose((r[0]["dbeta"] + r[1]["dbeta"]).numpy(), bn.bias.grad.float().numpy(), rtol=2e-4, atol=2e-5)

@@ -262,3 +262,37 @@ def test_reference_checkpoint_layouts_load():
     assert torch.equal(m3.backbone.conv1.weight, stripped["backbone.extract_feature.conv1.weight"])
     f = FCOS([2048, 1024, 512], 20, 256)
     f.load_state_dict({k[7:]: v for k, v in {"module." + k: v for k, v in f.state_dict().items()}.items()}, strict=True)
+
+
+def test_tile_table_wave_entry_is_demoted_without_fragment_packed_weights(monkeypatch):
+    """the committed tile table holds an FD_TILE_WAVE64 entry whose key does not say whether the caller packed its weights in MFMA
+    fragment order (fd_conv_params.w_frag).  train_ops._conv_launch never does and plans built with FD_WAVE_TILE=0 do not either: the table
+    entry -- also through the nearest-batch transfer -- must then come out as the heuristic tile, not as a launch the library refuses."""
+    key = "B16|208x336|32>192|k1s1p0d1|res0|xcs32|ycs192"
+    monkeypatch.setattr(ops, "_TUNE_MODE", "0")
+    monkeypatch.setattr(ops, "_TUNE_CACHE", {key: _lib.WAVE_TILE})
+    monkeypatch.setattr(ops, "_TUNE_LOADED", True)
+
+    class Run:
+        params = _lib.ConvParams()
+    p = Run.params
+    for k in (key, key.replace("B16|", "B8|"), key.replace("B16|", "B32|")):          # exact entry and the 0.5x .. 2x batch transfer
+        p.w_frag = None
+        assert ops.autotune_conv(Run, k, 16 * 208 * 336, 192, 1) == 0 and p.tile == 0 and p.ksplit == 1
+        p.w_frag = 4096                                                                # a (fake) fragment-packed weight pointer: the entry stands
+        assert ops.autotune_conv(Run, k, 16 * 208 * 336, 192, 1) == _lib.WAVE_TILE and p.tile == _lib.WAVE_TILE
+    # split-K bits are dropped, and reported as dropped, when the launch has no workspace or carries a row-statistics epilogue
+    monkeypatch.setattr(ops, "_TUNE_CACHE", {"k": 8 | (4 << 8)})
+    p.w_frag, p.workspace, p.gn_stats = None, None, None
+    assert ops.autotune_conv(Run, "k", 1000, 64, 8) == 8 and p.ksplit == 1
+    p.workspace, p.gn_stats = 4096, 8192
+    assert ops.autotune_conv(Run, "k", 1000, 64, 8) == 8 and p.ksplit == 1
+    p.gn_stats = None
+    assert ops.autotune_conv(Run, "k", 1000, 64, 8) == (8 | (4 << 8)) and p.ksplit == 4
+
+
+def test_fderror_carries_the_numeric_return_code():
+    with pytest.raises(_lib.FdError) as ei:
+        _lib.check(_lib.E_UNSUPPORTED, "probe")
+    assert ei.value.rc == _lib.E_UNSUPPORTED == -2 and "(-2)" in str(ei.value)
+    assert _lib.FdError("host-side").rc is None

@@ -890,48 +890,6 @@ def test_conv1x1_with_input_gate(case):
     assert torch.equal(xr.tensor(), before)                 # x untouched
 
 
-_PERSIST_SCRIPT = r"""
-import sys, torch
-from pytorch_object_detection_amd import ops
-from pytorch_object_detection_amd._lib import ACT_RELU, Segs
-dev = "cuda:0"
-outs = []
-for (Cin, Cout, hw, use_res, tile) in [(72, 200, [(37, 41)], True, 9), (256, 64, [(40, 24)], False, 4), (128, 512, [(20, 20), (10, 10), (5, 5)], True, 8),
-                                       (64, 256, [(33, 17)], True, 1), (512, 96, [(9, 9)], False, 3)]:
-    gen = torch.Generator().manual_seed(Cin * 7 + Cout)
-    segs = Segs.make(3, hw)
-    x = ops.Rows(torch.randn(segs.rows, Cin, generator=gen).to(dev))
-    w = (torch.randn(Cout, Cin, 1, 1, generator=gen) / Cin ** 0.5).to(dev)
-    sc, sf = (torch.rand(Cout, generator=gen) + 0.5).to(dev), torch.randn(Cout, generator=gen).to(dev)
-    res = ops.Rows(torch.randn(segs.rows, Cout, generator=gen).to(dev)) if use_res else None
-    y = ops.new_rows(segs.rows, Cout, dev)
-    ops.conv_call(x, segs, ops.pack_conv_weight(w), y, Cin=Cin, Cout=Cout, k=1, scale=sc, shift=sf, res=res, act=ACT_RELU, tile=tile)()
-    ref = torch.relu(x.tensor() @ w.view(Cout, Cin).t() * sc + sf + (res.tensor() if use_res else 0))
-    assert torch.allclose(y.tensor(), ref, atol=2e-4, rtol=1e-4), (Cin, Cout, float((y.tensor() - ref).abs().max()))
-    outs.append(y.tensor().cpu())
-torch.save(outs, sys.argv[1])
-"""
-
-
-def test_conv1x1_persistent_kernel_matches_default(tmp_path):
-    """FD_CONV_PERSIST=1 routes the GEMM-addressed layers to fd_conv_pw.hip (opt-in: workgroups walk tiles, the next tile's operands and
-    this tile's residual are requested under the last K-tile's MFMAs).  Same per-output summation order as the default kernel, so the
-    two must agree bit for bit; the environment switch is read once per process, hence the two child processes."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    got = []
-    for mode in ("0", "1"):
-        out = tmp_path / f"pw{mode}.pt"
-        env = dict(os.environ, FD_CONV_PERSIST=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        r = subprocess.run([sys.executable, "-c", _PERSIST_SCRIPT, str(out)], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        got.append(torch.load(out))
-    for a, b in zip(*got):
-        assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("k,stride,pad", [(1, 1, 0), (3, 1, 1), (3, 2, 1)])
 def test_autotune_force_mode_times_only_tiles_the_layer_has(k, stride, pad, monkeypatch):
     """ops.autotune_conv's live-timing path (FD_AUTOTUNE=1 / force) used to offer FD_TILE_128x128_PATCH -- a 3x3 stride-1 'same'

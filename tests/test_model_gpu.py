@@ -31,6 +31,32 @@ def randomize_norms(model, seed):
             m.weight.data.copy_(torch.rand(m.num_channels, generator=gen) + 0.5)
             m.bias.data.copy_(torch.randn(m.num_channels, generator=gen) * 0.1)
 
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max |a - b| / (1 + |b|): the scale-free deviation the parity bounds are written in (LTRB distances of hundreds of pixels
+    go through exp(), only a relative bar is meaningful there)."""
+    return float(((a - b).abs() / (1 + b.abs())).max())
+
+
+F32_BOUND = 3e-5       # measured: 1.97e-5 for the shipped batch-16 plan (F(4x4, 3x3) Winograd on its wide layers), 0.9e-5 on F(2x2) / direct (DESIGN 7.3)
+
+
+def check_outputs(out, ref, prec: str, what: str = "") -> float:
+    """Every head output against the oracle: 1e-4 abs + 1e-4 rel for the opt-in split-f16 arithmetic (f16x3 / mixed); the exact-fp32 paths
+    additionally meet the measured bound F32_BOUND * (1 + |ref|)."""
+    worst = 0.0
+    for name, o, r in zip(("cls", "cnt", "reg"), out, ref):
+        assert len(o) == len(r)
+        for i in range(len(o)):
+            assert tuple(o[i].shape) == tuple(r[i].shape)
+            a = o[i].cpu()
+            np.testing.assert_allclose(a.numpy(), r[i].numpy(), err_msg=f"{name}{i}", **TOL)
+            worst = max(worst, rel_err(a, r[i]))
+    print(f"{what} [{prec}]: max |err| / (1 + |ref|) = {worst:.3g}")
+    if prec.startswith("f32"):
+        assert worst <= F32_BOUND, f"{what}: {worst:.3g} > {F32_BOUND} on an exact-fp32 path"
+    return worst
+
+
 def assert_same_detections(s, c, b, es, ec, eb):
     """HIP detections of one image against the oracle post-process of the SAME head outputs.  Boxes and classes are exact; the
     device's sigmoid / sqrt (expf, IEEE divide) and the host libm round a score differently in the last bit now and then (~2 % of
@@ -111,11 +137,7 @@ def test_full_hisfcos_vs_oracle(shape, prec, monkeypatch):
         ref = R.hisfcos_forward(sd, x)
     model.to(DEV)
     out = model(x.to(DEV))
-    for name, o, r in zip(("cls", "cnt", "reg"), out, ref):
-        assert len(o) == 5
-        for i in range(5):
-            assert tuple(o[i].shape) == tuple(r[i].shape)
-            np.testing.assert_allclose(o[i].cpu().numpy(), r[i].numpy(), err_msg=f"{name}{i}", **TOL)
+    check_outputs(out, ref, prec, f"HISFCOS {shape}")
     # detections: same kept boxes as the oracle post-process on the ORACLE's head outputs is not guaranteed
     # bitwise (different conv rounding); on the device's own outputs it must be exact
     head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
@@ -145,10 +167,7 @@ def test_full_fcos_vs_oracle(prec):
         ref = R.fcos_forward(sd, x)
     model.to(DEV)
     out = model(x.to(DEV))
-    for name, o, r in zip(("cls", "cnt", "reg"), out, ref):
-        for i in range(5):
-            assert tuple(o[i].shape) == tuple(r[i].shape)
-            np.testing.assert_allclose(o[i].cpu().numpy(), r[i].numpy(), err_msg=f"{name}{i}", **TOL)
+    check_outputs(out, ref, prec, "FCOS-R50 128x160")
 
 
 def test_plan_cache_follows_weight_updates():
@@ -181,14 +200,48 @@ def test_baseline_config_640_batch2_vs_oracle(prec):
     xd = x.to(DEV)
     out = model(xd)
     assert [tuple(t.shape[2:]) for t in out[0]] == [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
-    for name, o, r in zip(("cls", "cnt", "reg"), out, ref):
-        for i in range(5):
-            np.testing.assert_allclose(o[i].cpu().numpy(), r[i].numpy(), err_msg=f"{name}{i}", **TOL)
+    check_outputs(out, ref, prec, "HISFCOS 2 x 640 x 640")
     head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
     s, c, b, counts = head.detect_padded(out)
     b = ClipBoxes()(xd, b)
     exp = R.fcos_detect([[t.cpu() for t in grp] for grp in out], [8, 16, 32, 64, 128], 0.05, 0.6, 1000, (640, 640))
     for bi in range(2):
+        n = int(counts[bi])
+        assert n == len(exp[bi][0])
+        assert_same_detections(s[bi, :n].cpu().numpy(), c[bi, :n].cpu().numpy(), b[bi, :n].cpu().numpy(), *exp[bi])
+
+
+def test_full_size_batch16_shipped_plan_vs_oracle():
+    """THE headline configuration (BASELINE configs[1]: 16 x 640 x 640, 80 classes, default knobs -- the plan bench.py times) directly against
+    the CPU oracle: all 15 head outputs of all 16 images within the MEASURED bound 3e-5 * (1 + |ref|) (north_star's bar is 1e-4), and the
+    detections against the oracle post-process of the device's own outputs."""
+    torch.manual_seed(41)
+    model = HalfInvertedStageFCOS([512, 1024, 2048], 80, 256).eval()
+    randomize_norms(model, 42)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(16, 3, 640, 640)
+    with torch.no_grad():
+        ref = R.hisfcos_forward(sd, x)
+    model.to(DEV)
+    xd = x.to(DEV)
+    out = model(xd)
+    built = next(iter(model._plans.values()))[1]
+    plan = next(o for o in (built if isinstance(built, tuple) else (built,)) if hasattr(o, "tiles") and hasattr(o, "steps"))
+    on4 = [n for n, t in plan.tiles.items() if (t & 0xFF) == 16]
+    assert "head.tower3x3" in on4 and len(on4) >= 12, on4              # (this IS the shipped F(4x4) plan, not a forced variant)
+    worst = 0.0
+    for name, o, r in zip(("cls", "cnt", "reg"), out, ref):
+        for i in range(5):
+            assert tuple(o[i].shape) == tuple(r[i].shape)
+            e = rel_err(o[i].cpu(), r[i])
+            worst = max(worst, e)
+            assert e <= F32_BOUND, f"{name}{i}: max |err| / (1 + |ref|) = {e:.3g} > {F32_BOUND}"
+    print(f"batch-16 shipped plan vs oracle: max |err| / (1 + |ref|) = {worst:.3g}")
+    head = FCOSHead(0.05, 0.6, 1000, [8, 16, 32, 64, 128])
+    s, c, b, counts = head.detect_padded(out)
+    b = ClipBoxes()(xd, b)
+    exp = R.fcos_detect([[t.cpu() for t in grp] for grp in out], [8, 16, 32, 64, 128], 0.05, 0.6, 1000, (640, 640))
+    for bi in range(16):
         n = int(counts[bi])
         assert n == len(exp[bi][0])
         assert_same_detections(s[bi, :n].cpu().numpy(), c[bi, :n].cpu().numpy(), b[bi, :n].cpu().numpy(), *exp[bi])

@@ -58,6 +58,15 @@ def test_g3_box_nms_plus1(golden):
         np.testing.assert_array_equal(keep, g[f"p{c}_keep"], err_msg=f"case {c}")
 
 
+def test_g3_box_nms_plus1_greedy_torch_form(golden):
+    """The greedy-torch restatement (the form bench.py times as the reference's own NMS cost) against the reference's kept indices."""
+    g = golden("g3_nms")
+    for c in range(int(g["n_plus1"])):
+        keep = R.box_nms_plus1_torch(torch.from_numpy(g[f"p{c}_boxes"]), torch.from_numpy(g[f"p{c}_scores"]), float(g[f"p{c}_thr"]),
+                                     "union" if int(g[f"p{c}_mode"]) == 0 else "min")
+        np.testing.assert_array_equal(keep.numpy(), g[f"p{c}_keep"], err_msg=f"case {c}")
+
+
 @pytest.mark.parametrize("ci", [0, 1, 2])
 def test_g3b_head_end_to_end(golden, ci):
     g = golden("g3b_head_end2end")
