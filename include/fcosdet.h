@@ -113,7 +113,10 @@ const char* fd_last_error(void);
 #define FD_TILE_WINOGRAD4 16 /* 3x3 stride-1 'same' convs (dilation 1 or 2), fp32: Winograd F(4x4, 3x3) on the fp32 MFMA -- 36 multiplies per 4x4 output tile and
                                 channel pair (2.25 per output: 1.78x fewer than F(2x2), 4x fewer than direct); needs the fd_wino4_pack_weights_f32 packing in `w`;
                                 ksplit as FD_TILE_WINOGRAD; no gate / gn_stats.  Rounding error ~2x F(2x2)'s, inside the 1e-4 parity bar */
-#define FD_TILE_COUNT 16
+#define FD_TILE_NARROW 17    /* 3x3 stride-1 pad-1 convs with Cout <= 8 (the centre-ness + box-distance predictor, HISFcos.py:207-209), fp32, Cin % 16 == 0, no
+                                residual / gate / gn_stats / split-K: exact fp32 FMA chains on the VECTOR unit, one thread per output pixel (fd_conv_narrow.hip).
+                                `w` = [Cin / 16][3 r][4 quads][3 q][4 k][8 couts] fp32: channel 16 chunk + 4 quad + k, filter tap (r, q); zero filters past Cout */
+#define FD_TILE_COUNT 17
 
 typedef struct fd_conv_params {
     const float* x;
@@ -173,9 +176,33 @@ typedef struct fd_conv_params {
     int32_t gn_groups;
     int32_t gate_act;
     const float* gate_b;
+    /* A SECOND input whose channels continue the reduction (K-concatenation; 1x1 unpadded fp32 layers on a single level, no split-K / gate):
+     *     y = act((x . W[:, :Cin]^T  +  x2' . W[:, Cin:]^T) * scale + shift (+ res)),   x2'[n, i, j] = x2[n, x2_stride * i, x2_stride * j]
+     * with `w` the [Cout][Cin + x2_Cin] bank in the plain packing.  A ResNet bottleneck that changes resolution / width ends in
+     * relu(bn3(conv3(o2)) + bn_d(downsample(x))) (torchvision Bottleneck.forward behind model/backbone/resnet50.py:68-80): with the BatchNorm scales
+     * folded into the two filter banks this is ONE GEMM over K = planes + inplanes, and the 4 * planes wide identity map (420 MB per 16 images in
+     * layer1) is neither written nor read back.  x2 is an [batch][x2_H][x2_W] NHWC map; Cin % 32 == 0, x2_Cin % 32 == 0.  NULL = off. */
+    const float* x2;
+    int32_t x2_cs, x2_co, x2_Cin, x2_stride, x2_H, x2_W;
 } fd_conv_params;
 
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
+/* Two GEMM-addressed (1x1, stride 1, unpadded) layers back to back in ONE launch -- a ResNet bottleneck's conv3 + BN + residual + ReLU and the next
+ * block's conv1 + BN + ReLU (torchvision Bottleneck.forward behind model/backbone/resnet50.py:68-80):
+ *     y = act1(x . W1^T * scale1 + shift1 + res)   [rows][N1]   written to HBM (it is the next block's residual)
+ *     z = act2(y . W2^T * scale2 + shift2)         [rows][N2]   computed from the rows of y while they are still on chip: y is not read back
+ * w1_frag / w2_frag: the [N1][K1] / [N2][N1] filter banks in MFMA fragment order (fd_pack_conv_weight_wave_f32).  K1 % 32 == 0, N1 % 64 == 0,
+ * N2 in {64, 128}; activations NONE / RELU / SILU; all views 16-byte addressable.  y and z are bit-identical to two fd_conv2d_nhwc_f32 launches. */
+typedef struct fd_b2b_params {
+    const float* x; const float* w1_frag; const float* scale1; const float* shift1; const float* res; float* y;
+    const float* w2_frag; const float* scale2; const float* shift2; float* z;
+    int32_t x_cs, x_co, res_cs, res_co, y_cs, y_co, z_cs, z_co;
+    int32_t K1, N1, N2, act1, act2, reserved0;
+    int64_t rows;
+} fd_b2b_params;
+int32_t fd_conv1x1_b2b_f32(const fd_b2b_params* p, fd_stream_t stream);
+/* Accumulators per output pixel the FD_TILE_NARROW kernel instantiation of a Cout-channel layer carries (4, 5 or 8); -1: Cout not in 1..8. */
+int32_t fd_conv_narrow_nco(int32_t Cout);
 int64_t fd_conv_workspace_bytes(int64_t out_rows, int32_t Cout, int32_t ksplit);
 
 /* Weights for FD_TILE_WINOGRAD4: OIHW fp32 [Cout][Cin][3][3] -> U = G g G^T (6x6 per filter, computed in double, rounded once) packed

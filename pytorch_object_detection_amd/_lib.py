@@ -16,6 +16,7 @@ TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (128, 32), 6
          15: (64, 64)}                               # wave-autonomous 64x64 tiles, one wave per workgroup (1x1 stride-1 layers, needs w_frag)
 PATCH_TILE = 13
 WAVE_TILE = 15
+NARROW_TILE = 17    # 3x3 stride-1 pad-1 convs with Cout <= 8 on the vector unit (fd_conv_narrow.hip; ops.pack_conv_weight_narrow); not a member of TILES
 WINO4_TILE = 16     # Winograd F(4x4, 3x3) kernel (own weight packing: ops.pack_conv_weight_wino4); not a member of TILES
 PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2     # include/fcosdet.h FD_PREC_*
 WINO_TILE = 14      # Winograd F(2x2, 3x3) kernel (own weight packing: ops.pack_conv_weight_wino); not a member of TILES
@@ -60,6 +61,16 @@ class Segs(C.Structure):
         return [(self.H[i], self.W[i]) for i in range(self.nseg)]
 
 
+class B2BParams(C.Structure):
+    """fd_b2b_params (include/fcosdet.h): two 1x1 convs back to back in one launch."""
+    _fields_ = [("x", C.c_void_p), ("w1_frag", C.c_void_p), ("scale1", C.c_void_p), ("shift1", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p),
+                ("w2_frag", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("z", C.c_void_p),
+                ("x_cs", C.c_int32), ("x_co", C.c_int32), ("res_cs", C.c_int32), ("res_co", C.c_int32), ("y_cs", C.c_int32), ("y_co", C.c_int32),
+                ("z_cs", C.c_int32), ("z_co", C.c_int32),
+                ("K1", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("act1", C.c_int32), ("act2", C.c_int32), ("reserved0", C.c_int32),
+                ("rows", C.c_int64)]
+
+
 class ConvParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("res", C.c_void_p),
                 ("y", C.c_void_p),
@@ -73,7 +84,9 @@ class ConvParams(C.Structure):
                 ("out_H", C.c_int32), ("out_W", C.c_int32), ("sc_sy", C.c_int32), ("sc_sx", C.c_int32), ("sc_oy", C.c_int32),
                 ("sc_ox", C.c_int32), ("sc_H", C.c_int32), ("sc_W", C.c_int32),
                 ("gate", C.c_void_p), ("gate_cs", C.c_int32), ("reserved0", C.c_int32), ("w_frag", C.c_void_p),
-                ("gn_stats", C.c_void_p), ("gn_groups", C.c_int32), ("gate_act", C.c_int32), ("gate_b", C.c_void_p)]
+                ("gn_stats", C.c_void_p), ("gn_groups", C.c_int32), ("gate_act", C.c_int32), ("gate_b", C.c_void_p),
+                ("x2", C.c_void_p), ("x2_cs", C.c_int32), ("x2_co", C.c_int32), ("x2_Cin", C.c_int32), ("x2_stride", C.c_int32), ("x2_H", C.c_int32),
+                ("x2_W", C.c_int32)]
 
 
 class PackJob(C.Structure):
@@ -97,6 +110,8 @@ _SIGS = {
     "fd_version": (_I, []),
     "fd_last_error": (C.c_char_p, []),
     "fd_conv2d_nhwc_f32": (_I, [C.POINTER(ConvParams), _P]),
+    "fd_conv_narrow_nco": (_I, [_I]),
+    "fd_conv1x1_b2b_f32": (_I, [C.POINTER(B2BParams), _P]),
     "fd_conv_workspace_bytes": (_L, [_L, _I, _I]),
     "fd_conv_wgrad_workspace_bytes": (_L, [_L, _I, _I, _I, _I]),
     "fd_pack_conv_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -18,7 +18,8 @@
 // GNS: the epilogue also writes the row-group statistics of the stored output (fd_conv_params.gn_stats; one- and two-sub-tile tiles only).
 // H1 (with SPLIT): single-plane f16 -- operands rounded to f16 once, ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation: the
 // arithmetic of torch.autocast(float16) convolutions (FD_PREC_F16; the reference trains under AMP, train.py:33,175-181).
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT, bool GATE = false, bool GNS = false, bool H1 = false, bool GEMM = false>
+// DUAL (with GEMM): K-tiles >= a.kt2 are gathered from a second 1x1 source a.x2 (K-concatenation: a bottleneck's conv3 and its downsample conv as one GEMM).
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT, bool GATE = false, bool GNS = false, bool H1 = false, bool GEMM = false, bool DUAL = false>
 __global__ __launch_bounds__(WGM * WGN * 64, (TM * TN == 4) ? ((SPLIT || WGM * WGN == 8) ? 2 : (SB ? 3 : 1)) : 1)
 void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -101,6 +102,20 @@ void conv_igemm_kernel(ConvArgs a) {
                     (unsigned)(a.x_co + chunk * 4)) * 4u;
         if constexpr (GEMM) { if (m >= a.M) a_off[i] = OOB; }
     }
+    // DUAL: the second source's row addresses (single level; output pixel (n, i, j) reads x2[n, s * i, s * j]) and its buffer descriptor
+    unsigned a2_off[DUAL ? AP : 1];
+    const __amdgpu_buffer_rsrc_t x2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), (short)0, (int)(DUAL ? a.x2_bytes : 0u), 0x00020000);
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int m = m0 + lrow + RPP * i;
+            const int hw = a.Ho[0] * a.Wo[0];
+            const int n = m / hw, rem = m - n * hw;
+            const int ho = rem / a.Wo[0], wo = rem - ho * a.Wo[0];
+            const unsigned row2 = (unsigned)((n * a.x2_H + ho * a.x2_stride) * a.x2_W + wo * a.x2_stride);
+            a2_off[i] = (m < a.M) ? (row2 * (unsigned)a.x2_cs + (unsigned)(a.x2_co + chunk * 4)) * 4u : OOB;
+        }
+    }
     unsigned b_off[BP];
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
@@ -123,8 +138,14 @@ void conv_igemm_kernel(ConvArgs a) {
                     if (a.gate_b) rgb[i] = *reinterpret_cast<const float4*>(g_row[i] + gate_bo + kt * 32);
                 }
             }
+            if (DUAL && kt >= a.kt2) {      // (uniform) this K-tile's channels belong to the second source
+                const int kb2 = (kt - a.kt2) * 128;
 #pragma unroll
-            for (int i = 0; i < AP; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)a_off[i], kb, 0));
+                for (int i = 0; i < AP; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x2rsrc, (int)a2_off[DUAL ? i : 0], kb2, 0));
+            } else {
+#pragma unroll
+                for (int i = 0; i < AP; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)a_off[i], kb, 0));
+            }
 #pragma unroll
             for (int j = 0; j < BP; ++j) rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)b_off[j], kb, 0));
             return;
@@ -351,7 +372,8 @@ int fd_launch_splitk_reduce(const ConvArgs& orig, const float* ws, int nslice, i
     return FD_OK;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false, bool GATE = false, bool GNS = false, bool H1 = false, bool GEMM = false>
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false, bool GATE = false, bool GNS = false, bool H1 = false, bool GEMM = false,
+          bool DUAL = false>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int lds_ab = (SB ? 1 : 2) * (BM + BN) * 32 * 4;
@@ -361,7 +383,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT, GATE, GNS, H1, GEMM>;
+    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT, GATE, GNS, H1, GEMM, DUAL>;
     static std::atomic<unsigned> attr_mask{0};       // per kernel instantiation, one bit per device
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles, (a.KT + a.kt_per - 1) / a.kt_per), dim3(NT), lds, stream, b);
@@ -401,6 +423,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
 
     if (p->tile == FD_TILE_WINOGRAD) return fd_launch_conv_wino(p, stream);   // own argument block, own weight packing
     if (p->tile == FD_TILE_WINOGRAD4) return fd_launch_conv_wino4(p, stream);
+    if (p->tile == FD_TILE_NARROW) return fd_launch_conv_narrow(p, stream);
 
     ConvArgs a;
     a.x = p->x; a.w = p->w; a.scale = p->scale; a.shift = p->shift; a.res = p->res; a.y = p->y;
@@ -460,6 +483,28 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     }
     a.Cout_epi = a.Cout; a.kt_per = a.KT; a.slice_stride = 0;
     a.p_halo = 0;
+    a.x2 = nullptr; a.x2_cs = a.x2_co = 0; a.x2_stride = 1; a.x2_H = a.x2_W = 1; a.kt2 = 0; a.x2_bytes = 0;
+    if (p->x2) {         // K-concatenated second source: a bottleneck's conv3 and its downsample conv as one GEMM
+        FD_REQUIRE(!stem && p->KH == 1 && p->KW == 1 && p->pad == 0 && p->stride == 1 && p->in.nseg == 1 && p->Cin % 32 == 0 && p->x2_Cin >= 32 && p->x2_Cin % 32 == 0 &&
+                       p->precision == FD_PREC_F32 && p->ksplit <= 1 && !a.sc_on && p->out_H <= 0 && !p->gate && !p->gn_stats && p->tag != 1,
+                   FD_E_UNSUPPORTED, "fd_conv2d: `x2` needs an fp32 1x1 stride-1 unpadded single-level conv with Cin, x2_Cin multiples of 32, no split-K / scatter / gate / gn_stats");
+        FD_REQUIRE(p->x2_stride >= 1 && p->x2_cs % 4 == 0 && p->x2_co % 4 == 0 && p->x2_cs >= p->x2_co + p->x2_Cin && ((uintptr_t)p->x2 & 15) == 0 &&
+                       (p->in.H[0] - 1) * p->x2_stride < p->x2_H && (p->in.W[0] - 1) * p->x2_stride < p->x2_W,
+                   FD_E_INVAL, "fd_conv2d: `x2` view must be 16-byte addressable and cover the strided samples of a %d x %d output", p->in.H[0], p->in.W[0]);
+        const long x2b = (long)p->in.batch * p->x2_H * p->x2_W * p->x2_cs * 4;
+        FD_REQUIRE(x2b < 0xC0000000L, FD_E_UNSUPPORTED, "fd_conv2d: `x2` buffer exceeds 3 GiB");
+        a.x2 = p->x2; a.x2_cs = p->x2_cs; a.x2_co = p->x2_co; a.x2_stride = p->x2_stride; a.x2_H = p->x2_H; a.x2_W = p->x2_W;
+        a.kt2 = p->Cin / 32; a.x2_bytes = (unsigned)x2b;
+        a.KT = (p->Cin + p->x2_Cin) / 32; a.Kpacked = a.KT * 32; a.kt_per = a.KT;
+        a.w_bytes = (unsigned)((long)p->Cout * a.Kpacked * 4);
+        switch (p->tile) {      // (the single-buffer GEMM-addressed tiles the bottleneck expansions use)
+            case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true, 0, false, false, false, false, true, true>(a, stream);
+            case FD_TILE_64x64: return launch_conv<2, 2, 1, 1, false, false, 0, false, false, false, false, true, true>(a, stream);
+            case FD_TILE_128x128_SB: return launch_conv<2, 2, 2, 2, false, true, 0, false, false, false, false, true, true>(a, stream);
+            case FD_TILE_AUTO: case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true, 0, false, false, false, false, true, true>(a, stream);
+            default: fd_set_error("fd_conv2d: `x2` is built for tiles 64x64, 128x64_SB, 64x128_SB, 128x128_SB (got %d)", p->tile); return FD_E_UNSUPPORTED;
+        }
+    }
     a.gate = nullptr; a.gate_cs = 0; a.gate_hw = 1; a.gate_b = nullptr; a.gate_act = FD_ACT_NONE; a.gate_batch = p->in.batch;
     a.gn_stats = nullptr; a.gn_G = 1; a.gn_cg = 4;
     if (p->gn_stats) {   // row-group statistics of the stored output (GroupNorm fused into the producer)

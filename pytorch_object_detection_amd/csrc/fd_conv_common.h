@@ -34,6 +34,8 @@ struct ConvArgs {
     // row-group statistics of the STORED output (GroupNorm fused into the producer): gn_stats[m][g] = (sum, sum of squares) of the gn_cg
     // channels of group g in output row m, fp32 float2; gn_G groups over the conv's Cout channels
     float* gn_stats; int gn_G, gn_cg;
+    // DUAL kernels: K-tiles >= kt2 come from a second 1x1 source (its own row addresses, sampled with x2_stride): conv3 + downsample as one GEMM
+    const float* x2; int x2_cs, x2_co, x2_stride, x2_H, x2_W, kt2; unsigned x2_bytes;
     int p_halo;    // patch kernel (fd_conv_patch.hip): input rows staged on either side of an M-tile = dil * (max level width + 1)
 };
 
@@ -43,9 +45,10 @@ struct ConvArgs {
 int fd_launch_conv_patch(const ConvArgs& a, int tag, int split, hipStream_t stream);
 // fd_conv_wino.hip: 3x3 stride-1 'same' conv as Winograd F(2x2, 3x3) (FD_TILE_WINOGRAD; p->w is the fd_wino_pack_weights_f32 packing)
 int fd_launch_conv_wino(const fd_conv_params* p, hipStream_t stream);
-// fd_conv_pw.hip: persistent kernel of the GEMM-addressed (1x1 stride-1 unpadded) layers; FD_E_UNSUPPORTED when `tile` has no instantiation
 // fd_conv_wino4.hip: 3x3 stride-1 pad-1 conv as Winograd F(4x4, 3x3) (FD_TILE_WINOGRAD4; p->w is the fd_wino4_pack_weights_f32 packing)
 int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream);
+// fd_conv_narrow.hip: 3x3 stride-1 pad-1 conv with Cout <= 8 on the vector unit (FD_TILE_NARROW; p->w is the [Cin/16][3][4][3][NCO][4] packing)
+int fd_launch_conv_narrow(const fd_conv_params* p, hipStream_t stream);
 // fd_conv_wave.hip: GEMM-addressed layers as wave-autonomous 64 x 64 tiles (FD_TILE_WAVE64); wfrag = fd_pack_conv_weight_wave_f32 packing
 int fd_launch_conv_wave(const ConvArgs& a, const float* wfrag, hipStream_t stream);
 // fd_conv.hip: y = act(sum over the nslice slabs of ws (in slice order) * scale + shift (+ | mask) res) -- the split-K combine launch

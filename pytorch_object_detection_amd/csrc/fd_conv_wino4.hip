@@ -104,42 +104,6 @@ __device__ __forceinline__ void w4_bt_inplace(float4 (&d)[6]) {
 #undef W4_BT1
 }
 
-// the same, one half of the four components at a time (.x .y | .z .w): the main loop spreads a transform over two MFMA groups
-__device__ __forceinline__ void w4_bt_inplace_xy(float4 (&d)[6]) {
-#define W4_BT1(c)                                                              \
-    {                                                                          \
-        const float e42 = d[4].c - 4.f * d[2].c, e31 = d[3].c - 4.f * d[1].c;  \
-        const float f42 = d[4].c - d[2].c, f31 = 2.f * (d[3].c - d[1].c);      \
-        const float t0 = 4.f * d[0].c - 5.f * d[2].c + d[4].c;                 \
-        const float t5 = 4.f * d[1].c - 5.f * d[3].c + d[5].c;                 \
-        d[0].c = t0;                                                           \
-        d[1].c = e42 + e31;                                                    \
-        d[2].c = e42 - e31;                                                    \
-        d[3].c = f42 + f31;                                                    \
-        d[4].c = f42 - f31;                                                    \
-        d[5].c = t5;                                                           \
-    }
-    W4_BT1(x) W4_BT1(y)
-#undef W4_BT1
-}
-__device__ __forceinline__ void w4_bt_inplace_zw(float4 (&d)[6]) {
-#define W4_BT1(c)                                                              \
-    {                                                                          \
-        const float e42 = d[4].c - 4.f * d[2].c, e31 = d[3].c - 4.f * d[1].c;  \
-        const float f42 = d[4].c - d[2].c, f31 = 2.f * (d[3].c - d[1].c);      \
-        const float t0 = 4.f * d[0].c - 5.f * d[2].c + d[4].c;                 \
-        const float t5 = 4.f * d[1].c - 5.f * d[3].c + d[5].c;                 \
-        d[0].c = t0;                                                           \
-        d[1].c = e42 + e31;                                                    \
-        d[2].c = e42 - e31;                                                    \
-        d[3].c = f42 + f31;                                                    \
-        d[4].c = f42 - f31;                                                    \
-        d[5].c = t5;                                                           \
-    }
-    W4_BT1(z) W4_BT1(w)
-#undef W4_BT1
-}
-
 __device__ __forceinline__ void w4_bt(const float4 (&d)[6], float4 (&t)[6]) {
 #define W4_BT1(c)                                                              \
     {                                                                          \
@@ -181,22 +145,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x - px_b), (short)0, (int)(a.x_bytes + (unsigned)px_b), 0x00020000);
     const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, (int)a.u_bytes, 0x00020000);
 
-    // ---- loader roles (round 4): every SIMD carries 1.5 loader instruction streams.  Waves w and w + 4 share a SIMD; waves 0 .. 3 run the full
-    // G / R / C pipeline of patch lines 0 .. 3, the two remaining lines are split by stage over the second wave of each SIMD: wave 4 = G + R of
-    // line 4, wave 5 = C of column 4, wave 6 = G + R of line 5, wave 7 = C of column 5 (C reads the scratch, which any wave may do after the
-    // barrier).  Before: waves 0 .. 5 full streams, i.e. two SIMDs with 2 streams and two with 1, and one barrier per chunk waiting for the former.
-    // role: 0 none (timing builds), 1 full, 2 G + R, 3 C.  (tile lt, channel quad q) per lane; pr = patch row i in G / R, column j' in C.
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int role = (W4_DBG(a) & 1) ? 0 : (wv < 4 ? 1 : ((wv & 1) ? 3 : 2));
-    const bool ldr_g = role == 1 || role == 2;                     // wave-uniform: scalar branches around the loader slices
-    const int q = tid & 1, lt = (tid >> 1) & 31, pr = wv < 4 ? wv : 4 + ((wv - 4) >> 1);
+    // ---- loader role (threads 0 .. 383): (tile lt, line pr, channel quad q); pr = patch row i in G / R, column j' in C ----
+    const bool ldr = __builtin_amdgcn_readfirstlane(tid) < 384 && !(W4_DBG(a) & 1);       // wave-uniform: scalar branches around the loader slices
+    // one line pr per WAVE, (tile, quad) per lane: every scratch / V instruction of a wave then walks 64 different blocks at one in-block offset
+    const int q = tid & 1, lt = (tid >> 1) & 31, pr = min(tid >> 6, 5);
     // patch row pr of tile lt: one base offset per thread; the six columns differ by a uniform pixel stride (buffer soffset) and a validity bit each
     unsigned a_off[6];                                           // a_base where the column is inside the image, OOB elsewhere
     {
         const Tile4 p = wino4_decode(a, tile0 + lt);
         const int H = a.H[p.s], W = a.W[p.s];
         const int hh = (p.h0 - 1 + pr) * a.dil + p.ph;           // (negative exactly when the sub-grid row is)
-        const bool row_ok = ldr_g && p.ok && (unsigned)hh < (unsigned)H;
+        const bool row_ok = ldr && p.ok && (unsigned)hh < (unsigned)H;
         const int rowbase = a.m0[p.s] + (p.n * H + hh) * W;
         const unsigned a_base = ((unsigned)(rowbase + p.w0 * a.dil + p.pw) * (unsigned)a.x_cs + (unsigned)(a.x_co + q * 4)) * 4u;    // column j = 1
 #pragma unroll
@@ -255,29 +214,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     // registers are plenty), then R(0) R(1) | C(0): V[0] holds chunk 0, scratch[1] chunk 1's row pass, the patch registers chunk 2 ----
     {
         float4 p0[6], p1[6];
-        if (ldr_g) { load_G(p0, 0); load_G(p1, min(1, NC - 1)); stage_G(min(2, NC - 1)); }
+        if (ldr) { load_G(p0, 0); load_G(p1, min(1, NC - 1)); stage_G(min(2, NC - 1)); }
 #pragma unroll
         for (int fi = 0; fi < 9; ++fi) load_u(0, fi);
-        if (ldr_g) { row_pass(p0, 0); row_pass(p1, 1); }
+        if (ldr) { row_pass(p0, 0); row_pass(p1, 1); }
     }
     __syncthreads();
-    if (role == 1 || role == 3) stage_C(0);
+    if (ldr) stage_C(0);
     __syncthreads();
 
     // Main loop: one 8-channel chunk per iteration and workgroup barrier.  The loader stages of the NEXT chunks are cut into slices that sit between
     // the nine MFMA groups of this chunk (pinned with sched_barriers): issued in the shadow of the 64-cycle MFMAs instead of in front of them
-    // (as one block in front, loader time and MFMA time simply added: 0.34 + 0.90 ms on the head tower).  The two transforms are 56 VALU
-    // operations each; two waves share a SIMD's vector issue, and a slice that holds a whole transform saturates it for that group (2 x 56 x 4
-    // cycles + the MFMAs' own issue slots = the 512 cycles the pair's MFMAs of a group take): so a transform is cut in two component halves
-    // (.x .y | .z .w), and the second wave of a SIMD runs its half stream in the groups the first leaves empty.
-    //   full  (waves 0-3): g0, g1 R(cc+2) row pass in place in the patch registers | g2 -> scratch[st], C(cc+1) reads its column from scratch[st^1]
-    //                      into the same registers | g3, g4 column pass in place | g5 -> V[st^1], G(cc+3) issues the patch loads
-    //   G + R (waves 4, 6): g6, g7 row pass | g8 -> scratch[st], G(cc+3) (a barrier and six groups before the next row pass consumes them)
-    //   C     (waves 5, 7): g5 reads its column | g6, g7 column pass | g8 -> V[st^1]
-    // One instantiation of the loop per (role, MFMA-live) pair: s_waitcnt counts are in-order counts, and where paths joined after every slice the
-    // compiler had to assume the shorter queue -- waves then waited for their own slice's LDS traffic before every MFMA group.
-    auto main_loop = [&](auto role_c, auto mm_c) {
-    constexpr int ROLE = decltype(role_c)::value;
+    // (as one block in front, loader time and MFMA time simply added: 0.34 + 0.90 ms on the head tower).
+    //   group 0: R(cc+2) row pass in place in the patch registers   group 1: -> scratch[st]
+    //   group 2: C(cc+1) reads its column from scratch[st^1] into the same registers   group 3: column pass in place   group 4: -> V[st^1]
+    //   group 5: G(cc+3) issues the patch loads (four groups and a barrier before group 0 of the next chunk consumes them)
+    // The loop exists twice, for the loader waves and for the two waves without a loader role: s_waitcnt counts are in-order counts, and where the
+    // two paths joined after every slice the compiler had to assume the shorter queue -- the loader waves then waited for their own slice's LDS
+    // traffic before every MFMA group.
+    auto main_loop = [&](auto ldr_c, auto mm_c) {
+    constexpr bool LDR = decltype(ldr_c)::value;
     constexpr bool MM = decltype(mm_c)::value;         // false: this wave's 32-cout block lies past Cout (Cout % 64 in 1..32): no U loads, no MFMAs, only its loader role
     for (int cc = 0; cc < NC; ++cc) {
         const int st = cc & 1;
@@ -298,34 +254,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                 acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, fb.w, acc[fi], 0, 0, 0);
                 load_u(cn, fi);                                        // next chunk's block into the registers just consumed
             }
-            constexpr int R0 = ROLE == 1 ? 0 : 6, R1 = R0 + 1, RW = R0 + 2;            // row pass halves, scratch write (+ G when ROLE == 2)
-            constexpr int CR = ROLE == 1 ? 2 : 5, C0 = CR + 1, C1 = CR + 2, CW = CR + 3;   // column read, column pass halves, V write (+ G when ROLE == 1)
-            if constexpr (ROLE == 1 || ROLE == 2) {
-                if (fi == R0) w4_bt_inplace_xy(pv);
-                if (fi == R1) w4_bt_inplace_zw(pv);
-                if (fi == RW) {
+            if constexpr (LDR) {
+                if (fi == 0) w4_bt_inplace(pv);
+                if (fi == 1) {
                     float* d = Ss + st * W4_SSTAGE + s_wr;
 #pragma unroll
                     for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(d + j * 24) = pv[j];
-                    __builtin_amdgcn_sched_barrier(0);       // (all six writes issued before anything lands in the patch registers again: no second register set)
-                    if constexpr (ROLE == 2) stage_G(min(cc + 3, NC - 1));
                 }
-            }
-            if constexpr (ROLE == 1 || ROLE == 3) {
-                if (fi == CR) {
+                if (fi == 2) {
                     const float* r = Ss + (st ^ 1) * W4_SSTAGE + s_rd;
 #pragma unroll
                     for (int i = 0; i < 6; ++i) pv[i] = *reinterpret_cast<const float4*>(r + i * 4);
                 }
-                if (fi == C0) w4_bt_inplace_xy(pv);
-                if (fi == C1) w4_bt_inplace_zw(pv);
-                if (fi == CW) {
+                if (fi == 3) w4_bt_inplace(pv);
+                if (fi == 4) {
                     float* d = Vs + (st ^ 1) * W4_STAGE + v_wr;
 #pragma unroll
                     for (int i = 0; i < 6; ++i) *reinterpret_cast<float4*>(d + i * 6 * W4_PLANE) = pv[i];
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (ROLE == 1) stage_G(min(cc + 3, NC - 1));
                 }
+                if (fi == 5) stage_G(min(cc + 3, NC - 1));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -334,11 +281,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     }
     };
     const bool mm = __builtin_amdgcn_readfirstlane((int)nb_ok) != 0 && !(W4_DBG(a) & 2);
-    auto run_role = [&](auto role_c) { if (mm) main_loop(role_c, std::true_type{}); else main_loop(role_c, std::false_type{}); };
-    if (role == 1) run_role(std::integral_constant<int, 1>{});
-    else if (role == 2) run_role(std::integral_constant<int, 2>{});
-    else if (role == 3) run_role(std::integral_constant<int, 3>{});
-    else run_role(std::integral_constant<int, 0>{});
+    if (ldr) { if (mm) main_loop(std::true_type{}, std::true_type{}); else main_loop(std::true_type{}, std::false_type{}); }
+    else     { if (mm) main_loop(std::false_type{}, std::true_type{}); else main_loop(std::false_type{}, std::false_type{}); }
 
     // ---- epilogue: two halves of the 32 tiles in turn through the (now free) LDS, both channel blocks and all eight waves at once ----
     // Accumulator rows 0..15 are registers e = 0..7 of every f32x16, rows 16..31 registers 8..15: half h is dead in the register file once written, so

@@ -36,6 +36,10 @@ SE_GATE_IN_PROJECT = _os.environ.get("FD_SE_GATE_FUSED", "1") != "0"     # MBCon
 GN_FUSED_TOWER = _os.environ.get("FD_GN_FUSED_TOWER", "0") == "1"   # "1": the tower's statistics from its Winograd epilogue too (measured neutral, costs the tower launch 5 %)
 GN_FUSED = _os.environ.get("FD_GN_FUSED", "1") != "0"       # "0": HISFCOSHead's GroupNorms as three-pass launches (statistics / finalise / normalise)
 WAVE_TILE = _os.environ.get("FD_WAVE_TILE", "1") != "0"       # "0": the 1x1 layers never see FD_TILE_WAVE64 (wave-autonomous tiles, fd_conv_wave.hip)
+DUAL_DS = _os.environ.get("FD_DUAL_DS", "1") != "0"      # "0": a block's downsample conv as its own launch, its output read back as conv3's residual
+# FD_B2B: the trunk layers (digits) whose conv3 -> next-block conv1 seams run as ONE back-to-back launch (fd_conv1x1_b2b_f32: the 4 * planes wide map is
+# written once and never read back); "" = none
+B2B_LAYERS = _os.environ.get("FD_B2B", "1")
 STEM_KERNEL = _os.environ.get("FD_STEM_KERNEL", "1") != "0"     # "0": the ResNet stem through the generic conv kernel's FD_CONV_STEM mode
 
 
@@ -176,7 +180,8 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
              res: Optional[Rows] = None, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
              Cout: Optional[int] = None, act_c0: int = 0, seg_param=None, tag: int = 0, fold=None,
              gate: Optional[torch.Tensor] = None, gate_b: Optional[torch.Tensor] = None, gate_act: int = ACT_NONE,
-             gn_stats: Optional[torch.Tensor] = None, gn_groups: int = 0) -> Segs:
+             gn_stats: Optional[torch.Tensor] = None, gn_groups: int = 0,
+             x2: Optional[Rows] = None, x2_stride: int = 1, x2_hw: Optional[Tuple[int, int]] = None) -> Segs:
     """conv (+folded BN / bias) (+res) (+act).  `weight`/`bias` override conv's own (fused multi-conv launches);
     `fold` = (scale, shift) overrides the epilogue constants altogether (convs with different BN / bias merged by hand)."""
     dev = plan.device
@@ -188,6 +193,8 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     else:
         pad = pad[0]
     Cin, co = w.shape[1], (w.shape[0] if Cout is None else Cout)
+    if x2 is not None and (plan.precision != "f32" or k != 1 or stride != 1 or segs.nseg != 1 or (Cin - x2.C) % 32 or x2.C % 32 or gate is not None or gn_stats is not None):
+        raise FdError("add_conv: a K-concatenated second input needs an exact-fp32 1x1 stride-1 single-level conv with 32-aligned channel counts")
     if Cin % 4 and x.co == 0 and x.C == x.cs and x.C % 4 == 0 and 0 < x.C - Cin < 4:
         # input width that is not a multiple of 4: the caller staged the map into a zero-padded buffer (padded_input),
         # the weights get matching zero input channels
@@ -195,17 +202,24 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         Cin = x.C
     split = plan.precision == "f16x3" or (plan.precision == "mixed" and k == 1 and stride == 1 and gate is None and gn_stats is None
                                            and Cin % 32 == 0)
+    # <= 8 output channels (the centre-ness / box predictor): the vector-unit kernel, where the map has enough tiles to fill the chip
+    narrow = (ops.NARROW and plan.precision in ("f32", "mixed") and res is None and gate is None and gn_stats is None and w.shape[0] == co
+              and ops.narrow_ok(Cin, co, k, stride, pad, dil) and ops.narrow_tiles(segs) >= ops.NARROW_MIN_TILES)
+    if narrow:
+        split = False
     wino, wino_ks = False, 1
-    if (plan.winograd and ops.wino_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0 and
+    if (not narrow and plan.winograd and ops.wino_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0 and
             (res is None or (res.cs % 4 == 0 and res.co % 4 == 0))):
         wino, wino_ks = ops.wino_choice(segs, Cin, co, dil)
         wino = wino or tag == 1                   # (the head tower -- the roofline kernel -- always runs the Winograd kernel)
     # F(4x4, 3x3) where its cost model beats F(2x2, 3x3) / the direct kernel: exact-fp32 plans only, no gate / statistics epilogue
     wino4, w4_ks = False, 1
-    if (plan.winograd and gate is None and gn_stats is None and ops.wino4_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0
+    if (not narrow and plan.winograd and gate is None and gn_stats is None and ops.wino4_ok(Cin, co, k, stride, pad, dil) and y.cs % 4 == 0 and y.co % 4 == 0
             and (res is None or (res.cs % 4 == 0 and res.co % 4 == 0))):
         wino4, w4_ks = ops.wino4_choice(segs, Cin, co, dil)
-    if wino4:
+    if narrow:
+        wp = ops.pack_conv_weight_narrow(_dev(w, dev))
+    elif wino4:
         wino, wino_ks = True, w4_ks
         wp = ops.pack_conv_weight_wino4(_dev(w, dev))
     elif wino:
@@ -214,7 +228,7 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         wp = ops.pack_conv_weight_f16x3(_dev(w, dev)) if split else ops.pack_conv_weight(_dev(w, dev))
     # GEMM-addressed fp32 layers also get their weights in MFMA fragment order: the wave-autonomous tile (FD_TILE_WAVE64) becomes selectable
     wfrag = None
-    if (not wino and not split and WAVE_TILE and gate is None and ops.wave_ok(Cin, co, k, stride, pad) and act_c0 % 32 == 0
+    if (not wino and not narrow and not split and x2 is None and WAVE_TILE and gate is None and ops.wave_ok(Cin, co, k, stride, pad) and act_c0 % 32 == 0
             and act in (ACT_NONE, ACT_RELU, ACT_SILU) and y.cs % 4 == 0 and y.co % 4 == 0 and (res is None or (res.cs % 4 == 0 and res.co % 4 == 0))):
         if w.shape[0] == co and w.shape[1] == Cin:
             wfrag = ops.pack_conv_weight_wave(_dev(w, dev))
@@ -230,23 +244,30 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     out = ops.conv_out_segs(segs, k, stride, pad, dil)
     # split-K scratch: taken from the pool and handed straight back (stream order makes the sharing safe)
     ws_rows = ops.KSPLIT_MAX * out.rows
-    if gn_stats is not None:
+    if narrow:
+        ws = None
+    elif gn_stats is not None:
         if wino and wino_ks > 1:
             raise FdError("add_conv: gn_stats with a split-K Winograd launch (the caller checks ops.wino_choice first)")
         ws = None                  # (row-group statistics come out of the conv's own epilogue: no split-K, whose combine launch has none)
     elif wino:
         ws = plan.pool.get(wino_ks * out.rows, (co + 3) & ~3) if wino_ks > 1 else None
+    elif x2 is not None:
+        ws = None                  # (no split-K form)
     else:
         ws = plan.pool.get(ws_rows, (co + 3) & ~3) if (plan.autotune and ws_rows * ((co + 3) & ~3) <= 64 * 1024 * 1024) else None
-    call = ops.conv_call(x, segs, wp, y, Cin=Cin, Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
+    call = ops.conv_call(x, segs, wp, y, Cin=Cin - (x2.C if x2 is not None else 0), Cout=co, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                          shift=shift, res=res, act=act, act_c0=act_c0, seg_param=seg_param, tag=tag,
                          precision=1 if split else 0, workspace=ws.buf if ws is not None else None,
-                         tile=(_lib.WINO4_TILE if wino4 else _lib.WINO_TILE) if wino else 0, ksplit=wino_ks if wino else 1, gate=gate, w_frag=wfrag,
-                         gate_b=gate_b, gate_act=gate_act, gn_stats=gn_stats, gn_groups=gn_groups)
+                         tile=_lib.NARROW_TILE if narrow else ((_lib.WINO4_TILE if wino4 else _lib.WINO_TILE) if wino else 0), ksplit=wino_ks if wino else 1,
+                         gate=gate, w_frag=wfrag,
+                         gate_b=gate_b, gate_act=gate_act, gn_stats=gn_stats, gn_groups=gn_groups, x2=x2, x2_stride=x2_stride, x2_hw=x2_hw)
     plan.add(name, call)
     if ws is not None:
         plan.pool.put(ws)
-    if wino:
+    if narrow:
+        plan.tiles[name] = _lib.NARROW_TILE
+    elif wino:
         plan.tiles[name] = (_lib.WINO4_TILE if wino4 else _lib.WINO_TILE) | ((wino_ks if wino_ks > 1 else 0) << 8)
     elif gate is not None:
         plan.tiles[name] = 0                 # (the library picks the tile of a gated conv)
@@ -255,13 +276,19 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         key = f"B{segs.batch}|{hw}|{Cin}>{co}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{x.cs}|ycs{y.cs}"
         if split:
             key = "f16x3|" + key
+        if x2 is not None:
+            key += f"|x2s{x2_stride}c{x2.C}"
         plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co, -(-Cin // 32) * k * k, pair=plan.pair_tuned and tag != 1)
+        if x2 is not None:         # the dual-source loader is built for the tiles the bottleneck expansions use: map the choice onto them, no split-K
+            t = {1: 7, 2: 8, 3: 9, 4: 4, 7: 7, 8: 8, 9: 9}.get(plan.tiles[name] & 0xFF, 8)
+            call.params.tile, call.params.ksplit = t, 1
+            plan.tiles[name] = t
         if gn_stats is not None and (plan.tiles[name] & 0xFF) not in (0, 2, 3, 4, 8, 9, _lib.WAVE_TILE):
             call.params.tile = plan.tiles[name] = 8      # the statistics epilogue exists for the one- / two-sub-tile tiles (and WAVE64 / Winograd)
     plan.flops += 2 * out.rows * co * Cin * k * k
     plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k
     plan.step_info[len(plan.steps) - 1] = {"k": k, "stride": stride, "dil": dil, "Cin": Cin, "Cout": co, "rows": out.rows,
-                                           "family": "winograd3x3" if wino else ("1x1" if k == 1 else f"direct{k}x{k}"),
+                                           "family": "narrow3x3 (vector unit)" if narrow else ("winograd3x3" if wino else ("1x1" if k == 1 else f"direct{k}x{k}")),
                                            # multiplies saved on the matrix pipe: F(4x4,3x3) 36 per 16 outputs, F(2x2,3x3) 16 per 4, direct 9 per output
                                            "mfma_div": 4.0 if wino4 else (2.25 if wino else 1.0)}
     return out
@@ -319,31 +346,78 @@ def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: Lis
     pool.put(y1)
     x, sx = y2, s2
     feats = []
-    for li in (1, 2, 3, 4):
-        layer = getattr(trunk, f"layer{li}")
-        for bi, blk in enumerate(layer):
-            nm = f"backbone.layer{li}.{bi}"
-            planes = blk.conv1.weight.shape[0]
+    blocks_all = [(li, bi, blk) for li in (1, 2, 3, 4) for bi, blk in enumerate(getattr(trunk, f"layer{li}"))]
+    o1_ready = None            # the NEXT block's conv1 output when the previous block's conv3 launch has already produced it (back-to-back GEMMs)
+    for gi, (li, bi, blk) in enumerate(blocks_all):
+        nm = f"backbone.layer{li}.{bi}"
+        planes = blk.conv1.weight.shape[0]
+        so = ops.conv_out_segs(sx, 3, blk.conv2.stride[0], 1, 1)
+        ds = blk.downsample
+        if o1_ready is not None:
+            o1, o1_ready = o1_ready, None       # produced by the previous block's conv3 launch
+        else:
             o1 = pool.get(sx.rows, planes)
             add_conv(plan, nm + ".conv1", x, sx, blk.conv1, o1, bn=blk.bn1, act=ACT_RELU)
-            so = ops.conv_out_segs(sx, 3, blk.conv2.stride[0], 1, 1)
-            o2 = pool.get(so.rows, planes)
-            add_conv(plan, nm + ".conv2", o1, sx, blk.conv2, o2, bn=blk.bn2, act=ACT_RELU)
-            pool.put(o1)
-            if blk.downsample is not None:
-                idt = pool.get(so.rows, 4 * planes)
-                add_conv(plan, nm + ".downsample", x, sx, blk.downsample[0], idt, bn=blk.downsample[1])
-            else:
-                idt = x
+        o2 = pool.get(so.rows, planes)
+        add_conv(plan, nm + ".conv2", o1, sx, blk.conv2, o2, bn=blk.bn2, act=ACT_RELU)
+        pool.put(o1)
+        dual = (DUAL_DS and ds is not None and plan.precision == "f32" and ds[0].kernel_size[0] == 1 and ds[0].bias is None and blk.conv3.bias is None
+                and planes % 32 == 0 and x.C % 32 == 0 and x.cs % 4 == 0 and x.co % 4 == 0 and ds[0].stride[0] == blk.conv2.stride[0])
+        if dual:
+            # out = relu(bn3(conv3(o2)) + bn_d(downsample(x))) as ONE GEMM over K = planes + inplanes: the BatchNorm scales go into the two filter banks,
+            # the shifts add up, the strided input of the downsample conv is the launch's second source -- the identity map is never materialised
+            # (resnet50.py:68-80; 420 MB per 16 images in layer1, written and read back before)
+            f3 = ops.fold_bn(_dev(blk.bn3.weight, dev), _dev(blk.bn3.bias, dev), _dev(blk.bn3.running_mean, dev), _dev(blk.bn3.running_var, dev), blk.bn3.eps)
+            fdn = ops.fold_bn(_dev(ds[1].weight, dev), _dev(ds[1].bias, dev), _dev(ds[1].running_mean, dev), _dev(ds[1].running_var, dev), ds[1].eps)
+            wcat = torch.cat([_dev(blk.conv3.weight, dev) * f3[0][:, None, None, None], _dev(ds[0].weight, dev) * fdn[0][:, None, None, None]], 1)
             out = pool.get(so.rows, 4 * planes)
-            add_conv(plan, nm + ".conv3", o2, so, blk.conv3, out, bn=blk.bn3, act=ACT_RELU, res=idt)
+            add_conv(plan, nm + ".conv3+downsample", o2, so, blk.conv3, out, weight=wcat, fold=(None, (f3[1] + fdn[1]).contiguous()), act=ACT_RELU,
+                     x2=x, x2_stride=ds[0].stride[0], x2_hw=(sx.H[0], sx.W[0]))
+            plan.step_info[len(plan.steps) - 1]["dual"] = (planes, x.C, ds[0].stride[0])
             pool.put(o2)
-            if idt is not x:
-                pool.put(idt)
-            if not (feats and feats[-1][0] is x):  # keep C3/C4/C5 alive
+            if not (feats and feats[-1][0] is x):
                 pool.put(x)
             x, sx = out, so
-        if li >= 2:
+            if li >= 2 and bi == len(getattr(trunk, f"layer{li}")) - 1:
+                feats.append((x, sx))
+            continue
+        if ds is not None:
+            idt = pool.get(so.rows, 4 * planes)
+            add_conv(plan, nm + ".downsample", x, sx, ds[0], idt, bn=ds[1])
+        else:
+            idt = x
+        out = pool.get(so.rows, 4 * planes)
+        nxt = blocks_all[gi + 1][2] if gi + 1 < len(blocks_all) else None
+        n2 = nxt.conv1.weight.shape[0] if nxt is not None else 0
+        if (str(li) in B2B_LAYERS and nxt is not None and plan.precision == "f32" and blk.conv3.bias is None and nxt.conv1.bias is None
+                and nxt.conv1.kernel_size[0] == 1 and nxt.conv1.stride[0] == 1 and nxt.conv1.weight.shape[1] == 4 * planes
+                and ops.b2b_ok(planes, 4 * planes, n2) and all(r.cs % 4 == 0 and r.co % 4 == 0 for r in (o2, out, idt))):
+            # conv3 (+bn3 + identity, ReLU) and the NEXT block's conv1 (+bn1, ReLU) as one launch: `out` is written (next residual, downsample input)
+            # but not read back for the conv1 GEMM (resnet50.py:68-80)
+            o1_ready = pool.get(so.rows, n2)
+            f3 = ops.fold_bn(_dev(blk.bn3.weight, dev), _dev(blk.bn3.bias, dev), _dev(blk.bn3.running_mean, dev), _dev(blk.bn3.running_var, dev), blk.bn3.eps)
+            fn1 = ops.fold_bn(_dev(nxt.bn1.weight, dev), _dev(nxt.bn1.bias, dev), _dev(nxt.bn1.running_mean, dev), _dev(nxt.bn1.running_var, dev), nxt.bn1.eps)
+            wa = ops.pack_conv_weight_wave(_dev(blk.conv3.weight, dev))
+            wb = ops.pack_conv_weight_wave(_dev(nxt.conv1.weight, dev))
+            plan.keep += [f3, fn1, wa, wb]
+            nl, nb_ = blocks_all[gi + 1][0], blocks_all[gi + 1][1]
+            plan.add(f"{nm}.conv3+layer{nl}.{nb_}.conv1",
+                     ops.conv_b2b_call(o2, wa, out, wb, o1_ready, K1=planes, N1=4 * planes, N2=n2, scale1=f3[0], shift1=f3[1], res=idt, act1=ACT_RELU,
+                                       scale2=fn1[0], shift2=fn1[1], act2=ACT_RELU))
+            fl = 2 * so.rows * (4 * planes * planes + n2 * 4 * planes)
+            plan.flops += fl
+            plan.step_flops[len(plan.steps) - 1] = fl
+            plan.step_info[len(plan.steps) - 1] = {"k": 1, "stride": 1, "dil": 1, "Cin": planes, "Cout": 4 * planes, "rows": so.rows, "family": "1x1",
+                                                   "mfma_div": 1.0, "b2b": (4 * planes, n2)}
+        else:
+            add_conv(plan, nm + ".conv3", o2, so, blk.conv3, out, bn=blk.bn3, act=ACT_RELU, res=idt)
+        pool.put(o2)
+        if idt is not x:
+            pool.put(idt)
+        if not (feats and feats[-1][0] is x):  # keep C3/C4/C5 alive
+            pool.put(x)
+        x, sx = out, so
+        if li >= 2 and bi == len(getattr(trunk, f"layer{li}")) - 1:
             feats.append((x, sx))
     return feats  # [(C3, segs), (C4, segs), (C5, segs)]
 
@@ -552,7 +626,9 @@ def _out_convs(plan: Plan, head, tower: Rows, segs: Segs, F: int, ncls: int):
     scales = [float(s.scale.detach().reshape(-1)[0]) for s in head.scale_exp][:segs.nseg]
     rp = head.reg_pred
     rp_pad = rp.dilation[0] * (rp.kernel_size[0] - 1) // 2 if isinstance(rp.padding, str) else rp.padding[0]
-    if plan.winograd and ops.wino_ok(F, 8, rp.kernel_size[0], rp.stride[0], rp_pad, rp.dilation[0]) and ops.wino_choice(segs, F, 8, rp.dilation[0])[0]:
+    narrow = (ops.NARROW and plan.precision in ("f32", "mixed") and ops.narrow_ok(F, 5, rp.kernel_size[0], rp.stride[0], rp_pad, rp.dilation[0])
+              and ops.narrow_tiles(segs) >= ops.NARROW_MIN_TILES)
+    if not narrow and plan.winograd and ops.wino_ok(F, 8, rp.kernel_size[0], rp.stride[0], rp_pad, rp.dilation[0]) and ops.wino_choice(segs, F, 8, rp.dilation[0])[0]:
         # the Winograd kernel writes whole float4s: three zero filters fill the 8-wide buffer (channels 5..7 hold exp(0) = 1, never read);
         # 0.27 -> 0.17 ms against the direct kernel's 128 x 32 tile at Cout = 5
         w = torch.cat([w, torch.zeros(3, *w.shape[1:], dtype=w.dtype, device=w.device)], 0)

@@ -51,12 +51,19 @@ class HisBlock(nn.Module):
                                      torch.cat((self.conv1.bias * sc + sf, self.conv2.bias)), None, segs, 1, 0, 1, ACT_NONE, T.amp_prec())
             x1, x2 = T.act_rows(both[:, :half], ACT_SILU), both[:, half:]
         else:
-            x1 = T.conv_norm_act_rows(self.conv1, self.bn1, x, segs, ACT_SILU)
+            # a SyncBatchNorm's statistics all-reduce is issued by ..._begin and waited for by ..._finish: conv2(x) does not depend on bn1 and is
+            # enqueued under it (and, mirrored, its backward under bn1's backward collective) -- train.py:101-103, VERDICT r3 item 7
+            h1 = T.conv_norm_begin(self.conv1, self.bn1, x, segs, ACT_SILU)
             x2 = T.conv_norm_act_rows(self.conv2, None, x, segs)
-        u = T.conv_norm_act_rows(self.conv1_1, self.bn2, x1, segs, ACT_RELU) if x1 is not None else None
-        if x1 is None or x2 is None or u is None:
+            x1 = T.conv_norm_finish(h1)
+        if x1 is None or x2 is None:
             return None
-        left = torch.cat((u, T.se_rows(self.conv1_2, x1, B, HW)), 1)
+        hu = T.conv_norm_begin(self.conv1_1, self.bn2, x1, segs, ACT_RELU)           # bn2's collective flies under the squeeze-excitation branch
+        v = T.se_rows(self.conv1_2, x1, B, HW)
+        u = T.conv_norm_finish(hu)
+        if u is None:
+            return None
+        left = torch.cat((u, v), 1)
         y = T.conv_norm_act_rows(self.conv3, self.bn3, left, segs, ACT_RELU)
         if y is None:
             return None
@@ -116,13 +123,18 @@ class HalfInvertedStageFPN(PlannedModule):
             return None
         sg = [Segs.make(B, [h]) for h in hw]
         pool = lambda t, lv, add=None: T._PoolAddRows.apply(t, add, (B, hw[lv][0], hw[lv][1], 2, 2, 0))  # noqa: E731
-        a = T.conv_norm_act_rows(self.tf1, self.gn1, T.to_rows(c5), sg[2], ACT_RELU)
-        l4 = T.conv_norm_act_rows(self.tf2, self.gn2, T.to_rows(c4), sg[1], ACT_RELU) if a is not None else None
-        l3 = T.conv_norm_act_rows(self.tf3, self.gn2, T.to_rows(c3), sg[0], ACT_RELU) if l4 is not None else None    # gn2 twice, as the reference
-        if l3 is None:
+        # the three laterals: each SyncBatchNorm's statistics all-reduce (if the model was converted, train.py:103) is in flight while the next lateral's
+        # conv -- or the two max-pools -- is enqueued; finished in the reference's order (gn2 sees tf2's map, then tf3's: its running statistics)
+        ha = T.conv_norm_begin(self.tf1, self.gn1, T.to_rows(c5), sg[2], ACT_RELU)
+        h4 = T.conv_norm_begin(self.tf2, self.gn2, T.to_rows(c4), sg[1], ACT_RELU) if ha is not None else None
+        a = T.conv_norm_finish(ha)
+        h3 = T.conv_norm_begin(self.tf3, self.gn2, T.to_rows(c3), sg[0], ACT_RELU) if h4 is not None else None    # gn2 twice, as the reference
+        l4 = T.conv_norm_finish(h4)
+        if a is None or l4 is None or h3 is None:
             return None
         x4 = pool(a, 2)
         x5 = pool(x4, 3)
+        l3 = T.conv_norm_finish(h3)
         blk = lambda i, t, lv: getattr(self, f"HisBlock{i}").train_forward_rows(t, sg[lv])  # noqa: E731
         t3 = blk(1, a, 2)
         t4 = blk(2, T._UpAddRows.apply(t3, l4, (B, hw[2][0], hw[2][1])), 1) if t3 is not None else None

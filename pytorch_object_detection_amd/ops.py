@@ -17,7 +17,11 @@ from . import _lib
 from ._lib import ACT_EXP, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ConvParams, FdError, Segs, check  # noqa: F401
 
 
+LAUNCHES = [0]      # C-ABI launches enqueued by this process (every wrapper asks for the stream once per launch): train_ops.SYNC_TRACE differences it
+
+
 def _stream() -> int:
+    LAUNCHES[0] += 1
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -169,7 +173,8 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
               workspace: Optional[torch.Tensor] = None, res_mask: bool = False, kw: Optional[int] = None,
               out_hw: Optional[Tuple[int, int]] = None, scatter: Optional[Tuple[int, int, int, int, int, int]] = None,
               gate: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None, gn_stats: Optional[torch.Tensor] = None,
-              gn_groups: int = 0, gate_b: Optional[torch.Tensor] = None, gate_act: int = ACT_NONE) -> Callable[[], None]:
+              gn_groups: int = 0, gate_b: Optional[torch.Tensor] = None, gate_act: int = ACT_NONE,
+              x2: Optional[Rows] = None, x2_stride: int = 1, x2_hw: Optional[Tuple[int, int]] = None) -> Callable[[], None]:
     """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream.
     w_frag: the same weights in FD_TILE_WAVE64's fragment order (pack_conv_weight_wave), which makes that tile selectable."""
     _need_gpu(w_packed, scale, shift)
@@ -206,6 +211,9 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     if w_frag is not None:
         _need_gpu(w_frag)
         p.w_frag = w_frag.data_ptr()
+    if x2 is not None:               # K-concatenated second source (1x1 layers): x2 [batch, x2_hw[0], x2_hw[1]] sampled with x2_stride; w covers Cin + x2.C channels
+        p.x2, p.x2_cs, p.x2_co, p.x2_Cin, p.x2_stride = x2.ptr, x2.cs, x2.co, x2.C, x2_stride
+        p.x2_H, p.x2_W = x2_hw
     if workspace is not None:
         _need_gpu(workspace)
         p.workspace, p.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
@@ -215,12 +223,45 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     p.segs = segs
     fn = _lib.lib().fd_conv2d_nhwc_f32
     ref = C.byref(p)
-    keep = (x, w_packed, y, scale, shift, res, p, workspace, gate, w_frag, gn_stats, gate_b)
+    keep = (x, w_packed, y, scale, shift, res, p, workspace, gate, w_frag, gn_stats, gate_b, x2)
 
     def run(_keep=keep):
         check(fn(ref, _stream()), "fd_conv2d_nhwc_f32")
 
     run.params = p  # type: ignore[attr-defined]   (autotuning rewrites p.tile in place)
+    return run
+
+
+def b2b_ok(K1: int, N1: int, N2: int) -> bool:
+    """Shapes fd_conv1x1_b2b_f32 covers (two 1x1 stride-1 convs back to back: a bottleneck's conv3 and the next block's conv1)."""
+    return K1 % 32 == 0 and N1 % 64 == 0 and N2 in (64, 128)
+
+
+def conv_b2b_call(x: Rows, w1_frag: torch.Tensor, y: Rows, w2_frag: torch.Tensor, z: Rows, *, K1: int, N1: int, N2: int,
+                  scale1: Optional[torch.Tensor] = None, shift1: Optional[torch.Tensor] = None, res: Optional[Rows] = None, act1: int = ACT_NONE,
+                  scale2: Optional[torch.Tensor] = None, shift2: Optional[torch.Tensor] = None, act2: int = ACT_NONE) -> Callable[[], None]:
+    """y = act1(x . W1^T * scale1 + shift1 + res); z = act2(y . W2^T * scale2 + shift2) in ONE launch (fd_conv1x1_b2b_f32): y is written (it is the next
+    residual) but never read back.  w1_frag / w2_frag = pack_conv_weight_wave of the [N1, K1] / [N2, N1] filter banks."""
+    _need_gpu(w1_frag, w2_frag, scale1, shift1, scale2, shift2)
+    p = _lib.B2BParams()
+    p.x, p.w1_frag, p.y, p.w2_frag, p.z = x.ptr, w1_frag.data_ptr(), y.ptr, w2_frag.data_ptr(), z.ptr
+    p.scale1 = scale1.data_ptr() if scale1 is not None else None
+    p.shift1 = shift1.data_ptr() if shift1 is not None else None
+    p.scale2 = scale2.data_ptr() if scale2 is not None else None
+    p.shift2 = shift2.data_ptr() if shift2 is not None else None
+    p.res = res.ptr if res is not None else None
+    p.x_cs, p.x_co, p.y_cs, p.y_co, p.z_cs, p.z_co = x.cs, x.co, y.cs, y.co, z.cs, z.co
+    if res is not None:
+        p.res_cs, p.res_co = res.cs, res.co
+    p.K1, p.N1, p.N2, p.act1, p.act2, p.rows = K1, N1, N2, act1, act2, y.rows
+    fn = _lib.lib().fd_conv1x1_b2b_f32
+    ref = C.byref(p)
+    keep = (x, w1_frag, y, w2_frag, z, scale1, shift1, scale2, shift2, res, p)
+
+    def run(_keep=keep):
+        check(fn(ref, _stream()), "fd_conv1x1_b2b_f32")
+
+    run.params = p  # type: ignore[attr-defined]
     return run
 
 
@@ -462,6 +503,34 @@ def pack_conv_weight_wino4(w: torch.Tensor, scale: Optional[torch.Tensor] = None
     check(_lib.lib().fd_wino4_pack_weights_f32(w.data_ptr(), scale.data_ptr() if (scale is not None and dgrad) else None,
                                                out.data_ptr(), co, ci, 1 if dgrad else 0, _stream()), "fd_wino4_pack_weights_f32")
     return out
+
+
+NARROW = os.environ.get("FD_NARROW", "1") != "0"     # "0": layers of <= 8 output channels stay on the Winograd / direct MFMA kernels
+NARROW_MIN_TILES = 128     # below this many 16 x 16 tiles (batch-1 plans) the MFMA kernels' split-K forms are the lower-latency choice
+
+
+def narrow_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bool:
+    """Shapes FD_TILE_NARROW covers (fd_conv_narrow.hip: the vector-unit kernel for 3x3 convs of <= 8 output channels)."""
+    return k == 3 and stride == 1 and pad == 1 and dil == 1 and 1 <= Cout <= 8 and Cin % 16 == 0
+
+
+def narrow_tiles(segs: Segs) -> int:
+    return sum(segs.batch * -(-h // 16) * -(-w // 16) for h, w in segs.level_hw())
+
+
+def pack_conv_weight_narrow(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout <= 8, Cin, 3, 3] -> [Cin / 16][3 r][4 quads][3 q][4 k][8 couts] (FD_TILE_NARROW; zero filters past Cout): one (chunk, filter row,
+    channel quad, filter column) step is a [4 channels][8 couts] block that the kernel keeps in LDS and reads one row of per lane."""
+    w = w.detach().float()
+    co, ci, kh, kw = w.shape
+    if kh != 3 or kw != 3 or not 1 <= co <= 8 or ci % 16:
+        raise FdError(f"narrow-conv weights need a 3x3 filter bank with Cout <= 8 and Cin % 16 == 0 (got {tuple(w.shape)})")
+    if co < 8:
+        w = torch.cat([w, torch.zeros(8 - co, ci, 3, 3, dtype=w.dtype, device=w.device)], 0)
+    if os.environ.get("FD_NARROW_MODE") == "1":          # (experiment: [step][8 couts][4 k] for the LDS-broadcast variant)
+        return w.reshape(8, ci // 16, 4, 4, 3, 3).permute(1, 4, 2, 5, 0, 3).contiguous()
+    # (co, ch, c4, k, r, q) -> (ch, r, c4, q, k, co)
+    return w.reshape(8, ci // 16, 4, 4, 3, 3).permute(1, 4, 2, 5, 3, 0).contiguous()
 
 
 def wino4_ok(Cin: int, Cout: int, k: int, stride: int, pad: int, dil: int) -> bool:

@@ -393,7 +393,7 @@ class _ConvRows(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight, scale, y = ctx.saved_tensors
         segs, so, stride, pad, dil, act, prec = ctx.geom
-        g = gy.contiguous()
+        g = resolve_pending(gy).contiguous()
         if act == ACT_RELU:
             g = relu_mask(g, y)
         Cin = x.shape[1]
@@ -588,7 +588,7 @@ class _DwRows(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight, scale, y = ctx.saved_tensors
         segs, act = ctx.geom
-        g = gy.contiguous()
+        g = resolve_pending(gy).contiguous()
         if act == ACT_RELU:
             g = relu_mask(g, y)
         Cc = x.shape[1]
@@ -798,39 +798,93 @@ class _BatchNormTrainRows(torch.autograd.Function):
         return gx, dgamma, dbeta, None, None, None, None, None
 
 
-class _SyncBatchNormTrainRows(torch.autograd.Function):
-    """nn.SyncBatchNorm in TRAINING mode + ReLU / SiLU on rows (train.py:101-103 converts the model after the DDP wrap): batch
-    statistics over ALL ranks' rows.  The same HIP kernels as _BatchNormTrainRows, cut in two around ONE all-reduce per direction
-    (fd_batchnorm_sync_fwd_nhwc / _bwd_nhwc): forward all-reduces the fp64 (sum x, sum x^2) of every channel plus the row count
-    -- one flat [2C + 1] buffer --, backward the fp64 (sum dz, sum dz * xhat).  Like torch's SyncBatchNorm the affine gradients come
-    from the local sums (DDP averages them)."""
+# ---- nn.SyncBatchNorm: statistics collectives OFF the critical path (round 4) ----
+# A layer's statistics cannot be batched with another layer's (data dependence), but the all-reduce need not be WAITED for where it is issued:
+#   forward   syncbn_begin() runs phase 1 (this rank's fp64 sums) and issues the all-reduce with async_op=True; the caller enqueues whatever does not
+#             depend on the normalised tensor (HisBlock: conv2(x) beside bn1, the SE branch beside bn2; the FPN laterals beside the previous block),
+#             then syncbn_finish() waits and runs phase 2.
+#   backward  the node issues the all-reduce of (sum dz, sum dz * xhat) asynchronously too and -- when its caller has promised that the ONLY consumer of
+#             its input gradient is one of this module's conv nodes (`defer`) -- returns that gradient UNFINISHED with a pending entry; the consumer
+#             resolves it (wait + phase 2, same stream) on entry.  Autograd runs the nodes created between begin() and finish() in between (bn1's
+#             all-reduce flies under conv2's data / weight gradient kernels, bn2's under the SE backward).
+# With RCCL the collective runs on its own stream and wait() is a stream dependency; with gloo (tests) wait() blocks the host after the independent
+# launches were enqueued.  SYNC_TRACE records, per collective, how many HIP launches were enqueued between issue and wait (tests assert on it).
+SYNC_TRACE: list = []
+_PENDING: dict = {}          # data_ptr of an unfinished input gradient -> closure that finishes it
+
+
+def resolve_pending(g: torch.Tensor) -> torch.Tensor:
+    """Called by the conv nodes' backward on their incoming gradient: finishes it if a SyncBatchNorm node deferred its second phase."""
+    if _PENDING:
+        fin = _PENDING.pop(g.data_ptr(), None)
+        if fin is not None:
+            fin()
+    return g
+
+
+def flush_pending() -> None:
+    """Finish every deferred gradient (safety net, queued at the end of each backward pass that deferred one)."""
+    while _PENDING:
+        _, fin = _PENDING.popitem()
+        fin()
+
+
+class _SyncHandle:
+    __slots__ = ("bn", "x", "act", "group", "buf", "ws", "work", "launches_at_issue", "defer")
+
+
+def syncbn_begin(bn: nn.Module, x: torch.Tensor, act: int = ACT_NONE, defer_backward: bool = False) -> "_SyncHandle":
+    """Phase 1 of nn.SyncBatchNorm's forward on rows + the asynchronous all-reduce of the [2C + 1] fp64 buffer (sums and row count)."""
+    import torch.distributed as dist
+    h = _SyncHandle()
+    h.bn, h.act, h.defer = bn, act, defer_backward
+    h.group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    with torch.no_grad():
+        xd = x.detach().float().contiguous()
+        rows, Cc = xd.shape
+        segs = Segs.make(1, [(rows, 1)])
+        h.ws = ops.groupnorm_workspace(segs, Cc, xd.device)
+        h.buf = torch.empty(2 * Cc + 1, dtype=torch.float64, device=xd.device)
+        fn = _lib.lib().fd_batchnorm_sync_fwd_nhwc
+        ops.check(fn(xd.data_ptr(), Cc, 0, None, None, None, 0, 0, rows, Cc, bn.eps, act, 1, h.buf.data_ptr(), 0.0, h.ws.data_ptr(), ops._stream()),
+                  "fd_batchnorm_sync_fwd_nhwc (stats)")
+        h.buf[2 * Cc] = float(rows)                               # this rank's row count rides behind the 2C sums (a device-side fill, no sync)
+        h.work = dist.all_reduce(h.buf, group=h.group, async_op=True)       # THE forward collective of this layer (C3), not waited for here
+    h.x = x
+    h.launches_at_issue = ops.LAUNCHES[0]
+    return h
+
+
+def syncbn_finish(h: "_SyncHandle") -> torch.Tensor:
+    bn = h.bn
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _SyncBatchNormApply.apply(h.x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, h.act, h)
+
+
+class _SyncBatchNormApply(torch.autograd.Function):
+    """Second half of nn.SyncBatchNorm in TRAINING mode + ReLU / SiLU on rows (train.py:101-103 converts the model after the DDP wrap): waits for the
+    all-reduce syncbn_begin issued, normalises with the GLOBAL statistics, updates the running statistics with the global row count -- read ON THE
+    DEVICE from the all-reduced buffer: ranks whose batches are padded to different H x W hold different row counts (dataset/voc.py:141-171).  Like
+    torch's SyncBatchNorm the affine gradients come from the local sums (DDP averages them)."""
 
     @staticmethod
     @_fwd32
-    def forward(ctx, x, gamma, beta, rmean, rvar, momentum, eps, act, group):
+    def forward(ctx, x, gamma, beta, rmean, rvar, momentum, eps, act, h):
         import ctypes as C
-        import torch.distributed as dist
         x = x.contiguous()
         rows, Cc = x.shape
-        segs = Segs.make(1, [(rows, 1)])
         y = torch.empty_like(x)
-        ws = ops.groupnorm_workspace(segs, Cc, x.device)
         gm, bt = gamma.detach().contiguous(), beta.detach().contiguous()
-        buf = torch.empty(2 * Cc + 1, dtype=torch.float64, device=x.device)
+        SYNC_TRACE.append(("fwd", ops.LAUNCHES[0] - h.launches_at_issue))
+        h.work.wait()
         fn, st = _lib.lib().fd_batchnorm_sync_fwd_nhwc, ops._stream()
-        ops.check(fn(x.data_ptr(), Cc, 0, None, None, None, 0, 0, rows, Cc, eps, act, 1, buf.data_ptr(), 0.0, ws.data_ptr(), st),
-                  "fd_batchnorm_sync_fwd_nhwc (stats)")
-        buf[2 * Cc] = float(rows)                                # this rank's row count rides behind the 2C sums (a device-side fill, no sync)
-        dist.all_reduce(buf, group=group)                       # THE forward collective of this layer (C3)
-        # The GLOBAL row count is buf[2C] AFTER the all-reduce and is read ON THE DEVICE (total_rows = -1): ranks hold different row counts
-        # whenever their batches are padded to different H x W (dataset/voc.py:141-171), so rows * world_size would be wrong -- and different
-        # on every rank -- there (ADVICE r3); no .item(), no host synchronisation.
-        ops.check(fn(x.data_ptr(), Cc, 0, gm.data_ptr(), bt.data_ptr(), y.data_ptr(), Cc, 0, rows, Cc, eps, act, 2, buf.data_ptr(),
-                     C.c_double(-1.0), ws.data_ptr(), st), "fd_batchnorm_sync_fwd_nhwc (apply)")
+        ops.check(fn(x.data_ptr(), Cc, 0, gm.data_ptr(), bt.data_ptr(), y.data_ptr(), Cc, 0, rows, Cc, eps, act, 2, h.buf.data_ptr(),
+                     C.c_double(-1.0), h.ws.data_ptr(), st), "fd_batchnorm_sync_fwd_nhwc (apply)")
         if rmean is not None and momentum is not None:
-            ops.batchnorm_update_running_dev(ws, buf[2 * Cc:], Cc, momentum, eps, rmean, rvar)
-        ctx.save_for_backward(x, gm, bt, ws, buf)
-        ctx.geom = (eps, act, group)
+            ops.batchnorm_update_running_dev(h.ws, h.buf[2 * Cc:], Cc, momentum, eps, rmean, rvar)
+        ctx.save_for_backward(x, gm, bt, h.ws, h.buf)
+        ctx.geom = (eps, act, h.group, h.defer)
         return y
 
     @staticmethod
@@ -839,7 +893,7 @@ class _SyncBatchNormTrainRows(torch.autograd.Function):
         import ctypes as C
         import torch.distributed as dist
         x, gm, bt, ws, buf = ctx.saved_tensors
-        eps, act, group = ctx.geom
+        eps, act, group, defer = ctx.geom
         rows, Cc = x.shape
         g = gy.contiguous()
         gx = torch.empty_like(x)
@@ -849,13 +903,27 @@ class _SyncBatchNormTrainRows(torch.autograd.Function):
         nb = _lib.lib().fd_groupnorm_bwd_workspace_bytes(C.byref(segs), Cc)
         bws = torch.empty(nb // 8, dtype=torch.float64, device=x.device)
         sums = torch.empty(2 * Cc + 1, dtype=torch.float64, device=x.device)       # [sum dz | sum dz * xhat | global row count]
-        fn, st = _lib.lib().fd_batchnorm_sync_bwd_nhwc, ops._stream()
+        fn = _lib.lib().fd_batchnorm_sync_bwd_nhwc
         ops.check(fn(x.data_ptr(), Cc, 0, g.data_ptr(), Cc, 0, gm.data_ptr(), bt.data_ptr(), None, 0, 0, dgamma.data_ptr(), dbeta.data_ptr(),
-                     rows, Cc, eps, act, 1, sums.data_ptr(), 0.0, ws.data_ptr(), bws.data_ptr(), st), "fd_batchnorm_sync_bwd_nhwc (sums)")
-        dist.all_reduce(sums[:2 * Cc], group=group)             # THE backward collective of this layer
-        sums[2 * Cc:].copy_(buf[2 * Cc:])                       # the forward's all-reduced row count, device to device
-        ops.check(fn(x.data_ptr(), Cc, 0, g.data_ptr(), Cc, 0, gm.data_ptr(), bt.data_ptr(), gx.data_ptr(), Cc, 0, None, None,
-                     rows, Cc, eps, act, 2, sums.data_ptr(), C.c_double(-1.0), ws.data_ptr(), None, st), "fd_batchnorm_sync_bwd_nhwc (apply)")
+                     rows, Cc, eps, act, 1, sums.data_ptr(), 0.0, ws.data_ptr(), bws.data_ptr(), ops._stream()), "fd_batchnorm_sync_bwd_nhwc (sums)")
+        sums[2 * Cc:].copy_(buf[2 * Cc:])                       # the forward's all-reduced row count, device to device (its own slot: not all-reduced again)
+        work = dist.all_reduce(sums[:2 * Cc], group=group, async_op=True)     # THE backward collective of this layer
+        at_issue = ops.LAUNCHES[0]
+
+        def finish(x=x, g=g, gm=gm, bt=bt, gx=gx, sums=sums, ws=ws, work=work):
+            SYNC_TRACE.append(("bwd", ops.LAUNCHES[0] - at_issue))
+            work.wait()
+            ops.check(fn(x.data_ptr(), Cc, 0, g.data_ptr(), Cc, 0, gm.data_ptr(), bt.data_ptr(), gx.data_ptr(), Cc, 0, None, None,
+                         rows, Cc, eps, act, 2, sums.data_ptr(), C.c_double(-1.0), ws.data_ptr(), None, ops._stream()), "fd_batchnorm_sync_bwd_nhwc (apply)")
+
+        if defer:
+            # the ONLY consumer of gx is one of this module's conv nodes (conv_norm_begin built the chain): it finishes gx on entry (resolve_pending);
+            # the nodes autograd runs before it are enqueued under the collective.  flush_pending at the end of the pass is the safety net.
+            if not _PENDING:
+                torch.autograd.Variable._execution_engine.queue_callback(flush_pending)
+            _PENDING[gx.data_ptr()] = finish
+        else:
+            finish()
         return gx, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -869,14 +937,48 @@ def batchnorm_train_rows(bn: nn.Module, x: torch.Tensor, act: int = ACT_NONE) ->
     """act(bn(x)) with batch statistics on rows; bn.running_mean / running_var / num_batches_tracked are updated in place like
     nn.BatchNorm2d does (check with _bn_train_ok).  An nn.SyncBatchNorm in an initialised process group of more than one rank
     takes its statistics over all ranks (_SyncBatchNormTrainRows: one all-reduce forward, one backward)."""
-    import torch.distributed as dist
+    if _is_sync(bn):
+        return syncbn_finish(syncbn_begin(bn, x, act))          # one-shot form: nothing enqueued between issue and wait
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
+    return _BatchNormTrainRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act)
+
+
+def _is_sync(bn: nn.Module) -> bool:
+    """An nn.SyncBatchNorm in an initialised process group of more than one rank (its statistics span all ranks)."""
+    import torch.distributed as dist
     if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
         group = bn.process_group if bn.process_group is not None else dist.group.WORLD
-        if dist.get_world_size(group) > 1:
-            return _SyncBatchNormTrainRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act, group)
-    return _BatchNormTrainRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act)
+        return dist.get_world_size(group) > 1
+    return False
+
+
+class NormHandle:
+    """What conv_norm_begin returns: either the finished tensor (`y`) or a SyncBatchNorm whose all-reduce is in flight (`sync`)."""
+    __slots__ = ("y", "sync")
+
+    def __init__(self, y=None, sync=None):
+        self.y, self.sync = y, sync
+
+
+def conv_norm_begin(m: nn.Conv2d, bn: Optional[nn.Module], x: torch.Tensor, segs: Segs, act: int = ACT_NONE) -> Optional["NormHandle"]:
+    """conv_norm_act_rows in two halves: everything up to and including the ISSUE of a SyncBatchNorm's statistics all-reduce.  The caller enqueues work
+    that does not need the normalised tensor, then calls conv_norm_finish.  (Any other layer kind is simply computed here.)"""
+    if bn is not None and not bn_is_frozen(bn) and _is_sync(bn):
+        dense, dw = _dense_ok(m, x), _dw_ok(m, x)
+        if _STOCK or not (dense or dw) or not _bn_train_ok(bn, x) or (dw and m.bias is not None):
+            return None
+        pre = conv_rows(m, x, segs, None, ACT_NONE) if dense else dw_rows(m, x, segs, None, ACT_NONE)
+        # the conv node just created is the only consumer of the BatchNorm's input gradient: its backward resolves the deferred second phase
+        return NormHandle(sync=syncbn_begin(bn, pre, act, defer_backward=True))
+    y = conv_norm_act_rows(m, bn, x, segs, act)
+    return None if y is None else NormHandle(y=y)
+
+
+def conv_norm_finish(h: Optional["NormHandle"]) -> Optional[torch.Tensor]:
+    if h is None:
+        return None
+    return h.y if h.sync is None else syncbn_finish(h.sync)
 
 
 def conv_norm_act_rows(m: nn.Conv2d, bn: Optional[nn.Module], x: torch.Tensor, segs: Segs, act: int = ACT_NONE) -> Optional[torch.Tensor]:

@@ -70,6 +70,17 @@ def _worker(rank, world, init_file, out_dir, sync_bn=False):
             assert train_ops.STATS["stock_fallbacks"] == 0                   # no layer of the step left the HIP kernels (FD_STRICT would have raised)
             stat_calls = [c for c in calls if c[0] == torch.float64]
             assert len(stat_calls) >= 2 * 30, len(stat_calls)                # one fp64 all-reduce per SyncBatchNorm forward and one per backward
+            # the collectives are issued asynchronously and waited for where their result is first needed: SYNC_TRACE holds, per
+            # collective in issue order, the number of HIP launches enqueued between its issue and its wait -- independent work under the all-reduce
+            # (HisBlock: conv2 beside bn1, the SE branch beside bn2, forward and -- mirrored by autograd's node order -- backward; the FPN laterals)
+            tr = list(train_ops.SYNC_TRACE)
+            assert len(tr) == len(stat_calls), (len(tr), len(stat_calls))
+            fwd, bwd = [d for k, d in tr if k == "fwd"], [d for k, d in tr if k == "bwd"]
+            assert len(fwd) == len(bwd) >= 30
+            over = sum(d > 0 for d in fwd) + sum(d > 0 for d in bwd)
+            out["sync_overlapped"], out["sync_total"] = over, len(tr)
+            assert 2 * over >= len(tr), (sum(d > 0 for d in fwd), sum(d > 0 for d in bwd), len(tr))
+            assert not train_ops._PENDING                                  # every deferred input gradient was finished by its consumer
             out.update({k: v.cpu() for k, v in model.state_dict().items() if "fpn" in k and ("running" in k or "num_batches" in k)})
         torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
         dist.barrier()

@@ -37,6 +37,8 @@ def test_struct_layout_matches_c():
         offsetof(fd_conv_params, x_cs), offsetof(fd_conv_params, seg_param), offsetof(fd_conv_params, in),
         offsetof(fd_conv_params, tile), offsetof(fd_conv_params, ksplit), offsetof(fd_conv_params, workspace),
         offsetof(fd_conv_params, workspace_bytes), offsetof(fd_conv_params, precision));
+      printf("%zu %zu %zu %zu %zu\n", offsetof(fd_conv_params, x2), offsetof(fd_conv_params, x2_W), sizeof(fd_b2b_params), offsetof(fd_b2b_params, x_cs),
+        offsetof(fd_b2b_params, rows));
       printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(fd_conv_wgrad_params), offsetof(fd_conv_wgrad_params, dw),
         offsetof(fd_conv_wgrad_params, workspace), offsetof(fd_conv_wgrad_params, nsplit), offsetof(fd_conv_wgrad_params, layout),
         offsetof(fd_conv_wgrad_params, scale), offsetof(fd_conv_wgrad_params, in)); return 0; }'''
@@ -46,8 +48,10 @@ def test_struct_layout_matches_c():
     vals = [int(v) for v in subprocess.check_output([exe]).split()]
     P = _lib.ConvParams
     Q = _lib.WgradParams
+    B = _lib.B2BParams
     assert vals == [ctypes.sizeof(_lib.Segs), ctypes.sizeof(P), P.x_cs.offset, P.seg_param.offset, P.segs.offset,
                     P.tile.offset, P.ksplit.offset, P.workspace.offset, P.workspace_bytes.offset, P.precision.offset,
+                    P.x2.offset, P.x2_W.offset, ctypes.sizeof(B), B.x_cs.offset, B.rows.offset,
                     ctypes.sizeof(Q), Q.dw.offset, Q.workspace.offset, Q.nsplit.offset, Q.layout.offset, Q.scale.offset,
                     Q.segs.offset]
 

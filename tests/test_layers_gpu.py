@@ -1245,3 +1245,117 @@ def test_winograd_f4x4_random_shapes_against_the_direct_kernel():
             pass
         err = (a - b).abs()
         assert float(err.max()) < 6e-5 * scale, (case, Cin, Cout, dil, hw, B, ks, float(err.max()), scale)
+
+
+@pytest.mark.parametrize("case", [(256, 5, [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)], 2), (64, 5, [(17, 23), (9, 12), (5, 6), (3, 3), (2, 1)], 3),
+                                  (32, 1, [(33, 16)], 2), (16, 2, [(16, 16), (1, 1)], 1), (48, 4, [(7, 40)], 2), (32, 8, [(18, 18), (15, 17)], 2), (32, 7, [(9, 9)], 1)])
+def test_conv3x3_narrow_on_the_vector_unit(case):
+    """FD_TILE_NARROW (fd_conv_narrow.hip): 3x3 stride-1 pad-1 convs of <= 8 output channels as exact fp32 FMA chains, one thread per output pixel,
+    against F.conv2d in fp64 -- the bench's cnt_logits + reg_pred shape (pyramid of 640 x 640, 256 -> 5), ragged pyramids (partial 16 x 16 tiles, maps
+    smaller than a tile), every padded width (1, 2, 4, 5, 8), channel views whose neighbours are NaN, bias + per-level ScaleExp on channels >= 1."""
+    from pytorch_object_detection_amd import _lib
+    Cin, Cout, hw, B = case
+    gen = torch.Generator().manual_seed(3 * Cin + Cout + len(hw))
+    xs = [torch.randn(B, Cin, h, w, generator=gen) for h, w in hw]
+    wt = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout, generator=gen) * 0.3
+    prm = [1.2, 0.9, 1.1, 0.8, 1.0][:len(hw)]
+    segs = Segs.make(B, hw)
+    ref = []
+    for lv, x in enumerate(xs):
+        y = F.conv2d(x.double(), wt.double(), bias.double(), 1, 1)
+        ref.append(torch.cat([y[:, :1], torch.exp(y[:, 1:] * prm[lv])], 1).float())
+    xb = torch.full((segs.rows, Cin + 8), float("nan"), device=DEV)
+    xb[:, 4:4 + Cin] = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cin) for t in xs]).to(DEV)
+    yb = torch.full((segs.rows, Cout + 3), float("nan"), device=DEV)
+    y = ops.Rows(yb, 2, Cout)                       # (the output view needs no alignment: scalar stores)
+    wp = ops.pack_conv_weight_narrow(wt.to(DEV))
+    assert wp.shape == (Cin // 16, 3, 4, 3, 4, 8) and _lib.lib().fd_conv_narrow_nco(Cout) in (4, 5, 8)
+    run = ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y, Cin=Cin, Cout=Cout, k=3, pad=1, shift=bias.to(DEV), act=ACT_EXP, act_c0=1, seg_param=prm,
+                        tile=_lib.NARROW_TILE)
+    run()
+    got = yb.cpu()
+    assert torch.isnan(got[:, :2]).all() and torch.isnan(got[:, 2 + Cout:]).all(), "wrote outside its channel view"
+    got = got[:, 2:2 + Cout]
+    assert not torch.isnan(got).any(), "an output pixel was never written"
+    for i, ((h, w), r) in enumerate(zip(hw, ref)):
+        g = got[segs.m_start[i]:segs.m_start[i + 1]].reshape(B, h, w, Cout).permute(0, 3, 1, 2)
+        np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=2e-5, atol=5e-6, err_msg=f"level {i}")      # one fp32 fma chain of up to 2 304 terms per output (+ expf)
+    first = yb.clone()
+    run()
+    assert torch.equal(yb.nan_to_num(7.0), first.nan_to_num(7.0))          # bitwise reproducible
+    with pytest.raises(Exception, match="NARROW"):       # 9 output channels / a residual: a clean error, no launch
+        ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(torch.empty(segs.rows, 12, device=DEV), 0, 9), Cin=Cin, Cout=9, k=3, pad=1, tile=_lib.NARROW_TILE)()
+
+
+@pytest.mark.parametrize("case", [(64, 256, 64, 3 * 33 * 17, True), (64, 256, 128, 2 * 40 * 40, True), (128, 512, 128, 1000, True), (32, 64, 64, 77, False),
+                                  (256, 1024, 128, 513, True)])
+def test_conv1x1_back_to_back_is_bit_identical_to_two_launches(case):
+    """fd_conv1x1_b2b_f32 (fd_conv_b2b.hip): a bottleneck's conv3 + BN + residual + ReLU and the next block's conv1 + BN + ReLU in one launch -- the wide
+    map y is written once and never read back.  Both outputs must equal, BIT FOR BIT, two fd_conv2d launches on the workgroup-tiled kernel (same k
+    order per GEMM), on row counts that are no multiple of the 64 / 32-row wave tile, channel views with NaN neighbours, with and without a residual."""
+    K1, N1, N2, M, use_res = case
+    gen = torch.Generator().manual_seed(K1 + N1 + N2 + M)
+    segs = Segs.make(1, [(M, 1)])
+    xb = torch.full((M, K1 + 8), float("nan"), device=DEV)
+    xb[:, 4:4 + K1] = torch.randn(M, K1, generator=gen).to(DEV)
+    x = ops.Rows(xb, 4, K1)
+    w1 = (torch.randn(N1, K1, 1, 1, generator=gen) / K1 ** 0.5).to(DEV)
+    w2 = (torch.randn(N2, N1, 1, 1, generator=gen) / N1 ** 0.5).to(DEV)
+    s1, t1 = (torch.rand(N1, generator=gen) + 0.5).to(DEV), torch.randn(N1, generator=gen).to(DEV)
+    s2, t2 = (torch.rand(N2, generator=gen) + 0.5).to(DEV), torch.randn(N2, generator=gen).to(DEV)
+    rb = torch.full((M, N1 + 4), float("nan"), device=DEV)
+    rb[:, :N1] = torch.randn(M, N1, generator=gen).to(DEV)
+    res = ops.Rows(rb, 0, N1) if use_res else None
+    # reference: two launches of the workgroup-tiled kernel
+    y0, z0 = ops.new_rows(M, N1, DEV), ops.new_rows(M, N2, DEV)
+    ops.conv_call(x, segs, ops.pack_conv_weight(w1), y0, Cin=K1, Cout=N1, k=1, scale=s1, shift=t1, res=res, act=ACT_RELU, tile=4)()
+    ops.conv_call(y0, segs, ops.pack_conv_weight(w2), z0, Cin=N1, Cout=N2, k=1, scale=s2, shift=t2, act=ACT_RELU, tile=4)()
+    yb = torch.full((M, N1 + 8), float("nan"), device=DEV)
+    zb = torch.full((M, N2 + 8), float("nan"), device=DEV)
+    y, z = ops.Rows(yb, 4, N1), ops.Rows(zb, 4, N2)
+    ops.conv_b2b_call(x, ops.pack_conv_weight_wave(w1), y, ops.pack_conv_weight_wave(w2), z, K1=K1, N1=N1, N2=N2, scale1=s1, shift1=t1, res=res, act1=ACT_RELU,
+                      scale2=s2, shift2=t2, act2=ACT_RELU)()
+    assert torch.isnan(yb[:, :4]).all() and torch.isnan(yb[:, 4 + N1:]).all() and torch.isnan(zb[:, :4]).all() and torch.isnan(zb[:, 4 + N2:]).all()
+    assert torch.equal(y.tensor(), y0.tensor()), float((y.tensor() - y0.tensor()).abs().max())
+    assert torch.equal(z.tensor(), z0.tensor()), float((z.tensor() - z0.tensor()).abs().max())
+    # and both are the convolution: fp64 reference
+    yr = torch.relu(x.tensor().double() @ w1.view(N1, K1).double().t() * s1.double() + t1.double() + (res.tensor().double() if use_res else 0))
+    np.testing.assert_allclose(y.tensor().cpu().numpy(), yr.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    with pytest.raises(Exception, match="b2b"):          # N2 = 96: a clean error, no launch
+        ops.conv_b2b_call(x, ops.pack_conv_weight_wave(w1), y, ops.pack_conv_weight_wave(w2), ops.new_rows(M, 96, DEV), K1=K1, N1=N1, N2=96)()
+
+
+@pytest.mark.parametrize("case", [(64, 64, 256, 1, (33, 17), 8), (128, 256, 512, 2, (20, 24), 9), (256, 512, 1024, 2, (9, 7), 4), (512, 1024, 2048, 2, (5, 5), 7),
+                                  (32, 96, 72, 1, (11, 13), 0)])
+def test_conv1x1_with_a_k_concatenated_second_source(case):
+    """fd_conv_params.x2 (the DUAL instantiations of the GEMM-addressed kernel): y = relu(o2 . Wa^T + x[::s, ::s] . Wb^T + shift) in one launch -- a
+    bottleneck's conv3 and its (strided) downsample conv with the BatchNorm scales folded into the filter banks (resnet50.py:68-80) -- against fp64, on
+    every tile the loader is built for, channel views with NaN neighbours, row counts that are no multiple of the tile."""
+    K1, K2, N, s2, (Ho, Wo), tile = case
+    B = 3
+    gen = torch.Generator().manual_seed(K1 + K2 + N + tile)
+    H2, W2 = s2 * Ho + (s2 - 1), s2 * Wo            # the strided source may be larger than stride * output (odd input sizes)
+    a = torch.randn(B, K1, Ho, Wo, generator=gen)
+    b = torch.randn(B, K2, H2, W2, generator=gen)
+    wa = torch.randn(N, K1, 1, 1, generator=gen) / (K1 + K2) ** 0.5
+    wb = torch.randn(N, K2, 1, 1, generator=gen) / (K1 + K2) ** 0.5
+    shift = torch.randn(N, generator=gen)
+    ref = torch.relu(F.conv2d(a.double(), wa.double()) + F.conv2d(b.double(), wb.double(), stride=s2)[:, :, :Ho, :Wo] + shift.double()[None, :, None, None]).float()
+    segs = Segs.make(B, [(Ho, Wo)])
+    ab = torch.full((segs.rows, K1 + 8), float("nan"), device=DEV)
+    ab[:, 4:4 + K1] = a.permute(0, 2, 3, 1).reshape(-1, K1).to(DEV)
+    bb = torch.full((B * H2 * W2, K2 + 4), float("nan"), device=DEV)
+    bb[:, :K2] = b.permute(0, 2, 3, 1).reshape(-1, K2).to(DEV)
+    yb = torch.full((segs.rows, N + 8), float("nan"), device=DEV)
+    wp = ops.pack_conv_weight(torch.cat([wa, wb], 1).to(DEV))
+    run = ops.conv_call(ops.Rows(ab, 4, K1), segs, wp, ops.Rows(yb, 4, N), Cin=K1, Cout=N, k=1, shift=shift.to(DEV), act=ACT_RELU, tile=tile,
+                        x2=ops.Rows(bb, 0, K2), x2_stride=s2, x2_hw=(H2, W2))
+    run()
+    got = yb.cpu()
+    assert torch.isnan(got[:, :4]).all() and torch.isnan(got[:, 4 + N:]).all() and not torch.isnan(got[:, 4:4 + N]).any()
+    g = got[:, 4:4 + N].reshape(B, Ho, Wo, N).permute(0, 3, 1, 2)
+    np.testing.assert_allclose(g.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    with pytest.raises(Exception, match="x2"):       # split-K with a second source: a clean error
+        ops.conv_call(ops.Rows(ab, 4, K1), segs, wp, ops.Rows(yb, 4, N), Cin=K1, Cout=N, k=1, tile=8, ksplit=2, workspace=torch.empty(1 << 22, device=DEV),
+                      x2=ops.Rows(bb, 0, K2), x2_stride=s2, x2_hw=(H2, W2))()

@@ -159,6 +159,20 @@ def test_plan_runs_the_recorded_layer_graph(golden):
     steps = [i for i, n in enumerate(names) if n.startswith("backbone.") and n != "backbone.maxpool"]
     assert names[steps[0]] == "backbone.conv1" and sum(n == "backbone.maxpool" for n in names) == 1
     by_name = {names[i]: plan.step_info[i] for i in steps[1:]}
+    # a block's conv3 and its downsample conv as ONE K-concatenated GEMM (round 4, fd_conv_params.x2): it stands for both recorded convs
+    for name in [n for n in by_name if n.endswith(".conv3+downsample")]:
+        info = by_name.pop(name)
+        k1, k2, s2 = info["dual"]
+        base = name[:-len(".conv3+downsample")]
+        by_name[base + ".conv3"] = dict(info, Cin=k1)
+        by_name[base + ".downsample"] = dict(info, Cin=k2, stride=s2)
+    # a bottleneck's conv3 and the next block's conv1 as ONE back-to-back launch (round 4, fd_conv1x1_b2b_f32): it stands for both recorded convs
+    for name in [n for n in by_name if ".conv3+layer" in n]:
+        info = by_name.pop(name)
+        first, second = name.split("+")
+        n1, n2 = info["b2b"]
+        by_name[first] = dict(info)
+        by_name["backbone." + second] = dict(info, Cin=n1, Cout=n2)
     assert len(by_name) == len(want) - 1
     seq = want[1:]
     # walk the table: blocks are conv1, conv2, conv3 [, down]

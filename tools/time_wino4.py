@@ -38,5 +38,6 @@ bench("layer2.conv2 128>128 80x80", 16, [(80, 80)], 128, 128)
 bench("layer1.conv2 64>64 160x160", 16, [(160, 160)], 64, 64)
 bench("layer4.conv2 512>512 20x20", 16, [(20, 20)], 512, 512)
 bench("cls_logits 256>80 pyramid", 16, pyr, 256, 80)
+bench("cnt_reg 256>8 pyramid", 16, pyr, 256, 8)
 bench("HisBlock3.conv4 256>256 80x80 dil2", 16, [(80, 80)], 256, 256, 2)
 bench("HisBlock2.conv4 256>256 40x40 dil2", 16, [(40, 40)], 256, 256, 2)
