@@ -281,6 +281,13 @@ int32_t fd_pack_conv_weights_batch_f32(const fd_pack_job* jobs_dev, int32_t n_jo
 int32_t fd_stem7x7_nhwc4(const float* x4, const float* w, const float* scale, const float* shift, float* y, int32_t y_cs, int32_t y_co,
                          int32_t N, int32_t H, int32_t W, int32_t act, fd_stream_t stream);
 
+/* The stem WITH the max-pool that follows it (torchvision resnet50: conv1 + bn1 + relu + maxpool(3, stride 2, padding 1)) in one launch:
+ * y_pooled [N][Hp][Wp] rows, 64 channels, Hp = (H/2 - 1) / 2 + 1.  The 64-channel stride-2 map is never written.  Windows that straddle two workgroups
+ * are combined by integer atomicMax on the bits of the (non-negative, post-ReLU) values, starting from zeros that a first small launch of the same call
+ * writes to exactly those pixels (two launches on `stream`; nothing outside y_pooled's 64-channel view is touched).  Bitwise reproducible. */
+int32_t fd_stem7x7_pool_nhwc4(const float* x4, const float* w, const float* scale, const float* shift, float* y_pooled, int32_t y_cs, int32_t y_co,
+                              int32_t N, int32_t H, int32_t W, fd_stream_t stream);
+
 /* [N][3][H][W] fp32 (NCHW, the reference's input layout, dataset/voc.py:141-173) -> [N][H][W][4] (c=3 zero) */
 int32_t fd_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, fd_stream_t stream);
 /* Input pipeline tail on the device: uint8 [N][H][W][3] images, already resized and zero padded on

@@ -124,6 +124,7 @@ _SIGS = {
     "fd_wino_pack_weights_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fd_conv2d_bwd_weight_f32": (_I, [C.POINTER(WgradParams), _P]),
     "fd_stem7x7_nhwc4": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fd_stem7x7_pool_nhwc4": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fd_nchw3_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _P]),
     "fd_nhwc_to_nchw": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),
     "fd_preprocess_u8_nhwc4": (_I, [_P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),

@@ -242,11 +242,7 @@ extern "C" int32_t fd_conv1x1_b2b_f32(const fd_b2b_params* p, fd_stream_t stream
     a.x_bytes = (unsigned)xb;
     a.y_bytes = (unsigned)((long)p->rows * p->y_cs * 4); a.z_bytes = (unsigned)((long)p->rows * p->z_cs * 4);
     a.res_bytes = p->res ? (unsigned)((long)p->rows * p->res_cs * 4) : 0u;
-    static const int tm1 = getenv("FD_B2B_TM1") ? atoi(getenv("FD_B2B_TM1")) : 0;     // (experiment: 32-row waves for N2 = 64 too)
-    if (p->N2 == 64 && tm1) {
-        const unsigned blocks = (unsigned)((p->rows + 31) / 32);
-        hipLaunchKernelGGL((conv1x1_b2b_kernel<1, 2>), dim3(blocks), dim3(64), 2 * 32 * 32 * 4, stream, a, p->w1_frag, p->w2_frag);
-    } else if (p->N2 == 64) {
+    if (p->N2 == 64) {      // 64-row waves (32-row waves for N2 = 64 measured slower: DESIGN 4.1h)
         const unsigned blocks = (unsigned)((p->rows + 63) / 64);
         hipLaunchKernelGGL((conv1x1_b2b_kernel<2, 2>), dim3(blocks), dim3(64), 2 * 64 * 32 * 4, stream, a, p->w1_frag, p->w2_frag);
     } else {

@@ -23,7 +23,6 @@ struct NarrowArgs {
     const float* x; const float* w; const float* scale; const float* shift; float* y;
     int x_cs, x_co, y_cs, y_co;
     int Cout, act, act_c0;
-    int mode;                     // experiment: 0 = weights [step][4 k][8 couts], DPP quad broadcast; 1 = weights [step][8 couts][4 k], LDS broadcast reads + plain FMAs
     int NCH;                      // 16-channel chunks
     int nseg, batch;
     int H[FD_MAX_SEG], W[FD_MAX_SEG], TH[FD_MAX_SEG], TW[FD_MAX_SEG];   // TH x TW tiles of 16 x 16 outputs per image
@@ -50,7 +49,7 @@ __device__ __forceinline__ void nr_fmac_quad(float& acc, float w, float v) {
     if constexpr (K == 3) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(v));
 }
 
-template <int NCO, int MODE = 0>
+template <int NCO>
 __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(NarrowArgs a) {
     __shared__ __attribute__((aligned(16))) float patch[NR_P * NR_P * NR_PITCH];
     __shared__ __attribute__((aligned(16))) float wts[NR_WCHUNK];
@@ -108,20 +107,7 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(NarrowArgs a) {
         store();
         __syncthreads();
         if (ch + 1 < a.NCH) load(ch + 1);      // the next chunk's patch travels under this chunk's FMAs
-        if constexpr (MODE == 1) {
-#pragma unroll
-            for (int st = 0; st < 36; ++st) {
-                const int r = st / 12, c4 = (st / 3) & 3, q = st % 3;
-                const float4 v = *reinterpret_cast<const float4*>(my + (r * NR_P + q) * NR_PITCH + c4 * 4);
-                const float* wb = wts + st * NR_WSTEP;       // every lane reads the same addresses: LDS broadcast
-#pragma unroll
-                for (int co = 0; co < NCO; ++co) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(wb + co * 4);
-                    acc[co] = fmaf(v.x, w4.x, acc[co]); acc[co] = fmaf(v.y, w4.y, acc[co]);
-                    acc[co] = fmaf(v.z, w4.z, acc[co]); acc[co] = fmaf(v.w, w4.w, acc[co]);
-                }
-            }
-        } else {
+        {
             // 36 steps (r, c4, q), software-pipelined by hand: the operands of step st + 1 are requested from LDS before the FMAs of step st go out
             // (the FMAs are asm statements: left alone the compiler reads a step's operands right in front of them and waits out the LDS latency 36 times)
             float4 va[2], wa[2], wb_[2];
@@ -209,17 +195,6 @@ int fd_launch_conv_narrow(const fd_conv_params* p, hipStream_t stream) {
     const long rows = p->in.m_start[p->in.nseg];
     FD_REQUIRE(rows * p->x_cs < (1L << 31) && rows * p->y_cs < (1L << 31), FD_E_UNSUPPORTED, "fd_conv2d: tensor exceeds 2^31 elements");
     const dim3 grid((unsigned)t), block(256);
-    static const int mode = getenv("FD_NARROW_MODE") ? atoi(getenv("FD_NARROW_MODE")) : 0;     // (experiment; the packing must match: ops.pack_conv_weight_narrow)
-    a.mode = mode;
-    if (mode == 1) {
-        switch (fd_conv_narrow_nco(p->Cout)) {
-            case 4: hipLaunchKernelGGL((conv3x3_narrow_kernel<4, 1>), grid, block, 0, stream, a); break;
-            case 5: hipLaunchKernelGGL((conv3x3_narrow_kernel<5, 1>), grid, block, 0, stream, a); break;
-            default: hipLaunchKernelGGL((conv3x3_narrow_kernel<8, 1>), grid, block, 0, stream, a); break;
-        }
-        FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (narrow 3x3 on the vector unit, LDS-broadcast weights)");
-        return FD_OK;
-    }
     switch (fd_conv_narrow_nco(p->Cout)) {
         case 4: hipLaunchKernelGGL(conv3x3_narrow_kernel<4>, grid, block, 0, stream, a); break;
         case 5: hipLaunchKernelGGL(conv3x3_narrow_kernel<5>, grid, block, 0, stream, a); break;

@@ -16,6 +16,16 @@
 //     current tile's MFMAs;
 //   * epilogue: BN scale / shift + ReLU, each 32 x 32 block transposed through a per-wave LDS stage into 16-byte NHWC stores.
 // Measured (MI355X, 16 x 640 x 640): 0.50 -> 0.35 ms (62 -> 87 TFLOP/s in the stem's 30.8 algorithmic GFLOP).
+//
+// POOL = true (round 4, fd_stem7x7_pool_nhwc4): the 3x3 stride-2 pad-1 MAX-POOL that follows the stem (torchvision resnet50.maxpool) in the epilogue.
+// As two launches the 64-channel 320 x 320 map (420 MB per 16 images) is written by the stem and read back by the pool; here a workgroup walks its
+// 4 tiles DOWN the image, keeps a tile's outputs in LDS (32 channels at a time, in the patch / transposition area), and emits pooled pixels:
+//   * a window whose 3 x 3 conv outputs all lie in this workgroup's tiles -- the row above a tile comes from a carry of the previous tile's last
+//     row kept in LDS -- is stored once (16-byte stores);
+//   * a window that straddles a workgroup boundary (the first row of the strip, the left column, and the contributions of the strip's last row /
+//     the tile's last column to the neighbours' windows) is combined with the neighbours' parts by integer atomicMax on the float bits: the values are
+//     ReLU outputs (>= +0), for which the integer order IS the float order and 0 is the identity -- a small launch zero-fills exactly those pixels first;
+//     max is order-independent: bitwise reproducible.  12 % of the pooled pixels take that path (every workgroup-strip boundary row, every 16th column).
 #include "fd_conv_common.h"
 
 #define ST_TH 8
@@ -32,11 +42,14 @@ struct StemArgs {
     int y_cs, y_co, N, H, W, Ho, Wo, act, tiles_h, tiles_w;
 };
 
+template <bool POOL>
 __global__ __launch_bounds__(256, 2) void stem7x7_kernel(StemArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Ps = reinterpret_cast<float*>(smem);                   // [21][208]
-    float* Ws = Ps + ST_PR * ST_PITCH;                            // [7 * 22][64]
-    float* St = Ws + 7 * ST_KR * ST_CO;                           // per-wave transpose stages (4 x 4 KB)
+    float* Ws = reinterpret_cast<float*>(smem);                   // [7 * 22][64]
+    float* Ps = Ws + 7 * ST_KR * ST_CO;                           // [21][208]
+    float* St = Ps + ST_PR * ST_PITCH;                            // per-wave transpose stages (4 x 4 KB)
+    float* Cb = Ps;                                               // POOL: [8 rows][32 cols][32 channels] of this tile's outputs (patch + stages: 8 464 >= 8 192 floats)
+    float* Cy = St + 4 * 1024;                                    // POOL: carry = the previous tile's last output row, [32 cols][64 channels]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     // ---- the filter bank once per workgroup; ST_TPW consecutive output tiles per workgroup amortise it ----
@@ -48,9 +61,15 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(StemArgs a) {
     float4 pv[NPX];
     const int ntile = a.N * a.tiles_h * a.tiles_w;
     auto tile_pos = [&](int t, int& n, int& ho0, int& wo0) {
-        const int tw = t % a.tiles_w; t /= a.tiles_w;
-        const int th = t % a.tiles_h;
-        n = t / a.tiles_h; ho0 = th * ST_TH; wo0 = tw * ST_TW;
+        if constexpr (POOL) {   // consecutive tiles walk DOWN a 32-column strip (a workgroup's ST_TPW tiles share the carry row); strips of ST_TPW tiles never cross an image
+            const int th = t % a.tiles_h; t /= a.tiles_h;
+            const int tw = t % a.tiles_w;
+            n = t / a.tiles_w; ho0 = th * ST_TH; wo0 = tw * ST_TW;
+        } else {
+            const int tw = t % a.tiles_w; t /= a.tiles_w;
+            const int th = t % a.tiles_h;
+            n = t / a.tiles_h; ho0 = th * ST_TH; wo0 = tw * ST_TW;
+        }
     };
     auto load_patch = [&](int t) {            // global -> registers (zero outside the image)
         int n, ho0, wo0;
@@ -118,6 +137,69 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(StemArgs a) {
             a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
         }
         __syncthreads();                    // everyone is done reading the patch
+        if constexpr (POOL) {
+            const bool first = (t == t0), last = (t + 1 == t1);
+            const int Hp = (a.Ho - 1) / 2 + 1, Wp = (a.Wo - 1) / 2 + 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nn0 = j * 32;
+                const float sc = a.scale ? a.scale[nn0 + l31] : 1.0f;
+                const float sf = a.shift ? a.shift[nn0 + l31] : 0.0f;
+                // this half's outputs -> Cb[row][col][32 ch]; positions outside the image hold 0 (the identity of max over ReLU outputs)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = 2 * wave + i;
+                    const bool rok = ho0 + row < a.Ho;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int col = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        const float v = acc[i][j][e] * sc + sf;
+                        Cb[(row * 32 + col) * 32 + l31] = (rok && wo0 + col < a.Wo && v > 0.f) ? v : 0.f;
+                    }
+                }
+                __syncthreads();
+                // pooled pixels: centre rows cr = 0, 2, 4, 6 (+ 8: the strip's last row seen from the window below), centre columns cc = 0 .. 30 (+ 32)
+                for (int it = tid; it < 5 * 17 * 8; it += 256) {
+                    const int c4 = it & 7, pc = (it >> 3) % 17, pr = (it >> 3) / 17;
+                    const int cr = 2 * pr, cc = 2 * pc;
+                    if (pr == 4 && !last) continue;                       // (the next tile of this workgroup takes row 7 from the carry)
+                    const int ph = (ho0 + cr) >> 1, pw = (wo0 + cc) >> 1;
+                    if (ph >= Hp || pw >= Wp) continue;
+                    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int dr = -1; dr <= 1; ++dr) {
+                        const int r = cr + dr;
+                        if (r > 7) continue;
+                        if (r < 0 && first) continue;                      // (the row above the strip belongs to another workgroup)
+#pragma unroll
+                        for (int dc = -1; dc <= 1; ++dc) {
+                            const int c = cc + dc;
+                            if (c < 0 || c > 31) continue;
+                            const float4 v = r < 0 ? *reinterpret_cast<const float4*>(Cy + c * 64 + nn0 + c4 * 4)
+                                                   : *reinterpret_cast<const float4*>(Cb + (r * 32 + c) * 32 + c4 * 4);
+                            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                        }
+                    }
+                    const bool whole = (pr < 4) && (cr > 0 || !first || ho0 == 0) && (pc < 16) && (cc > 0 || wo0 == 0);
+                    float* yp = a.y + ((size_t)(n * Hp + ph) * Wp + pw) * a.y_cs + a.y_co + nn0 + c4 * 4;
+                    if (whole) {
+                        *reinterpret_cast<float4*>(yp) = m;
+                    } else {      // a window shared with a neighbouring workgroup: integer max on the bits of non-negative floats
+                        unsigned* up = reinterpret_cast<unsigned*>(yp);
+                        atomicMax(up + 0, __float_as_uint(m.x)); atomicMax(up + 1, __float_as_uint(m.y));
+                        atomicMax(up + 2, __float_as_uint(m.z)); atomicMax(up + 3, __float_as_uint(m.w));
+                    }
+                }
+                // carry: this tile's last row, for the first window row of the next tile (this half's 32 channels) -- picked up into a register beside the pooling
+                // reads and written behind the barrier that ends them (the old carry is still being read until then; one barrier less per half)
+                const float4 cyv = *reinterpret_cast<const float4*>(Cb + (7 * 32 + (tid >> 3)) * 32 + (tid & 7) * 4);
+                __syncthreads();
+                if (!last) *reinterpret_cast<float4*>(Cy + (tid >> 3) * 64 + nn0 + (tid & 7) * 4) = cyv;
+            }
+            __syncthreads();                // (the carry row is complete before the next tile reads it; the tile buffer is free for the next patch)
+            if (tid < ST_PR) Ps[tid * ST_PITCH + ST_PITCH - 1] = 0.f;      // (the tile buffer overwrote the patch rows' zero pad)
+            if (t + 1 < t1) store_patch();
+        } else {
         if (t + 1 < t1) store_patch();
         // ---- epilogue: acc reg e of lane l is C[pixel (e & 3) + 8 (e >> 2) + 4 lh][cout l31]; 32 x 32 block -> LDS -> float4 rows ----
 #pragma unroll
@@ -144,14 +226,27 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(StemArgs a) {
                 wave_lds_sync();
             }
         }
+        }
         __syncthreads();                    // the next tile's patch is complete
     }
 }
 
+// POOL: the pooled pixels that more than one workgroup contributes to -- the first pooled row of every strip of ST_TPW tiles and the first pooled column of every tile
+// column (except the image's own first row / column) -- are combined by atomicMax and therefore start from 0, written here (12 % of the map, nothing is read)
+__global__ __launch_bounds__(256) void stem_pool_zero_kernel(float* __restrict__ y, int y_cs, int y_co, int N, int Hp, int Wp) {
+    const long total = (long)N * Hp * Wp * 16;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i & 15);
+        const long px = i >> 4;
+        const int pw = (int)(px % Wp), ph = (int)((px / Wp) % Hp);
+        if ((ph > 0 && (2 * ph) % (ST_TH * ST_TPW) == 0) || (pw > 0 && (2 * pw) % ST_TW == 0))
+            *reinterpret_cast<float4*>(y + px * y_cs + y_co + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 /* w packed [7 filter rows][22][64 cout]: k = 3 * q + c for filter column q and input channel c, k = 21 zero (ops.pack_stem7_weight). */
-extern "C" int32_t fd_stem7x7_nhwc4(const float* x4, const float* w, const float* scale, const float* shift, float* y, int32_t y_cs,
-                                    int32_t y_co, int32_t N, int32_t H, int32_t W, int32_t act, fd_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int stem_launch(bool pool, const float* x4, const float* w, const float* scale, const float* shift, float* y, int32_t y_cs, int32_t y_co, int32_t N,
+                       int32_t H, int32_t W, int32_t act, hipStream_t stream) {
     FD_REQUIRE(x4 && w && y && N >= 1 && H >= 2 && W >= 2, FD_E_INVAL, "fd_stem7x7: bad arguments");
     FD_REQUIRE((((uintptr_t)x4 | (uintptr_t)w | (uintptr_t)y) & 15) == 0 && y_cs % 4 == 0 && y_co % 4 == 0 && y_cs >= y_co + ST_CO, FD_E_INVAL,
                "fd_stem7x7: pointers must be 16-byte aligned and the 64-channel output view 4-aligned");
@@ -161,12 +256,44 @@ extern "C" int32_t fd_stem7x7_nhwc4(const float* x4, const float* w, const float
     a.y_cs = y_cs; a.y_co = y_co; a.N = N; a.H = H; a.W = W; a.act = act;
     a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1;
     a.tiles_h = (a.Ho + ST_TH - 1) / ST_TH; a.tiles_w = (a.Wo + ST_TW - 1) / ST_TW;
+    const long out_rows = pool ? (long)N * ((a.Ho - 1) / 2 + 1) * ((a.Wo - 1) / 2 + 1) : (long)N * a.Ho * a.Wo;
+    FD_REQUIRE(out_rows * y_cs < (1L << 31), FD_E_UNSUPPORTED, "fd_stem7x7: tensor exceeds 2^31 elements");
+    if (pool) {
+        // a workgroup's ST_TPW tiles must lie in ONE column strip of ONE image (the carry row): the tile rows are padded to a multiple of ST_TPW per strip
+        // (tiles past the image compute nothing that is stored)
+        a.tiles_h = (a.tiles_h + ST_TPW - 1) / ST_TPW * ST_TPW;
+        const long blocks = (long)N * a.tiles_w * (a.tiles_h / ST_TPW);
+        FD_REQUIRE(blocks < (1L << 31), FD_E_UNSUPPORTED, "fd_stem7x7: too many tiles");
+        constexpr int lds = (7 * ST_KR * ST_CO + ST_PR * ST_PITCH + 4 * 1024 + 32 * 64) * 4;   // 81 KB: filter bank + patch + stages (= the tile buffer) + carry row
+        static std::atomic<unsigned> attr_mask{0};
+        fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(stem7x7_kernel<true>), lds);
+        {
+            const int Hp = (a.Ho - 1) / 2 + 1, Wp = (a.Wo - 1) / 2 + 1;
+            long g = ((long)N * Hp * Wp * 16 + 255) / 256;
+            if (g > 8192) g = 8192;
+            hipLaunchKernelGGL(stem_pool_zero_kernel, dim3((unsigned)g), dim3(256), 0, stream, y, y_cs, y_co, N, Hp, Wp);
+            FD_CHECK_LAUNCH("fd_stem7x7_pool_nhwc4 (zero)");
+        }
+        hipLaunchKernelGGL(stem7x7_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+        FD_CHECK_LAUNCH("fd_stem7x7_pool_nhwc4");
+        return FD_OK;
+    }
     const long blocks = ((long)N * a.tiles_h * a.tiles_w + ST_TPW - 1) / ST_TPW;
-    FD_REQUIRE(blocks < (1L << 31) && (long)N * a.Ho * a.Wo * y_cs < (1L << 31), FD_E_UNSUPPORTED, "fd_stem7x7: tensor exceeds 2^31 elements");
+    FD_REQUIRE(blocks < (1L << 31), FD_E_UNSUPPORTED, "fd_stem7x7: too many tiles");
     constexpr int lds = (ST_PR * ST_PITCH + 7 * ST_KR * ST_CO + 4 * 1024) * 4;       // 73 KB: patch + filter bank + transpose stages
     static std::atomic<unsigned> attr_mask{0};
-    fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(stem7x7_kernel), lds);
-    hipLaunchKernelGGL(stem7x7_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(stem7x7_kernel<false>), lds);
+    hipLaunchKernelGGL(stem7x7_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
     FD_CHECK_LAUNCH("fd_stem7x7_nhwc4");
     return FD_OK;
+}
+
+extern "C" int32_t fd_stem7x7_nhwc4(const float* x4, const float* w, const float* scale, const float* shift, float* y, int32_t y_cs,
+                                    int32_t y_co, int32_t N, int32_t H, int32_t W, int32_t act, fd_stream_t stream_) {
+    return stem_launch(false, x4, w, scale, shift, y, y_cs, y_co, N, H, W, act, (hipStream_t)stream_);
+}
+
+extern "C" int32_t fd_stem7x7_pool_nhwc4(const float* x4, const float* w, const float* scale, const float* shift, float* y_pooled, int32_t y_cs,
+                                         int32_t y_co, int32_t N, int32_t H, int32_t W, fd_stream_t stream_) {
+    return stem_launch(true, x4, w, scale, shift, y_pooled, y_cs, y_co, N, H, W, FD_ACT_RELU, (hipStream_t)stream_);
 }

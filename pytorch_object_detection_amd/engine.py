@@ -40,6 +40,7 @@ DUAL_DS = _os.environ.get("FD_DUAL_DS", "1") != "0"      # "0": a block's downsa
 # FD_B2B: the trunk layers (digits) whose conv3 -> next-block conv1 seams run as ONE back-to-back launch (fd_conv1x1_b2b_f32: the 4 * planes wide map is
 # written once and never read back); "" = none
 B2B_LAYERS = _os.environ.get("FD_B2B", "1")
+STEM_POOL = _os.environ.get("FD_STEM_POOL", "1") != "0"         # "0": the stem's 3x3 s2 max-pool as its own launch (the 64-channel stride-2 map written and read back)
 STEM_KERNEL = _os.environ.get("FD_STEM_KERNEL", "1") != "0"     # "0": the ResNet stem through the generic conv kernel's FD_CONV_STEM mode
 
 
@@ -326,24 +327,37 @@ def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: Lis
     sc, sf = ops.fold_bn(_dev(trunk.bn1.weight, dev), _dev(trunk.bn1.bias, dev), _dev(trunk.bn1.running_mean, dev),
                          _dev(trunk.bn1.running_var, dev), trunk.bn1.eps)
     s1 = ops.conv_out_segs(s_in, 7, 2, 3, 1)
-    y1 = pool.get(s1.rows, 64)
-    if STEM_KERNEL and plan.precision in ("f32", "mixed") and tuple(trunk.conv1.weight.shape) == (64, 3, 7, 7):
+    H1, W1 = s1.H[0], s1.W[0]
+    H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+    s2 = Segs.make(batch, [(H2, W2)])
+    fused_pool = STEM_POOL and STEM_KERNEL and plan.precision in ("f32", "mixed") and tuple(trunk.conv1.weight.shape) == (64, 3, 7, 7)
+    if fused_pool:
+        # conv1 + bn1 + relu + maxpool as ONE launch (fd_stem7x7_pool_nhwc4): the 64-channel stride-2 map is never written (resnet50.py:68-80)
+        wp = ops.pack_stem7_weight(_dev(trunk.conv1.weight, dev))
+        y2 = pool.get(s2.rows, 64)
+        plan.add("backbone.conv1+maxpool", lambda: ops.stem7x7_pool(x4, wp, y2, batch, H, W, sc, sf))
+        plan.keep += [wp, sc, sf]
+        plan.flops += 2 * s1.rows * 64 * 147
+        plan.step_flops[len(plan.steps) - 1] = 2 * s1.rows * 64 * 147
+        pool.put(x4)
+    y1 = pool.get(s1.rows, 64) if not fused_pool else None
+    if fused_pool:
+        pass
+    elif STEM_KERNEL and plan.precision in ("f32", "mixed") and tuple(trunk.conv1.weight.shape) == (64, 3, 7, 7):
         wp = ops.pack_stem7_weight(_dev(trunk.conv1.weight, dev))      # the dedicated stem kernel (fd_stem.hip): patch + filters staged in LDS
         plan.add("backbone.conv1", lambda: ops.stem7x7(x4, wp, y1, batch, H, W, sc, sf, ACT_RELU))
     else:
         wp = ops.pack_stem_weight(_dev(trunk.conv1.weight, dev))
         plan.add("backbone.conv1", ops.conv_call(x4, s_in, wp, y1, Cin=4, Cout=64, k=7, stride=2, pad=3, scale=sc, shift=sf,
                                                  act=ACT_RELU, stem=True))
-    plan.keep += [wp, sc, sf]
-    plan.flops += 2 * s1.rows * 64 * 147
-    plan.step_flops[len(plan.steps) - 1] = 2 * s1.rows * 64 * 147
-    pool.put(x4)
-    H1, W1 = s1.H[0], s1.W[0]
-    H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
-    s2 = Segs.make(batch, [(H2, W2)])
-    y2 = pool.get(s2.rows, 64)
-    plan.add("backbone.maxpool", lambda: ops.maxpool(y1, y2, batch, H1, W1, 3, 2, 1))
-    pool.put(y1)
+    if not fused_pool:
+        plan.keep += [wp, sc, sf]
+        plan.flops += 2 * s1.rows * 64 * 147
+        plan.step_flops[len(plan.steps) - 1] = 2 * s1.rows * 64 * 147
+        pool.put(x4)
+        y2 = pool.get(s2.rows, 64)
+        plan.add("backbone.maxpool", lambda: ops.maxpool(y1, y2, batch, H1, W1, 3, 2, 1))
+        pool.put(y1)
     x, sx = y2, s2
     feats = []
     blocks_all = [(li, bi, blk) for li in (1, 2, 3, 4) for bi, blk in enumerate(getattr(trunk, f"layer{li}"))]

@@ -137,6 +137,17 @@ def stem7x7(x4: Rows, w722: torch.Tensor, y: Rows, N: int, H: int, W: int, scale
           "fd_stem7x7_nhwc4")
 
 
+def stem7x7_pool(x4: Rows, w722: torch.Tensor, y: Rows, N: int, H: int, W: int, scale=None, shift=None) -> None:
+    """ResNet stem 7x7 s2 p3 (3 -> 64) + scale / shift + ReLU + max-pool 3x3 s2 p1 in one call (fd_stem7x7_pool_nhwc4): y = the pooled map; the
+    64-channel stride-2 map is never written."""
+    _need_gpu(w722, scale, shift)
+    if x4.cs != 4 or x4.co != 0 or y.C != 64:
+        raise FdError("stem7x7_pool: input must be the [rows][4] image buffer, output a 64-channel view")
+    check(_lib.lib().fd_stem7x7_pool_nhwc4(x4.ptr, w722.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                           shift.data_ptr() if shift is not None else None, y.ptr, y.cs, y.co, N, H, W, _stream()),
+          "fd_stem7x7_pool_nhwc4")
+
+
 def pack_dw_weight(w: torch.Tensor) -> torch.Tensor:
     """[C,1,3,3] -> [9][C]."""
     return w.detach().reshape(w.shape[0], 9).t().contiguous().float()
@@ -527,8 +538,6 @@ def pack_conv_weight_narrow(w: torch.Tensor) -> torch.Tensor:
         raise FdError(f"narrow-conv weights need a 3x3 filter bank with Cout <= 8 and Cin % 16 == 0 (got {tuple(w.shape)})")
     if co < 8:
         w = torch.cat([w, torch.zeros(8 - co, ci, 3, 3, dtype=w.dtype, device=w.device)], 0)
-    if os.environ.get("FD_NARROW_MODE") == "1":          # (experiment: [step][8 couts][4 k] for the LDS-broadcast variant)
-        return w.reshape(8, ci // 16, 4, 4, 3, 3).permute(1, 4, 2, 5, 0, 3).contiguous()
     # (co, ch, c4, k, r, q) -> (ch, r, c4, q, k, co)
     return w.reshape(8, ci // 16, 4, 4, 3, 3).permute(1, 4, 2, 5, 3, 0).contiguous()
 
