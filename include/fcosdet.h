@@ -116,8 +116,6 @@ const char* fd_last_error(void);
 #define FD_TILE_NARROW 17    /* 3x3 stride-1 pad-1 convs with Cout <= 8 (the centre-ness + box-distance predictor, HISFcos.py:207-209), fp32, Cin % 16 == 0, no
                                 residual / gate / gn_stats / split-K: exact fp32 FMA chains on the VECTOR unit, one thread per output pixel (fd_conv_narrow.hip).
                                 `w` = [Cin / 16][3 r][4 quads][3 q][4 k][8 couts] fp32: channel 16 chunk + 4 quad + k, filter tap (r, q); zero filters past Cout */
-#define FD_TILE_WINOGRAD4_PRE 18 /* FD_TILE_WINOGRAD4 with the input transform done ONCE by a pre-pass launch into `workspace` (fd_wino4_prepass_bytes) instead of once per
-                                   64-cout workgroup column; same weights, same results bit for bit; no split-K (round-4 experiment) */
 #define FD_TILE_COUNT 17
 
 typedef struct fd_conv_params {
@@ -189,8 +187,6 @@ typedef struct fd_conv_params {
 } fd_conv_params;
 
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
-/* Workspace bytes of tile = FD_TILE_WINOGRAD4_PRE: the transformed input, 36 / 16 x the input rounded up to whole 32-tile blocks. */
-int64_t fd_wino4_prepass_bytes(const fd_segs* segs, int32_t Cin, int32_t dil);
 /* Two GEMM-addressed (1x1, stride 1, unpadded) layers back to back in ONE launch -- a ResNet bottleneck's conv3 + BN + residual + ReLU and the next
  * block's conv1 + BN + ReLU (torchvision Bottleneck.forward behind model/backbone/resnet50.py:68-80):
  *     y = act1(x . W1^T * scale1 + shift1 + res)   [rows][N1]   written to HBM (it is the next block's residual)

@@ -16,7 +16,6 @@ TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (128, 32), 6
          15: (64, 64)}                               # wave-autonomous 64x64 tiles, one wave per workgroup (1x1 stride-1 layers, needs w_frag)
 PATCH_TILE = 13
 WAVE_TILE = 15
-WINO4P_TILE = 18    # FD_TILE_WINOGRAD4 with a transform pre-pass (round-4 experiment)
 NARROW_TILE = 17    # 3x3 stride-1 pad-1 convs with Cout <= 8 on the vector unit (fd_conv_narrow.hip; ops.pack_conv_weight_narrow); not a member of TILES
 WINO4_TILE = 16     # Winograd F(4x4, 3x3) kernel (own weight packing: ops.pack_conv_weight_wino4); not a member of TILES
 PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2     # include/fcosdet.h FD_PREC_*
@@ -112,7 +111,6 @@ _SIGS = {
     "fd_last_error": (C.c_char_p, []),
     "fd_conv2d_nhwc_f32": (_I, [C.POINTER(ConvParams), _P]),
     "fd_conv_narrow_nco": (_I, [_I]),
-    "fd_wino4_prepass_bytes": (_L, [C.POINTER(Segs), _I, _I]),
     "fd_conv1x1_b2b_f32": (_I, [C.POINTER(B2BParams), _P]),
     "fd_conv_workspace_bytes": (_L, [_L, _I, _I]),
     "fd_conv_wgrad_workspace_bytes": (_L, [_L, _I, _I, _I, _I]),

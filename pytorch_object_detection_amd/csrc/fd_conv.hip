@@ -422,7 +422,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
                    "fd_conv2d: multi-level input needs stride 1 and 'same' padding");
 
     if (p->tile == FD_TILE_WINOGRAD) return fd_launch_conv_wino(p, stream);   // own argument block, own weight packing
-    if (p->tile == FD_TILE_WINOGRAD4 || p->tile == FD_TILE_WINOGRAD4_PRE) return fd_launch_conv_wino4(p, stream);
+    if (p->tile == FD_TILE_WINOGRAD4) return fd_launch_conv_wino4(p, stream);
     if (p->tile == FD_TILE_NARROW) return fd_launch_conv_narrow(p, stream);
 
     ConvArgs a;

@@ -46,7 +46,6 @@ struct Wino4Args {
     int T;                        // tiles in all
     int mtiles, ntiles, mt_per;   // M tiles (32 tiles each), N tiles (64 cout), M tiles per XCD
     unsigned x_bytes, u_bytes;
-    const float* vg;              // PRE kernels (FD_TILE_WINOGRAD4_PRE): the transformed input V[M tile][chunk][36 f][32 tiles][8 c] a pre-pass launch left in the workspace
     int dbg;                      // timing builds only (-DFD_W4_TIMING + FD_W4_DBG): 1 = no loader stages, 2 = no MFMAs, 4 = no epilogue (wrong results)
 };
 // The shipped library never skips parts of the kernel: the timing switches exist only in a build compiled with -DFD_W4_TIMING (tools/pmc_wino.sh).
@@ -121,9 +120,7 @@ __device__ __forceinline__ void w4_bt(const float4 (&d)[6], float4 (&t)[6]) {
 #undef W4_BT1
 }
 
-// PRE = true (experiment of round 4, FD_TILE_WINOGRAD4_PRE): the input transform is NOT redone per 64-cout workgroup column -- a pre-pass launch
-// (wino4_prepass_kernel) writes V once, and this kernel's "loader" is a linear copy of the chunk's 36 KB from global to its LDS stage.
-template <int TAG, bool PRE = false>
+template <int TAG>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Vs = reinterpret_cast<float*>(smem);                  // [2][36][32][8]
@@ -149,7 +146,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, (int)a.u_bytes, 0x00020000);
 
     // ---- loader role (threads 0 .. 383): (tile lt, line pr, channel quad q); pr = patch row i in G / R, column j' in C ----
-    const bool ldr = PRE ? true : (__builtin_amdgcn_readfirstlane(tid) < 384 && !(W4_DBG(a) & 1));       // wave-uniform: scalar branches around the loader slices
+    const bool ldr = __builtin_amdgcn_readfirstlane(tid) < 384 && !(W4_DBG(a) & 1);       // wave-uniform: scalar branches around the loader slices
     // one line pr per WAVE, (tile, quad) per lane: every scratch / V instruction of a wave then walks 64 different blocks at one in-block offset
     const int q = tid & 1, lt = (tid >> 1) & 31, pr = min(tid >> 6, 5);
     // patch row pr of tile lt: one base offset per thread; the six columns differ by a uniform pixel stride (buffer soffset) and a validity bit each
@@ -158,7 +155,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
         const Tile4 p = wino4_decode(a, tile0 + lt);
         const int H = a.H[p.s], W = a.W[p.s];
         const int hh = (p.h0 - 1 + pr) * a.dil + p.ph;           // (negative exactly when the sub-grid row is)
-        const bool row_ok = !PRE && ldr && p.ok && (unsigned)hh < (unsigned)H;
+        const bool row_ok = ldr && p.ok && (unsigned)hh < (unsigned)H;
         const int rowbase = a.m0[p.s] + (p.n * H + hh) * W;
         const unsigned a_base = ((unsigned)(rowbase + p.w0 * a.dil + p.pw) * (unsigned)a.x_cs + (unsigned)(a.x_co + q * 4)) * 4u;    // column j = 1
 #pragma unroll
@@ -190,19 +187,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
             dst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)a_off[j], j * px_b + cb, 0));
     };
     auto stage_G = [&](int cc) { load_G(pv, cc); };
-    // PRE: the chunk's V image (2 304 float4, this workgroup's M tile) copied linearly: float4 tid + 512 u, u < 5 (the last pass half empty)
-    const float4* vsrc = reinterpret_cast<const float4*>(a.vg) + (size_t)mt * a.NC * (W4_STAGE / 4) + tid;
-    auto load_V = [&](int cc) {
-#pragma unroll
-        for (int u = 0; u < 5; ++u)
-            if (u < 4 || tid < 256) pv[u] = vsrc[(size_t)(c0 + cc) * (W4_STAGE / 4) + 512 * u];
-    };
-    auto store_V = [&](int st) {
-        float4* d = reinterpret_cast<float4*>(Vs + st * W4_STAGE) + tid;
-#pragma unroll
-        for (int u = 0; u < 5; ++u)
-            if (u < 4 || tid < 256) d[512 * u] = pv[u];
-    };
     auto row_pass = [&](const float4 (&src)[6], int st) {          // row pass (along the patch row) -> scratch
         float4 t[6];
         w4_bt(src, t);
@@ -228,15 +212,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     const int NC = min(a.NC, c0 + a.nc_per) - c0;               // this slice's chunks [c0, c0 + NC)
     // ---- prologue: the patch rows of chunks 0, 1, 2 are requested together (ONE global round trip, not three: the accumulators are not live yet,
     // registers are plenty), then R(0) R(1) | C(0): V[0] holds chunk 0, scratch[1] chunk 1's row pass, the patch registers chunk 2 ----
-    if constexpr (PRE) {
-        load_V(0);
-#pragma unroll
-        for (int fi = 0; fi < 9; ++fi) load_u(0, fi);
-        store_V(0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_V(min(1, NC - 1));
-        __syncthreads();
-    } else {
     {
         float4 p0[6], p1[6];
         if (ldr) { load_G(p0, 0); load_G(p1, min(1, NC - 1)); stage_G(min(2, NC - 1)); }
@@ -247,7 +222,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     __syncthreads();
     if (ldr) stage_C(0);
     __syncthreads();
-    }
 
     // Main loop: one 8-channel chunk per iteration and workgroup barrier.  The loader stages of the NEXT chunks are cut into slices that sit between
     // the nine MFMA groups of this chunk (pinned with sched_barriers): issued in the shadow of the 64-cycle MFMAs instead of in front of them
@@ -280,11 +254,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                 acc[fi] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, fb.w, acc[fi], 0, 0, 0);
                 load_u(cn, fi);                                        // next chunk's block into the registers just consumed
             }
-            if constexpr (LDR && PRE) {
-                if (fi == 0) { store_V(st ^ 1); }                                      // chunk cc + 1 (in the registers since the last iteration) -> the other stage
-                if (fi == 1) { load_V(min(cc + 2, NC - 1)); }                          // chunk cc + 2 -> registers: a whole iteration of latency
-            }
-            if constexpr (LDR && !PRE) {
+            if constexpr (LDR) {
                 if (fi == 0) w4_bt_inplace(pv);
                 if (fi == 1) {
                     float* d = Ss + st * W4_SSTAGE + s_wr;
@@ -410,68 +380,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     }
 }
 
-// The transform pre-pass of FD_TILE_WINOGRAD4_PRE: V = B^T d B of every (tile, channel) ONCE, written [M tile][chunk][36 f][32 tiles][8 c] (the LDS stage's layout:
-// the consuming kernel copies a chunk linearly).  One workgroup of six waves (one patch line per wave, (tile, quad) per lane -- the loader roles of the fused
-// kernel) walks W4_PRE_CPW chunks of one M tile: G(c + 1) is requested before R(c) | barrier | C(c) -> global.
-#define W4_PRE_CPW 4
-__global__ __launch_bounds__(384) void wino4_prepass_kernel(Wino4Args a, float* __restrict__ vg) {
-    __shared__ __attribute__((aligned(16))) float Ss[W4_SSTAGE];
-    const int tid = threadIdx.x;
-    const int mt = blockIdx.x, tile0 = mt * W4_TB;
-    const int cA = blockIdx.y * W4_PRE_CPW, cB = min(a.NC, cA + W4_PRE_CPW);
-    constexpr unsigned OOB = 0xC0000000u;
-    const int px_b = a.x_cs * 4 * a.dil;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x - px_b), (short)0, (int)(a.x_bytes + (unsigned)px_b), 0x00020000);
-    const int q = tid & 1, lt = (tid >> 1) & 31, pr = tid >> 6;
-    unsigned a_off[6];
-    {
-        const Tile4 p = wino4_decode(a, tile0 + lt);
-        const int H = a.H[p.s], W = a.W[p.s];
-        const int hh = (p.h0 - 1 + pr) * a.dil + p.ph;
-        const bool row_ok = p.ok && (unsigned)hh < (unsigned)H;
-        const int rowbase = a.m0[p.s] + (p.n * H + hh) * W;
-        const unsigned a_base = ((unsigned)(rowbase + p.w0 * a.dil + p.pw) * (unsigned)a.x_cs + (unsigned)(a.x_co + q * 4)) * 4u;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) a_off[j] = (row_ok && (unsigned)((p.w0 - 1 + j) * a.dil + p.pw) < (unsigned)W) ? a_base : OOB;
-    }
-    const int s_wr = ((lt * 2 + q) * W4_SBLK + pr) * 4, s_rd = ((lt * 2 + q) * W4_SBLK + pr * 6) * 4;
-    const int v_wr = (pr * W4_TB + lt) * W4_KC + 4 * q;
-    float4 pv[6], nx[6];
-    auto load_G = [&](float4 (&dst)[6], int cc) {
-        const int cb = cc * 32;
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-            dst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)a_off[j], j * px_b + cb, 0));
-    };
-    load_G(pv, cA);
-    for (int cc = cA; cc < cB; ++cc) {
-        if (cc + 1 < cB) load_G(nx, cc + 1);
-        float4 t[6];
-        w4_bt(pv, t);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(Ss + s_wr + j * 24) = t[j];
-        __syncthreads();
-        float4 sc[6], v[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) sc[i] = *reinterpret_cast<const float4*>(Ss + s_rd + i * 4);
-        w4_bt(sc, v);
-        float* d = vg + ((size_t)mt * a.NC + cc) * W4_STAGE + v_wr;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) *reinterpret_cast<float4*>(d + i * 6 * W4_PLANE) = v[i];
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 6; ++j) pv[j] = nx[j];
-    }
-}
-
-extern "C" int64_t fd_wino4_prepass_bytes(const fd_segs* segs, int32_t Cin, int32_t dil) {
-    if (!fd_segs_ok(segs) || Cin < 8 || Cin % 8 || (dil != 1 && dil != 2)) return -1;
-    long t = 0;
-    for (int s = 0; s < segs->nseg; ++s)
-        t += (long)segs->batch * dil * dil * (((segs->H[s] + dil - 1) / dil + 3) / 4) * (((segs->W[s] + dil - 1) / dil + 3) / 4);
-    return ((t + W4_TB - 1) / W4_TB) * (int64_t)W4_TB * 36 * Cin * 4;
-}
-
 // U = G g G^T per filter (fd_wino4_pack_one, fd_conv_common.h): one (n, k) filter per thread.
 __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
                                                          int N, int K, int mode) {
@@ -547,28 +455,6 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
     a.mt_per = (a.mtiles + 7) / 8;
     constexpr int lds = (2 * W4_STAGE + 2 * W4_SSTAGE) * 4;        // 146 KB
     a.nc_per = a.NC; a.slice_stride = 0;
-    a.vg = nullptr;
-    if (p->tile == FD_TILE_WINOGRAD4_PRE) {     // experiment: transform pre-pass + copy-loader kernel (no split-K: the workspace holds V)
-        const int64_t vb = (int64_t)a.mtiles * W4_TB * 36 * p->Cin * 4;
-        FD_REQUIRE(p->ksplit <= 1 && p->workspace && ((uintptr_t)p->workspace & 15) == 0 && p->workspace_bytes >= vb, FD_E_INVAL,
-                   "fd_conv2d: FD_TILE_WINOGRAD4_PRE needs a 16-byte aligned workspace of fd_wino4_prepass_bytes() = %ld bytes and no split-K", (long)vb);
-        a.vg = (const float*)p->workspace;
-        hipLaunchKernelGGL(wino4_prepass_kernel, dim3((unsigned)a.mtiles, (unsigned)((a.NC + W4_PRE_CPW - 1) / W4_PRE_CPW)), dim3(384), 0, stream, a, (float*)p->workspace);
-        FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (Winograd F(4x4,3x3) transform pre-pass)");
-        constexpr int lds_pre = lds;          // (the epilogue's frequency planes need the full 146 KB, as in the fused kernel)
-        const dim3 gridp((unsigned)(8 * a.mt_per * a.ntiles), 1u);
-        if (p->tag == 1) {
-            static std::atomic<unsigned> mp1{0};
-            fd_set_max_lds_once(mp1, reinterpret_cast<const void*>(conv3x3_wino4_kernel<1, true>), lds_pre);
-            hipLaunchKernelGGL((conv3x3_wino4_kernel<1, true>), gridp, dim3(512), lds_pre, stream, a);
-        } else {
-            static std::atomic<unsigned> mp0{0};
-            fd_set_max_lds_once(mp0, reinterpret_cast<const void*>(conv3x3_wino4_kernel<0, true>), lds_pre);
-            hipLaunchKernelGGL((conv3x3_wino4_kernel<0, true>), gridp, dim3(512), lds_pre, stream, a);
-        }
-        FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (Winograd F(4x4,3x3), pre-transformed input)");
-        return FD_OK;
-    }
     const int ksplit = p->ksplit > 1 ? p->ksplit : 1;
     ConvArgs o = {};
     int ldw = 0; long slab = 0;

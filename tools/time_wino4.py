@@ -27,16 +27,7 @@ def bench(name, B, hw, Cin, Cout, dil=1):
     c4 = ops.conv_call(x, segs, ops.pack_conv_weight_wino4(w), y4, Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, tile=_lib.WINO4_TILE)
     m2, m4 = timeit(c2), timeit(c4)
     err = (y2.tensor() - y4.tensor()).abs().max().item()
-    pre = ""
-    if os.environ.get("W4_PRE") == "1":      # the transform pre-pass variant (FD_TILE_WINOGRAD4_PRE, round-4 experiment): pre-pass + copy-loader kernel, bit-identical
-        import ctypes
-        nb = _lib.lib().fd_wino4_prepass_bytes(ctypes.byref(segs), Cin, dil)
-        ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
-        y5 = ops.new_rows(segs.rows, Cout, dev)
-        c5 = ops.conv_call(x, segs, ops.pack_conv_weight_wino4(w), y5, Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, tile=_lib.WINO4P_TILE, workspace=ws)
-        m5 = timeit(c5)
-        pre = f" | pre-pass variant {m5:.4f} ms, identical={torch.equal(y5.tensor(), y4.tensor())}, V {nb / 1e6:.0f} MB"
-    print(f"{name}: F(2x2) {m2:.4f} ms {fl / m2 / 1e9:.1f} TF/s-eq | F(4x4) {m4:.4f} ms {fl / m4 / 1e9:.1f} TF/s-eq ({m2 / m4:.2f}x) max|diff| {err:.2e}{pre}", flush=True)
+    print(f"{name}: F(2x2) {m2:.4f} ms {fl / m2 / 1e9:.1f} TF/s-eq | F(4x4) {m4:.4f} ms {fl / m4 / 1e9:.1f} TF/s-eq ({m2 / m4:.2f}x) max|diff| {err:.2e}", flush=True)
 
 
 pyr = [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
