@@ -114,7 +114,9 @@ const char* fd_last_error(void);
                                 channel pair (2.25 per output: 1.78x fewer than F(2x2), 4x fewer than direct); needs the fd_wino4_pack_weights_f32 packing in `w`;
                                 ksplit as FD_TILE_WINOGRAD; no gate / gn_stats.  Rounding error ~2x F(2x2)'s, inside the 1e-4 parity bar */
 #define FD_TILE_NARROW 17    /* 3x3 stride-1 pad-1 convs with Cout <= 8 (the centre-ness + box-distance predictor, HISFcos.py:207-209), fp32, Cin % 16 == 0, no
-                                residual / gate / gn_stats / split-K: exact fp32 FMA chains on the VECTOR unit, one thread per output pixel (fd_conv_narrow.hip).
+                                residual / gn_stats / split-K: exact fp32 FMA chains on the VECTOR unit, one thread per output pixel (fd_conv_narrow.hip).
+                                `gate` + `gate_b` (+ gate_act): the preceding GroupNorm's affine + activation applied to the patch on its way to LDS, zero
+                                padding AFTER it as in the reference (any number of levels; coefficient rows as documented at gate_b below).
                                 `w` = [Cin / 16][3 r][4 quads][3 q][4 k][8 couts] fp32: channel 16 chunk + 4 quad + k, filter tap (r, q); zero filters past Cout */
 #define FD_TILE_COUNT 17
 
@@ -171,7 +173,8 @@ typedef struct fd_conv_params {
      *     Needs Cout % 32 == 0, (Cout / gn_groups) in {4, 8, 16, 32}, 16-byte output views, no split-K, no output scatter.
      *   gate_b != NULL (with `gate`): the loader applies x' = act(x * gate[img][c] + gate_b[img][c]), gate_act in {NONE, RELU, SILU}, img =
      *     level * batch + image -- the GroupNorm affine + activation of the PRECEDING layer applied on the way to LDS (coefficients from
-     *     fd_groupnorm_from_rowstats), so the normalise pass over the map disappears too.  `gate` alone keeps meaning x * gate (MBConv SE). */
+     *     fd_groupnorm_from_rowstats), so the normalise pass over the map disappears too.  `gate` alone keeps meaning x * gate (MBConv SE).
+     *     Consumers: the 1x1 GEMM layers (above) and FD_TILE_NARROW (3x3, padded: the padding stays zero). */
     float* gn_stats;
     int32_t gn_groups;
     int32_t gate_act;
@@ -287,6 +290,12 @@ int32_t fd_stem7x7_nhwc4(const float* x4, const float* w, const float* scale, co
  * writes to exactly those pixels (two launches on `stream`; nothing outside y_pooled's 64-channel view is touched).  Bitwise reproducible. */
 int32_t fd_stem7x7_pool_nhwc4(const float* x4, const float* w, const float* scale, const float* shift, float* y_pooled, int32_t y_cs, int32_t y_co,
                               int32_t N, int32_t H, int32_t W, fd_stream_t stream);
+
+/* Both stem kernels reading the reference's own input tensor -- fp32 [N][3][H][W] (NCHW, dataset/voc.py:141-173), 4-byte aligned -- in their patch
+ * loaders: no fd_nchw3_to_nhwc4 pass.  pool != 0: conv1 + bn1 + relu + maxpool as fd_stem7x7_pool_nhwc4 (y = the pooled map, act ignored); pool == 0:
+ * as fd_stem7x7_nhwc4.  Same arithmetic and summation order: bit-identical to the nhwc4 entry points on the converted input. */
+int32_t fd_stem7x7_nchw3(const float* x, const float* w, const float* scale, const float* shift, float* y, int32_t y_cs, int32_t y_co,
+                         int32_t N, int32_t H, int32_t W, int32_t act, int32_t pool, fd_stream_t stream);
 
 /* [N][3][H][W] fp32 (NCHW, the reference's input layout, dataset/voc.py:141-173) -> [N][H][W][4] (c=3 zero) */
 int32_t fd_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, fd_stream_t stream);
@@ -438,6 +447,15 @@ int32_t fd_groupnorm_from_rowstats(const float* rowstats, int32_t C, int32_t G, 
 int32_t fd_groupnorm_apply_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* gamma, const float* beta, float* y,
                                 int32_t y_cs, int32_t y_co, int32_t C, int32_t G, float eps, int32_t act, const fd_segs* segs,
                                 const void* workspace, fd_stream_t stream);
+/* The statistics steps of fd_groupnorm_act_nhwc alone (`workspace` as there) + optionally the affine `coef` [imgs][2][C] of
+ * fd_groupnorm_from_rowstats: for a map whose consumers normalise it themselves (fd_conv_params.gate_b, fd_coef_apply_nhwc). */
+int32_t fd_groupnorm_stats_nhwc(const float* x, int32_t x_cs, int32_t x_co, int32_t C, int32_t G, float eps, const float* gamma, const float* beta,
+                                const fd_segs* segs, void* workspace, float* coef, fd_stream_t stream);
+/* y = act(x * coef_a[img][c] + coef_b[img][c]) over a C-channel view, img = level * batch + image, coefficient rows coef_cs floats apart
+ * (views into fd_groupnorm_from_rowstats' coef: a CHANNEL SLICE of a map whose statistics were reduced together with other channels -- the
+ * class half of the head tower, whose box half is normalised inside the FD_TILE_NARROW predictor's loader).  C / 4 must divide 256. */
+int32_t fd_coef_apply_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* coef_a, const float* coef_b, int32_t coef_cs, float* y,
+                           int32_t y_cs, int32_t y_co, int32_t C, int32_t act, const fd_segs* segs, fd_stream_t stream);
 int32_t fd_dwconv3x3_gn_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w, const float* in_coef, int32_t in_act,
                              float* y, int32_t y_cs, int32_t y_co, int32_t C, float* gn_stats, int32_t gn_groups,
                              const fd_segs* segs, fd_stream_t stream);

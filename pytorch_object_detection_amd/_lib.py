@@ -125,6 +125,7 @@ _SIGS = {
     "fd_conv2d_bwd_weight_f32": (_I, [C.POINTER(WgradParams), _P]),
     "fd_stem7x7_nhwc4": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fd_stem7x7_pool_nhwc4": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "fd_stem7x7_nchw3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fd_nchw3_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _P]),
     "fd_nhwc_to_nchw": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),
     "fd_preprocess_u8_nhwc4": (_I, [_P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
@@ -142,6 +143,8 @@ _SIGS = {
     "fd_groupnorm_act_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _I, C.POINTER(Segs), _P, _P]),
     "fd_groupnorm_from_rowstats": (_I, [_P, _I, _I, _F, _P, _P, C.POINTER(Segs), _P, _P, _P]),
     "fd_groupnorm_apply_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _I, C.POINTER(Segs), _P, _P]),
+    "fd_groupnorm_stats_nhwc": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, C.POINTER(Segs), _P, _P, _P]),
+    "fd_coef_apply_nhwc": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, C.POINTER(Segs), _P]),
     "fd_dwconv3x3_gn_nhwc": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, C.POINTER(Segs), _P]),
     "fd_groupnorm_bwd_workspace_bytes": (_L, [C.POINTER(Segs), _I]),
     "fd_groupnorm_act_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, C.POINTER(Segs), _P, _P,

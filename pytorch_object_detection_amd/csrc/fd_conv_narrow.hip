@@ -15,7 +15,10 @@
 //     them through a DPP quad_perm:[k,k,k,k] broadcast: v_fmac_f32_dpp acc[co], W[co] (lane k of the quad), v.k -- no VGPR per weight, no
 //     scalar round trips, three LDS instructions per 20 FMAs;
 //   * per output one fp32 fma chain over (chunk, r, c4, q, component): a direct convolution's arithmetic (no Winograd rounding);
-//   * pyramids are one launch (per-tile level decode); epilogue = scale / shift (bias) + activation on channels >= act_c0 (ScaleExp).
+//   * pyramids are one launch (per-tile level decode); epilogue = scale / shift (bias) + activation on channels >= act_c0 (ScaleExp);
+//   * GATE instantiations: the preceding GroupNorm's per-(level, image, channel) affine + activation (fd_conv_params.gate / gate_b / gate_act, the
+//     coef of fd_groupnorm_from_rowstats) is applied to the patch on its way from the load registers to LDS -- padding stays zero, as a padded
+//     conv of the normalised map has it -- so the normalise pass over the predictor's half of the tower map disappears.
 // 2 560 waves of ~11 500 FMAs at batch 16: see DESIGN 4.1f for the measurement.
 #include "fd_conv_common.h"
 
@@ -29,6 +32,8 @@ struct NarrowArgs {
     int m0[FD_MAX_SEG];           // first row of the level
     int t0[FD_MAX_SEG + 1];       // first tile of the level
     float seg_param[FD_MAX_SEG];
+    const float* gate; const float* gate_b;    // GATE: [nseg * batch][gate_cs] floats each, channel 0 = the view's first input channel
+    int gate_cs, gate_act;
 };
 
 #define NR_T 16                    // tile edge
@@ -49,7 +54,7 @@ __device__ __forceinline__ void nr_fmac_quad(float& acc, float w, float v) {
     if constexpr (K == 3) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(v));
 }
 
-template <int NCO>
+template <int NCO, bool GATE>
 __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(NarrowArgs a) {
     __shared__ __attribute__((aligned(16))) float patch[NR_P * NR_P * NR_PITCH];
     __shared__ __attribute__((aligned(16))) float wts[NR_WCHUNK];
@@ -79,6 +84,9 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(NarrowArgs a) {
         dst[u] = px < NR_P * NR_P ? px * NR_PITCH + c4 * 4 : -1;
     }
     float4 pf[NR_NLD], wf[2];
+    // GATE: every float4 of this thread has channel quad tid & 3 (256 % 4 == 0): one affine pair per chunk
+    float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), gb = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long grow = GATE ? ((long)s * a.batch + n) * a.gate_cs + (tid & 3) * 4 : 0;
     const float4* wsrc = reinterpret_cast<const float4*>(a.w);
     auto load = [&](int ch) {
 #pragma unroll
@@ -86,8 +94,28 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(NarrowArgs a) {
             pf[u] = src[u] ? *reinterpret_cast<const float4*>(src[u] + ch * NR_KC) : make_float4(0.f, 0.f, 0.f, 0.f);
         wf[0] = wsrc[(long)ch * (NR_WCHUNK / 4) + tid];
         if (tid < NR_WCHUNK / 4 - 256) wf[1] = wsrc[(long)ch * (NR_WCHUNK / 4) + 256 + tid];
+        if constexpr (GATE) {
+            ga = *reinterpret_cast<const float4*>(a.gate + grow + ch * NR_KC);
+            gb = *reinterpret_cast<const float4*>(a.gate_b + grow + ch * NR_KC);
+        }
     };
     auto store = [&]() {
+        if constexpr (GATE) {       // applied here, not in load(): the loads are still in flight under the previous chunk's FMAs there
+#pragma clang fp contract(off)
+            // (multiply, then add, each rounded -- contraction is off in this block: the arithmetic of the normalise pass this replaces, fd_layers.hip is
+            //  built without FMA contraction.)  One uniform branch on the activation per chunk, not one per element.
+            auto affine = [&](auto act_fn) {
+#pragma unroll
+                for (int u = 0; u < NR_NLD; ++u)
+                    if (src[u]) {       // (padding pixels stay zero: the reference pads the NORMALISED map)
+                        pf[u].x = act_fn(pf[u].x * ga.x + gb.x); pf[u].y = act_fn(pf[u].y * ga.y + gb.y);
+                        pf[u].z = act_fn(pf[u].z * ga.z + gb.z); pf[u].w = act_fn(pf[u].w * ga.w + gb.w);
+                    }
+            };
+            if (a.gate_act == FD_ACT_RELU) affine([](float v) { return fd_act(v, FD_ACT_RELU, 0.f); });
+            else if (a.gate_act == FD_ACT_SILU) affine([](float v) { return fd_act(v, FD_ACT_SILU, 0.f); });
+            else affine([](float v) { return v; });
+        }
 #pragma unroll
         for (int u = 0; u < NR_NLD; ++u)
             if (dst[u] >= 0) *reinterpret_cast<float4*>(patch + dst[u]) = pf[u];
@@ -168,14 +196,18 @@ extern "C" int32_t fd_conv_narrow_nco(int32_t Cout) {     // accumulators per pi
 
 int fd_launch_conv_narrow(const fd_conv_params* p, hipStream_t stream) {
     FD_REQUIRE(p->KH == 3 && p->KW == 3 && p->stride == 1 && p->dil == 1 && p->pad == 1 && p->Cout >= 1 && p->Cout <= 8 && p->Cin % NR_KC == 0 &&
-                   p->precision == FD_PREC_F32 && !p->res && !p->gate && !p->gn_stats && p->ksplit <= 1 && p->out_H <= 0 && p->sc_H <= 0,
-               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_NARROW needs an fp32 3x3 stride-1 pad-1 conv with Cout <= 8, Cin %% 16 == 0, no residual / gate / gn_stats / split-K / scatter");
+                   p->precision == FD_PREC_F32 && !p->res && !p->gn_stats && p->ksplit <= 1 && p->out_H <= 0 && p->sc_H <= 0,
+               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_NARROW needs an fp32 3x3 stride-1 pad-1 conv with Cout <= 8, Cin %% 16 == 0, no residual / gn_stats / split-K / scatter");
     FD_REQUIRE(p->x_cs % 4 == 0 && p->x_co % 4 == 0, FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_NARROW needs a 16-byte addressable input view");
+    FD_REQUIRE(!p->gate || (p->gate_b && p->gate_cs >= p->Cin && p->gate_cs % 4 == 0 && ((uintptr_t)p->gate & 15) == 0 && ((uintptr_t)p->gate_b & 15) == 0 &&
+                            (p->gate_act == FD_ACT_NONE || p->gate_act == FD_ACT_RELU || p->gate_act == FD_ACT_SILU)),
+               FD_E_INVAL, "fd_conv2d: FD_TILE_NARROW takes `gate` only with `gate_b` (a GroupNorm's affine), 16-byte aligned rows, gate_cs >= Cin, gate_act in {NONE, RELU, SILU}");
     NarrowArgs a;
     a.x = p->x; a.w = p->w; a.scale = p->scale; a.shift = p->shift; a.y = p->y;
     a.x_cs = p->x_cs; a.x_co = p->x_co; a.y_cs = p->y_cs; a.y_co = p->y_co;
     a.Cout = p->Cout; a.act = p->act; a.act_c0 = p->act_c0;
     a.NCH = p->Cin / NR_KC;
+    a.gate = p->gate; a.gate_b = p->gate_b; a.gate_cs = p->gate_cs; a.gate_act = p->gate_act;
     a.nseg = p->in.nseg; a.batch = p->in.batch;
     long t = 0;
     for (int s = 0; s < FD_MAX_SEG; ++s) {
@@ -195,10 +227,19 @@ int fd_launch_conv_narrow(const fd_conv_params* p, hipStream_t stream) {
     const long rows = p->in.m_start[p->in.nseg];
     FD_REQUIRE(rows * p->x_cs < (1L << 31) && rows * p->y_cs < (1L << 31), FD_E_UNSUPPORTED, "fd_conv2d: tensor exceeds 2^31 elements");
     const dim3 grid((unsigned)t), block(256);
-    switch (fd_conv_narrow_nco(p->Cout)) {
-        case 4: hipLaunchKernelGGL(conv3x3_narrow_kernel<4>, grid, block, 0, stream, a); break;
-        case 5: hipLaunchKernelGGL(conv3x3_narrow_kernel<5>, grid, block, 0, stream, a); break;
-        default: hipLaunchKernelGGL(conv3x3_narrow_kernel<8>, grid, block, 0, stream, a); break;
+    const int nco = fd_conv_narrow_nco(p->Cout);
+    if (p->gate) {
+        switch (nco) {
+            case 4: hipLaunchKernelGGL((conv3x3_narrow_kernel<4, true>), grid, block, 0, stream, a); break;
+            case 5: hipLaunchKernelGGL((conv3x3_narrow_kernel<5, true>), grid, block, 0, stream, a); break;
+            default: hipLaunchKernelGGL((conv3x3_narrow_kernel<8, true>), grid, block, 0, stream, a); break;
+        }
+    } else {
+        switch (nco) {
+            case 4: hipLaunchKernelGGL((conv3x3_narrow_kernel<4, false>), grid, block, 0, stream, a); break;
+            case 5: hipLaunchKernelGGL((conv3x3_narrow_kernel<5, false>), grid, block, 0, stream, a); break;
+            default: hipLaunchKernelGGL((conv3x3_narrow_kernel<8, false>), grid, block, 0, stream, a); break;
+        }
     }
     FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (narrow 3x3 on the vector unit)");
     return FD_OK;

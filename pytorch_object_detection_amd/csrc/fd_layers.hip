@@ -937,6 +937,34 @@ extern "C" int32_t fd_groupnorm_from_rowstats(const float* rowstats, int32_t C, 
     return FD_OK;
 }
 
+// statistics only (the first two steps of fd_groupnorm_act_nhwc) + optionally the per-(level, image, channel) affine of fd_groupnorm_from_rowstats:
+// for a map whose consumers normalise it themselves (a loader: fd_conv_params.gate_b) or in slices (fd_coef_apply_nhwc)
+extern "C" int32_t fd_groupnorm_stats_nhwc(const float* x, int32_t x_cs, int32_t x_co, int32_t C, int32_t G, float eps, const float* gamma, const float* beta,
+                                           const fd_segs* segs, void* workspace, float* coef, fd_stream_t stream) {
+    FD_REQUIRE(fd_segs_ok(segs), FD_E_INVAL, "fd_groupnorm_stats: bad segment table");
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && workspace, FD_E_INVAL, "fd_groupnorm_stats: bad pointer / channel view (C=%d)", C);
+    FD_REQUIRE(G >= 1 && C % G == 0 && C <= 1024 && 256 % (C / 4) == 0, FD_E_UNSUPPORTED,
+               "fd_groupnorm_stats: C=%d G=%d unsupported (C/4 must divide 256, C <= 1024)", C, G);
+    FD_REQUIRE(!coef || (gamma && beta && ((uintptr_t)coef & 15) == 0), FD_E_INVAL, "fd_groupnorm_stats: coef needs gamma, beta, 16-byte alignment");
+    FD_REQUIRE((long)segs->nseg * segs->batch <= 65535, FD_E_UNSUPPORTED, "fd_groupnorm_stats: too many (level, image) pairs");
+    SegTab tab; tab.s = *segs;
+    const int imgs = segs->nseg * segs->batch;
+    int maxhw = 0;
+    for (int s = 0; s < segs->nseg; ++s) maxhw = max(maxhw, segs->H[s] * segs->W[s]);
+    const int nchunk = min(GN_MAXCHUNK, (maxhw + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, imgs), dim3(256), 0, st, x, x_cs, x_co, C, G, tab, (double*)workspace);
+    FD_CHECK_LAUNCH("fd_groupnorm_stats (partial)");
+    double* gstat = (double*)workspace + (long)imgs * GN_MAXCHUNK * G * 2;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((G + 15) / 16, imgs), dim3(256), 0, st, C, G, eps, tab, (const double*)workspace, gstat);
+    FD_CHECK_LAUNCH("fd_groupnorm_stats (finalize)");
+    if (coef) {
+        hipLaunchKernelGGL(gn_coef_kernel, dim3(imgs), dim3(256), 0, st, (const double*)gstat, gamma, beta, C, G, coef);
+        FD_CHECK_LAUNCH("fd_groupnorm_stats (coef)");
+    }
+    return FD_OK;
+}
+
 // normalise + affine + activation from statistics already in `workspace` (fd_groupnorm_from_rowstats, or a previous fd_groupnorm_act_nhwc)
 extern "C" int32_t fd_groupnorm_apply_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* gamma, const float* beta, float* y,
                                            int32_t y_cs, int32_t y_co, int32_t C, int32_t G, float eps, int32_t act, const fd_segs* segs,
@@ -956,6 +984,55 @@ extern "C" int32_t fd_groupnorm_apply_nhwc(const float* x, int32_t x_cs, int32_t
     hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, imgs), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, gamma, beta, y, y_cs, y_co, C, G, eps,
                        act, tab, gstat);
     FD_CHECK_LAUNCH("fd_groupnorm_apply_nhwc");
+    return FD_OK;
+}
+
+// y = act(x * coef[img][0][c] + coef[img][1][c]) over a CHANNEL SLICE of a map whose GroupNorm statistics were reduced over more channels than
+// the slice (fd_groupnorm_from_rowstats' coef): the head tower's two GroupNorms are one 64-group reduction, its class half keeps a normalise
+// pass (the F(4x4) predictor has no registers for an affine in its loader) while the box half is normalised inside the narrow predictor's loader.
+__global__ __launch_bounds__(256) void coef_apply_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ ca,
+                                                          const float* __restrict__ cb, int coef_cs, float* __restrict__ y, int y_cs, int y_co,
+                                                          int C, int act, SegTab tab) {
+    const int img = blockIdx.y;
+    const int s = img / tab.s.batch, n = img - s * tab.s.batch;
+    const int HW = tab.s.H[s] * tab.s.W[s];
+    const int nblk = gridDim.x;
+    const int rows_per = (HW + nblk - 1) / nblk;
+    const int r_begin = blockIdx.x * rows_per, r_end = min(HW, r_begin + rows_per);
+    if (r_begin >= r_end) return;
+    const int tid = threadIdx.x;
+    const int C4 = C >> 2, q = tid % C4, rt = tid / C4, RT = 256 / C4;       // (host: C / 4 divides 256) a thread keeps one channel quad and walks rows
+    const long row0 = (long)tab.s.m_start[s] + (long)n * HW;
+    const float4 sa = *reinterpret_cast<const float4*>(ca + (long)img * coef_cs + 4 * q), sb = *reinterpret_cast<const float4*>(cb + (long)img * coef_cs + 4 * q);
+    const float* xp = x + (row0 + r_begin + rt) * x_cs + x_co + 4 * q;
+    float* yp = y + (row0 + r_begin + rt) * y_cs + y_co + 4 * q;
+    const long xs = (long)RT * x_cs, ys = (long)RT * y_cs;
+    for (int r = r_begin + rt; r < r_end; r += RT, xp += xs, yp += ys) {
+        const float4 v = *reinterpret_cast<const float4*>(xp);
+        float4 o;
+        o.x = fd_act(v.x * sa.x + sb.x, act, 0.f);
+        o.y = fd_act(v.y * sa.y + sb.y, act, 0.f);
+        o.z = fd_act(v.z * sa.z + sb.z, act, 0.f);
+        o.w = fd_act(v.w * sa.w + sb.w, act, 0.f);
+        *reinterpret_cast<float4*>(yp) = o;
+    }
+}
+
+extern "C" int32_t fd_coef_apply_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* coef_a, const float* coef_b, int32_t coef_cs, float* y,
+                                      int32_t y_cs, int32_t y_co, int32_t C, int32_t act, const fd_segs* segs, fd_stream_t stream) {
+    FD_REQUIRE(fd_segs_ok(segs), FD_E_INVAL, "fd_coef_apply: bad segment table");
+    FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C) && coef_a && coef_b && coef_cs >= C && coef_cs % 4 == 0 &&
+                   ((uintptr_t)coef_a & 15) == 0 && ((uintptr_t)coef_b & 15) == 0,
+               FD_E_INVAL, "fd_coef_apply: bad pointer / channel view / coefficient rows (C=%d)", C);
+    FD_REQUIRE(C >= 4 && C <= 1024 && 256 % (C / 4) == 0, FD_E_UNSUPPORTED, "fd_coef_apply: C=%d unsupported (C/4 must divide 256, C <= 1024)", C);
+    FD_REQUIRE((long)segs->nseg * segs->batch <= 65535, FD_E_UNSUPPORTED, "fd_coef_apply: too many (level, image) pairs");
+    SegTab tab; tab.s = *segs;
+    const int imgs = segs->nseg * segs->batch;
+    int maxhw = 0;
+    for (int s = 0; s < segs->nseg; ++s) maxhw = max(maxhw, segs->H[s] * segs->W[s]);
+    const int ablk = max(1, min(imgs >= 16 ? 64 : 512, (maxhw * (C / 4) + 2047) / 2048));
+    hipLaunchKernelGGL(coef_apply_kernel, dim3(ablk, imgs), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, coef_a, coef_b, coef_cs, y, y_cs, y_co, C, act, tab);
+    FD_CHECK_LAUNCH("fd_coef_apply_nhwc");
     return FD_OK;
 }
 

@@ -38,11 +38,12 @@
 #define ST_TPW 4                     // consecutive output tiles per workgroup (the 39 KB filter bank is staged once)
 
 struct StemArgs {
-    const float4* x; const float* w; const float* scale; const float* shift; float* y;
+    const float4* x; const float* xp;      // xp (NCHW instantiations): the reference's own [N][3][H][W] planes
+    const float* w; const float* scale; const float* shift; float* y;
     int y_cs, y_co, N, H, W, Ho, Wo, act, tiles_h, tiles_w;
 };
 
-template <bool POOL>
+template <bool POOL, bool NCHW>
 __global__ __launch_bounds__(256, 2) void stem7x7_kernel(StemArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ws = reinterpret_cast<float*>(smem);                   // [7 * 22][64]
@@ -74,14 +75,23 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(StemArgs a) {
     auto load_patch = [&](int t) {            // global -> registers (zero outside the image)
         int n, ho0, wo0;
         tile_pos(t, n, ho0, wo0);
-        const float4* xin = a.x + (size_t)n * a.H * a.W;
+        const size_t HW = (size_t)a.H * a.W;
+        const float4* xin = a.x + (size_t)n * HW;
+        const float* xpl = a.xp + (size_t)n * 3 * HW;
 #pragma unroll
         for (int u = 0; u < NPX; ++u) {
             const int i = tid + 256 * u;
             const int pr = i / ST_PC, pc = i - pr * ST_PC;
             const int hi = 2 * ho0 - 3 + pr, wi = 2 * wo0 - 3 + pc;
             pv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < ST_PR * ST_PC && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) pv[u] = xin[(size_t)hi * a.W + wi];
+            if (i < ST_PR * ST_PC && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) {
+                if constexpr (NCHW) {       // three plane reads, each coalesced along the patch row (consecutive threads = consecutive pixels)
+                    const float* q = xpl + (size_t)hi * a.W + wi;
+                    pv[u].x = q[0]; pv[u].y = q[HW]; pv[u].z = q[2 * HW];
+                } else {
+                    pv[u] = xin[(size_t)hi * a.W + wi];
+                }
+            }
         }
     };
     auto store_patch = [&]() {                // registers -> LDS, channel 3 dropped
@@ -245,14 +255,14 @@ __global__ __launch_bounds__(256) void stem_pool_zero_kernel(float* __restrict__
 }
 
 /* w packed [7 filter rows][22][64 cout]: k = 3 * q + c for filter column q and input channel c, k = 21 zero (ops.pack_stem7_weight). */
-static int stem_launch(bool pool, const float* x4, const float* w, const float* scale, const float* shift, float* y, int32_t y_cs, int32_t y_co, int32_t N,
+static int stem_launch(bool pool, bool nchw, const float* x4, const float* w, const float* scale, const float* shift, float* y, int32_t y_cs, int32_t y_co, int32_t N,
                        int32_t H, int32_t W, int32_t act, hipStream_t stream) {
     FD_REQUIRE(x4 && w && y && N >= 1 && H >= 2 && W >= 2, FD_E_INVAL, "fd_stem7x7: bad arguments");
-    FD_REQUIRE((((uintptr_t)x4 | (uintptr_t)w | (uintptr_t)y) & 15) == 0 && y_cs % 4 == 0 && y_co % 4 == 0 && y_cs >= y_co + ST_CO, FD_E_INVAL,
-               "fd_stem7x7: pointers must be 16-byte aligned and the 64-channel output view 4-aligned");
+    FD_REQUIRE(((((nchw ? (uintptr_t)0 : (uintptr_t)x4)) | (uintptr_t)w | (uintptr_t)y) & 15) == 0 && ((uintptr_t)x4 & 3) == 0 && y_cs % 4 == 0 && y_co % 4 == 0 &&
+                   y_cs >= y_co + ST_CO, FD_E_INVAL, "fd_stem7x7: pointers must be 16-byte aligned (the NCHW planes: 4-byte) and the 64-channel output view 4-aligned");
     FD_REQUIRE(act == FD_ACT_NONE || act == FD_ACT_RELU || act == FD_ACT_SILU, FD_E_INVAL, "fd_stem7x7: activation none / ReLU / SiLU");
     StemArgs a;
-    a.x = reinterpret_cast<const float4*>(x4); a.w = w; a.scale = scale; a.shift = shift; a.y = y;
+    a.x = reinterpret_cast<const float4*>(x4); a.xp = x4; a.w = w; a.scale = scale; a.shift = shift; a.y = y;
     a.y_cs = y_cs; a.y_co = y_co; a.N = N; a.H = H; a.W = W; a.act = act;
     a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1;
     a.tiles_h = (a.Ho + ST_TH - 1) / ST_TH; a.tiles_w = (a.Wo + ST_TW - 1) / ST_TW;
@@ -265,8 +275,9 @@ static int stem_launch(bool pool, const float* x4, const float* w, const float* 
         const long blocks = (long)N * a.tiles_w * (a.tiles_h / ST_TPW);
         FD_REQUIRE(blocks < (1L << 31), FD_E_UNSUPPORTED, "fd_stem7x7: too many tiles");
         constexpr int lds = (7 * ST_KR * ST_CO + ST_PR * ST_PITCH + 4 * 1024 + 32 * 64) * 4;   // 81 KB: filter bank + patch + stages (= the tile buffer) + carry row
-        static std::atomic<unsigned> attr_mask{0};
-        fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(stem7x7_kernel<true>), lds);
+        static std::atomic<unsigned> attr_mask{0}, attr_mask_p{0};
+        if (nchw) fd_set_max_lds_once(attr_mask_p, reinterpret_cast<const void*>(stem7x7_kernel<true, true>), lds);
+        else fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(stem7x7_kernel<true, false>), lds);
         {
             const int Hp = (a.Ho - 1) / 2 + 1, Wp = (a.Wo - 1) / 2 + 1;
             long g = ((long)N * Hp * Wp * 16 + 255) / 256;
@@ -274,26 +285,40 @@ static int stem_launch(bool pool, const float* x4, const float* w, const float* 
             hipLaunchKernelGGL(stem_pool_zero_kernel, dim3((unsigned)g), dim3(256), 0, stream, y, y_cs, y_co, N, Hp, Wp);
             FD_CHECK_LAUNCH("fd_stem7x7_pool_nhwc4 (zero)");
         }
-        hipLaunchKernelGGL(stem7x7_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
-        FD_CHECK_LAUNCH("fd_stem7x7_pool_nhwc4");
+        if (nchw) hipLaunchKernelGGL((stem7x7_kernel<true, true>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((stem7x7_kernel<true, false>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+        FD_CHECK_LAUNCH("fd_stem7x7 (+ max-pool)");
         return FD_OK;
     }
     const long blocks = ((long)N * a.tiles_h * a.tiles_w + ST_TPW - 1) / ST_TPW;
     FD_REQUIRE(blocks < (1L << 31), FD_E_UNSUPPORTED, "fd_stem7x7: too many tiles");
     constexpr int lds = (ST_PR * ST_PITCH + 7 * ST_KR * ST_CO + 4 * 1024) * 4;       // 73 KB: patch + filter bank + transpose stages
-    static std::atomic<unsigned> attr_mask{0};
-    fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(stem7x7_kernel<false>), lds);
-    hipLaunchKernelGGL(stem7x7_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
-    FD_CHECK_LAUNCH("fd_stem7x7_nhwc4");
+    static std::atomic<unsigned> attr_mask{0}, attr_mask_p{0};
+    if (nchw) {
+        fd_set_max_lds_once(attr_mask_p, reinterpret_cast<const void*>(stem7x7_kernel<false, true>), lds);
+        hipLaunchKernelGGL((stem7x7_kernel<false, true>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    } else {
+        fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(stem7x7_kernel<false, false>), lds);
+        hipLaunchKernelGGL((stem7x7_kernel<false, false>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    }
+    FD_CHECK_LAUNCH("fd_stem7x7");
     return FD_OK;
 }
 
 extern "C" int32_t fd_stem7x7_nhwc4(const float* x4, const float* w, const float* scale, const float* shift, float* y, int32_t y_cs,
                                     int32_t y_co, int32_t N, int32_t H, int32_t W, int32_t act, fd_stream_t stream_) {
-    return stem_launch(false, x4, w, scale, shift, y, y_cs, y_co, N, H, W, act, (hipStream_t)stream_);
+    return stem_launch(false, false, x4, w, scale, shift, y, y_cs, y_co, N, H, W, act, (hipStream_t)stream_);
 }
 
 extern "C" int32_t fd_stem7x7_pool_nhwc4(const float* x4, const float* w, const float* scale, const float* shift, float* y_pooled, int32_t y_cs,
                                          int32_t y_co, int32_t N, int32_t H, int32_t W, fd_stream_t stream_) {
-    return stem_launch(true, x4, w, scale, shift, y_pooled, y_cs, y_co, N, H, W, FD_ACT_RELU, (hipStream_t)stream_);
+    return stem_launch(true, false, x4, w, scale, shift, y_pooled, y_cs, y_co, N, H, W, FD_ACT_RELU, (hipStream_t)stream_);
+}
+
+// the same two kernels reading the reference's own input layout -- fp32 [N][3][H][W] planes (dataset/voc.py:141-173) -- in their patch loaders: the
+// fd_nchw3_to_nhwc4 pass (a read of the batch and a write of its 4-channel copy) disappears.  pool != 0: + ReLU + max-pool as fd_stem7x7_pool_nhwc4 (act ignored).
+extern "C" int32_t fd_stem7x7_nchw3(const float* x, const float* w, const float* scale, const float* shift, float* y, int32_t y_cs, int32_t y_co,
+                                    int32_t N, int32_t H, int32_t W, int32_t act, int32_t pool, fd_stream_t stream_) {
+    FD_REQUIRE((long)N * 3 * H * W < (1L << 31), FD_E_UNSUPPORTED, "fd_stem7x7_nchw3: input exceeds 2^31 elements");
+    return stem_launch(pool != 0, true, x, w, scale, shift, y, y_cs, y_co, N, H, W, pool ? FD_ACT_RELU : act, (hipStream_t)stream_);
 }

@@ -34,12 +34,14 @@ AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see 
 WINOGRAD = _os.environ.get("FD_WINOGRAD", "1") != "0"
 SE_GATE_IN_PROJECT = _os.environ.get("FD_SE_GATE_FUSED", "1") != "0"     # MBConv: SE gate applied by the project conv's loader ("0": a scaling pass)
 GN_FUSED_TOWER = _os.environ.get("FD_GN_FUSED_TOWER", "0") == "1"   # "1": the tower's statistics from its Winograd epilogue too (measured neutral, costs the tower launch 5 %)
+TOWER_GN_SPLIT = _os.environ.get("FD_TOWER_GN_SPLIT", "1") != "0"   # "0": the tower's GroupNorm normalises both halves in its own pass (else the box half in the narrow predictor's loader)
 GN_FUSED = _os.environ.get("FD_GN_FUSED", "1") != "0"       # "0": HISFCOSHead's GroupNorms as three-pass launches (statistics / finalise / normalise)
 WAVE_TILE = _os.environ.get("FD_WAVE_TILE", "1") != "0"       # "0": the 1x1 layers never see FD_TILE_WAVE64 (wave-autonomous tiles, fd_conv_wave.hip)
 DUAL_DS = _os.environ.get("FD_DUAL_DS", "1") != "0"      # "0": a block's downsample conv as its own launch, its output read back as conv3's residual
 # FD_B2B: the trunk layers (digits) whose conv3 -> next-block conv1 seams run as ONE back-to-back launch (fd_conv1x1_b2b_f32: the 4 * planes wide map is
 # written once and never read back); "" = none
 B2B_LAYERS = _os.environ.get("FD_B2B", "1")
+STEM_NCHW = _os.environ.get("FD_STEM_NCHW", "1") != "0"         # "0": an fp32 NCHW input batch is first copied to the [N][H][W][4] layout (fd_nchw3_to_nhwc4) instead of being read by the stem's loader
 STEM_POOL = _os.environ.get("FD_STEM_POOL", "1") != "0"         # "0": the stem's 3x3 s2 max-pool as its own launch (the 64-channel stride-2 map written and read back)
 STEM_KERNEL = _os.environ.get("FD_STEM_KERNEL", "1") != "0"     # "0": the ResNet stem through the generic conv kernel's FD_CONV_STEM mode
 
@@ -204,7 +206,8 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     split = plan.precision == "f16x3" or (plan.precision == "mixed" and k == 1 and stride == 1 and gate is None and gn_stats is None
                                            and Cin % 32 == 0)
     # <= 8 output channels (the centre-ness / box predictor): the vector-unit kernel, where the map has enough tiles to fill the chip
-    narrow = (ops.NARROW and plan.precision in ("f32", "mixed") and res is None and gate is None and gn_stats is None and w.shape[0] == co
+    # (a gate there is the preceding GroupNorm's affine: gate + gate_b, applied to the patch)
+    narrow = (ops.NARROW and plan.precision in ("f32", "mixed") and res is None and (gate is None or gate_b is not None) and gn_stats is None and w.shape[0] == co
               and ops.narrow_ok(Cin, co, k, stride, pad, dil) and ops.narrow_tiles(segs) >= ops.NARROW_MIN_TILES)
     if narrow:
         split = False
@@ -320,8 +323,14 @@ def add_input(plan: Plan, x4: Rows, batch: int, H: int, W: int, image_ref: List)
 def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: List[torch.Tensor]):
     """torchvision-style ResNet-50 v1.5 trunk -> (C3, C4, C5) as (Rows, Segs).  `trunk` has conv1, bn1, layer1..4."""
     dev, pool = plan.device, plan.pool
-    x4 = pool.get(batch * H * W, 4)
-    add_input(plan, x4, batch, H, W, image_ref)
+    stem_own = STEM_KERNEL and plan.precision in ("f32", "mixed") and tuple(trunk.conv1.weight.shape) == (64, 3, 7, 7)
+    mode = getattr(plan, "input_mode", None) or ("u8" if getattr(plan, "input_u8", None) else None)
+    # the reference's fp32 NCHW batch is read by the stem's own patch loader (fd_stem7x7_nchw3): no [N][H][W][4] copy, no conversion launch
+    nchw_in = STEM_NCHW and stem_own and mode is None
+    x4 = None
+    if not nchw_in:
+        x4 = pool.get(batch * H * W, 4)
+        add_input(plan, x4, batch, H, W, image_ref)
     s_in = Segs.make(batch, [(H, W)])
     # stem 7x7 s2 + BN + ReLU
     sc, sf = ops.fold_bn(_dev(trunk.bn1.weight, dev), _dev(trunk.bn1.bias, dev), _dev(trunk.bn1.running_mean, dev),
@@ -330,22 +339,36 @@ def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: Lis
     H1, W1 = s1.H[0], s1.W[0]
     H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
     s2 = Segs.make(batch, [(H2, W2)])
-    fused_pool = STEM_POOL and STEM_KERNEL and plan.precision in ("f32", "mixed") and tuple(trunk.conv1.weight.shape) == (64, 3, 7, 7)
+    fused_pool = STEM_POOL and stem_own
+
+    def nchw_image() -> torch.Tensor:
+        x = image_ref[0]
+        if tuple(x.shape) != (batch, 3, H, W):
+            raise FdError(f"plan input: expected a [{batch}, 3, {H}, {W}] batch, got {tuple(x.shape)}")
+        return x
+
     if fused_pool:
         # conv1 + bn1 + relu + maxpool as ONE launch (fd_stem7x7_pool_nhwc4): the 64-channel stride-2 map is never written (resnet50.py:68-80)
         wp = ops.pack_stem7_weight(_dev(trunk.conv1.weight, dev))
         y2 = pool.get(s2.rows, 64)
-        plan.add("backbone.conv1+maxpool", lambda: ops.stem7x7_pool(x4, wp, y2, batch, H, W, sc, sf))
+        if nchw_in:
+            plan.add("backbone.conv1+maxpool", lambda: ops.stem7x7_nchw(nchw_image(), wp, y2, sc, sf, pool=True))
+        else:
+            plan.add("backbone.conv1+maxpool", lambda: ops.stem7x7_pool(x4, wp, y2, batch, H, W, sc, sf))
         plan.keep += [wp, sc, sf]
         plan.flops += 2 * s1.rows * 64 * 147
         plan.step_flops[len(plan.steps) - 1] = 2 * s1.rows * 64 * 147
-        pool.put(x4)
+        if x4 is not None:
+            pool.put(x4)
     y1 = pool.get(s1.rows, 64) if not fused_pool else None
     if fused_pool:
         pass
-    elif STEM_KERNEL and plan.precision in ("f32", "mixed") and tuple(trunk.conv1.weight.shape) == (64, 3, 7, 7):
+    elif stem_own:
         wp = ops.pack_stem7_weight(_dev(trunk.conv1.weight, dev))      # the dedicated stem kernel (fd_stem.hip): patch + filters staged in LDS
-        plan.add("backbone.conv1", lambda: ops.stem7x7(x4, wp, y1, batch, H, W, sc, sf, ACT_RELU))
+        if nchw_in:
+            plan.add("backbone.conv1", lambda: ops.stem7x7_nchw(nchw_image(), wp, y1, sc, sf, ACT_RELU))
+        else:
+            plan.add("backbone.conv1", lambda: ops.stem7x7(x4, wp, y1, batch, H, W, sc, sf, ACT_RELU))
     else:
         wp = ops.pack_stem_weight(_dev(trunk.conv1.weight, dev))
         plan.add("backbone.conv1", ops.conv_call(x4, s_in, wp, y1, Cin=4, Cout=64, k=7, stride=2, pad=3, scale=sc, shift=sf,
@@ -354,7 +377,8 @@ def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: Lis
         plan.keep += [wp, sc, sf]
         plan.flops += 2 * s1.rows * 64 * 147
         plan.step_flops[len(plan.steps) - 1] = 2 * s1.rows * 64 * 147
-        pool.put(x4)
+        if x4 is not None:
+            pool.put(x4)
         y2 = pool.get(s2.rows, 64)
         plan.add("backbone.maxpool", lambda: ops.maxpool(y1, y2, batch, H1, W1, 3, 2, 1))
         pool.put(y1)
@@ -628,8 +652,17 @@ def build_his_fpn(plan: Plan, fpn, feats):
 
 
 # ------------------------------------------------------------------------------------------------ heads
-def _out_convs(plan: Plan, head, tower: Rows, segs: Segs, F: int, ncls: int):
-    """cls_logits on tower[:, :F]; cnt_logits + reg_pred (+ScaleExp) on tower[:, F:] as one 5-wide conv."""
+def _narrow_predictor(plan: Plan, head, segs: Segs, F: int) -> bool:
+    """Does the 1 + 4-wide centre-ness / box predictor of this plan run on the vector-unit kernel (FD_TILE_NARROW)?"""
+    rp = head.reg_pred
+    rp_pad = rp.dilation[0] * (rp.kernel_size[0] - 1) // 2 if isinstance(rp.padding, str) else rp.padding[0]
+    return bool(ops.NARROW and plan.precision in ("f32", "mixed") and ops.narrow_ok(F, 5, rp.kernel_size[0], rp.stride[0], rp_pad, rp.dilation[0])
+                and ops.narrow_tiles(segs) >= ops.NARROW_MIN_TILES)
+
+
+def _out_convs(plan: Plan, head, tower: Rows, segs: Segs, F: int, ncls: int, reg_gate=None):
+    """cls_logits on tower[:, :F]; cnt_logits + reg_pred (+ScaleExp) on tower[:, F:] as one 5-wide conv.  reg_gate = (a, b, act): tower[:, F:] is
+    still the RAW tower output and the narrow predictor applies its GroupNorm affine + activation in its loader (build_his_head)."""
     dev, pool = plan.device, plan.pool
     M = segs.rows
     cls = pool.get(M, ncls if ncls % 4 == 0 else ncls + (4 - ncls % 4))
@@ -640,8 +673,9 @@ def _out_convs(plan: Plan, head, tower: Rows, segs: Segs, F: int, ncls: int):
     scales = [float(s.scale.detach().reshape(-1)[0]) for s in head.scale_exp][:segs.nseg]
     rp = head.reg_pred
     rp_pad = rp.dilation[0] * (rp.kernel_size[0] - 1) // 2 if isinstance(rp.padding, str) else rp.padding[0]
-    narrow = (ops.NARROW and plan.precision in ("f32", "mixed") and ops.narrow_ok(F, 5, rp.kernel_size[0], rp.stride[0], rp_pad, rp.dilation[0])
-              and ops.narrow_tiles(segs) >= ops.NARROW_MIN_TILES)
+    narrow = _narrow_predictor(plan, head, segs, F)
+    if reg_gate is not None and not narrow:
+        raise FdError("_out_convs: a GroupNorm folded into the box predictor's loader needs the narrow kernel")
     if not narrow and plan.winograd and ops.wino_ok(F, 8, rp.kernel_size[0], rp.stride[0], rp_pad, rp.dilation[0]) and ops.wino_choice(segs, F, 8, rp.dilation[0])[0]:
         # the Winograd kernel writes whole float4s: three zero filters fill the 8-wide buffer (channels 5..7 hold exp(0) = 1, never read);
         # 0.27 -> 0.17 ms against the direct kernel's 128 x 32 tile at Cout = 5
@@ -652,8 +686,9 @@ def _out_convs(plan: Plan, head, tower: Rows, segs: Segs, F: int, ncls: int):
         plan.flops -= 2 * segs.rows * 3 * F * 9          # (count the 5 real filters only)
         plan.step_flops[len(plan.steps) - 1] -= 2 * segs.rows * 3 * F * 9
     else:
+        g = {} if reg_gate is None else {"gate": reg_gate[0], "gate_b": reg_gate[1], "gate_act": reg_gate[2]}
         add_conv(plan, "head.cnt_reg", tower.slice(F, F), segs, head.reg_pred, cr.slice(0, 5), weight=w, bias=b, Cout=5,
-                 act=ACT_EXP, act_c0=1, seg_param=scales)
+                 act=ACT_EXP, act_c0=1, seg_param=scales, **g)
     return cls.slice(0, ncls), cr.slice(0, 1), cr.slice(1, 4)
 
 
@@ -739,12 +774,34 @@ def build_his_head(plan: Plan, head, pyr: Rows, segs: Segs):
         rgs3 = pool.get(M, 2 * Gt)
         add_conv(plan, "head.tower3x3", z, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F, tag=1, gn_stats=rgs3.buf, gn_groups=Gt)
         plan.marks["head.tower3x3"] = (mark, len(plan.steps))
-        ws, gamma, beta, G, eps, _ = _gn_from_rowstats(plan, "head.tower_gn.stats", rgs3, segs, tgn, 2 * F, False)
+        reg_in_loader = TOWER_GN_SPLIT and _narrow_predictor(plan, head, segs, F)
+        ws, gamma, beta, G, eps, coef = _gn_from_rowstats(plan, "head.tower_gn.stats", rgs3, segs, tgn, 2 * F, reg_in_loader)
         pool.put(rgs3)
+        if reg_in_loader:
+            # the box half of the tower is normalised inside the narrow predictor's patch loader; only the class half (whose consumer is the
+            # F(4x4) kernel: no registers for an affine in its loader) keeps a normalise pass -- over half the bytes
+            tc = tower.slice(0, F)
+            plan.add("head.tower_gn", lambda: ops.coef_apply(tc, coef[:, 0, :F], coef[:, 1, :F], tc, segs, ACT_RELU))
+            pool.put(z)
+            return _out_convs(plan, head, tower, segs, F, ncls, reg_gate=(coef[:, 0, F:], coef[:, 1, F:], ACT_RELU))
         plan.add("head.tower_gn", lambda: ops.groupnorm_apply(tower, gamma, beta, tower, segs, G, ACT_RELU, ws, eps))
     else:
         add_conv(plan, "head.tower3x3", z, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F, tag=1)
         plan.marks["head.tower3x3"] = (mark, len(plan.steps))
+        if TOWER_GN_SPLIT and _narrow_predictor(plan, head, segs, F) and 256 % (F // 4) == 0:
+            # statistics of both halves in one pass; the class half keeps a normalise pass (over half the bytes), the box half is normalised inside
+            # the narrow predictor's patch loader (fd_conv_params.gate_b on FD_TILE_NARROW): same arithmetic, bit-identical outputs
+            gamma = torch.cat([_dev(g.weight, dev) for g in tgn]).contiguous()
+            beta = torch.cat([_dev(g.bias, dev) for g in tgn]).contiguous()
+            G, eps = sum(g.num_groups for g in tgn), tgn[0].eps
+            ws = ops.groupnorm_workspace(segs, G, dev)
+            coef = torch.empty(segs.nseg * segs.batch, 2, 2 * F, dtype=torch.float32, device=dev)
+            plan.keep += [gamma, beta, ws, coef]
+            plan.add("head.tower_gn.stats", lambda: ops.groupnorm_stats(tower, gamma, beta, segs, G, ws, eps, coef))
+            tc = tower.slice(0, F)
+            plan.add("head.tower_gn", lambda: ops.coef_apply(tc, coef[:, 0, :F], coef[:, 1, :F], tc, segs, ACT_RELU))
+            pool.put(z)
+            return _out_convs(plan, head, tower, segs, F, ncls, reg_gate=(coef[:, 0, F:], coef[:, 1, F:], ACT_RELU))
         _fused_gn(plan, "head.tower_gn", tower, segs, tgn, ACT_RELU)
     pool.put(z)
     return _out_convs(plan, head, tower, segs, F, ncls)

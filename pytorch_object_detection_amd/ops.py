@@ -148,6 +148,18 @@ def stem7x7_pool(x4: Rows, w722: torch.Tensor, y: Rows, N: int, H: int, W: int, 
           "fd_stem7x7_pool_nhwc4")
 
 
+def stem7x7_nchw(x: torch.Tensor, w722: torch.Tensor, y: Rows, scale=None, shift=None, act: int = ACT_NONE, pool: bool = False) -> None:
+    """The stem (pool: + ReLU + max-pool 3x3 s2 p1) straight from the reference's fp32 [N, 3, H, W] input tensor (fd_stem7x7_nchw3): the planes are
+    read by the patch loader, no [N][H][W][4] copy of the batch is made."""
+    _need_gpu(x, w722, scale, shift)
+    if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_contiguous() or y.C != 64:
+        raise FdError("stem7x7_nchw: input must be a contiguous fp32 [N, 3, H, W] tensor, output a 64-channel view")
+    N, _, H, W = x.shape
+    check(_lib.lib().fd_stem7x7_nchw3(x.data_ptr(), w722.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                      shift.data_ptr() if shift is not None else None, y.ptr, y.cs, y.co, N, H, W, act, 1 if pool else 0, _stream()),
+          "fd_stem7x7_nchw3")
+
+
 def pack_dw_weight(w: torch.Tensor) -> torch.Tensor:
     """[C,1,3,3] -> [9][C]."""
     return w.detach().reshape(w.shape[0], 9).t().contiguous().float()
@@ -821,6 +833,26 @@ def groupnorm_apply(x: Rows, gamma: torch.Tensor, beta: torch.Tensor, y: Rows, s
     """y = act(GroupNorm(x)) from statistics already in `ws` (groupnorm_from_rowstats / an earlier groupnorm_act): one pass over the map."""
     check(_lib.lib().fd_groupnorm_apply_nhwc(x.ptr, x.cs, x.co, gamma.data_ptr(), beta.data_ptr(), y.ptr, y.cs, y.co, x.C, G, eps, act,
                                              C.byref(segs), ws.data_ptr(), _stream()), "fd_groupnorm_apply_nhwc")
+
+
+def groupnorm_stats(x: Rows, gamma: torch.Tensor, beta: torch.Tensor, segs: Segs, G: int, ws: torch.Tensor, eps: float = 1e-5,
+                    coef: Optional[torch.Tensor] = None) -> None:
+    """GroupNorm statistics of x per (level, image, group) into `ws` (groupnorm_workspace layout) and, with `coef` [levels * batch, 2, C], the
+    affine (rstd * gamma, beta - mean * rstd * gamma) for consumers that normalise themselves (conv_call(gate_b=...), coef_apply)."""
+    _need_gpu(ws, coef, gamma, beta)
+    check(_lib.lib().fd_groupnorm_stats_nhwc(x.ptr, x.cs, x.co, x.C, G, eps, gamma.data_ptr(), beta.data_ptr(), C.byref(segs), ws.data_ptr(),
+                                             coef.data_ptr() if coef is not None else None, _stream()), "fd_groupnorm_stats_nhwc")
+
+
+def coef_apply(x: Rows, coef_a: torch.Tensor, coef_b: torch.Tensor, y: Rows, segs: Segs, act: int) -> None:
+    """y = act(x * coef_a[img] + coef_b[img]) over x's channel view: coef_a / coef_b are [levels * batch, x.C] views (unit channel stride, same row
+    stride) into groupnorm_from_rowstats' coef -- the normalise pass of a channel SLICE of a jointly reduced map."""
+    _need_gpu(coef_a, coef_b)
+    if (coef_a.dim() != 2 or coef_a.shape != (segs.batch * segs.nseg, x.C) or coef_b.shape != coef_a.shape or coef_a.stride() != coef_b.stride()
+            or coef_a.stride(1) != 1 or coef_a.dtype != torch.float32 or coef_b.dtype != torch.float32):
+        raise FdError("coef_apply: coef_a / coef_b must be [levels * batch, C] fp32 views with unit channel stride and equal row strides")
+    check(_lib.lib().fd_coef_apply_nhwc(x.ptr, x.cs, x.co, coef_a.data_ptr(), coef_b.data_ptr(), coef_a.stride(0), y.ptr, y.cs, y.co, x.C, act,
+                                        C.byref(segs), _stream()), "fd_coef_apply_nhwc")
 
 
 def dwconv3x3_gn(x: Rows, w9c: torch.Tensor, y: Rows, segs: Segs, in_coef: Optional[torch.Tensor], in_act: int,

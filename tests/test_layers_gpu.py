@@ -1288,6 +1288,58 @@ def test_conv3x3_narrow_on_the_vector_unit(case):
         ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(torch.empty(segs.rows, 12, device=DEV), 0, 9), Cin=Cin, Cout=9, k=3, pad=1, tile=_lib.NARROW_TILE)()
 
 
+@pytest.mark.parametrize("case", [(256, 5, 512, 64, [(40, 40), (20, 20), (10, 10), (5, 5), (3, 3)], 2, ACT_RELU), (32, 8, 64, 16, [(17, 23), (2, 1)], 3, ACT_SILU),
+                                  (64, 4, 128, 8, [(33, 16)], 1, ACT_NONE)])
+def test_groupnorm_split_between_a_slice_pass_and_the_narrow_loader(case):
+    """The head tower's GroupNorm + ReLU (HISFcos.py:221-225) without a normalise pass over the box half: fd_groupnorm_stats_nhwc leaves the statistics
+    of the WHOLE map and the per-(level, image, channel) affine; fd_coef_apply_nhwc normalises the class slice; the FD_TILE_NARROW predictor applies the
+    affine + activation of ITS slice to the patch on its way to LDS (fd_conv_params.gate / gate_b), padding zero after the normalisation.  Both must
+    equal, BIT FOR BIT, the three-pass fd_groupnorm_act_nhwc followed by the ungated predictor; the statistics themselves are checked against
+    F.group_norm in fp64."""
+    from pytorch_object_detection_amd import _lib
+    Cin, Cout, Ct, G, hw, B, act = case                       # the predictor reads the LAST Cin channels of a Ct-channel map normalised in G groups
+    gen = torch.Generator().manual_seed(Cin + Cout + Ct + len(hw))
+    segs = Segs.make(B, hw)
+    xs = [torch.randn(B, Ct, h, w, generator=gen) * 1.7 + 0.4 for h, w in hw]
+    gamma, beta = torch.rand(Ct, generator=gen) + 0.5, torch.randn(Ct, generator=gen) * 0.3
+    wt = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout, generator=gen) * 0.3
+    raw = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Ct) for t in xs]).to(DEV).contiguous()
+    wp = ops.pack_conv_weight_narrow(wt.to(DEV))
+    g_, b_ = gamma.to(DEV), beta.to(DEV)
+    # reference: normalise pass over the whole map, then the plain predictor on its slice
+    norm = raw.clone()
+    ws0 = ops.groupnorm_workspace(segs, G, DEV)
+    ops.groupnorm_act(ops.Rows(norm), g_, b_, ops.Rows(norm), segs, G, act, ws0, 1e-5)
+    y0 = torch.full((segs.rows, 8), float("nan"), device=DEV)
+    ops.conv_call(ops.Rows(norm, Ct - Cin, Cin), segs, wp, ops.Rows(y0, 0, Cout), Cin=Cin, Cout=Cout, k=3, pad=1, shift=bias.to(DEV), tile=_lib.NARROW_TILE)()
+    # split: statistics + affine, slice pass over the first Ct - Cin channels, gated predictor on the raw rest
+    cur = raw.clone()
+    ws1 = ops.groupnorm_workspace(segs, G, DEV)
+    coef = torch.empty(segs.nseg * B, 2, Ct, device=DEV)
+    ops.groupnorm_stats(ops.Rows(cur), g_, b_, segs, G, ws1, 1e-5, coef)
+    Cs = Ct - Cin
+    sl = ops.Rows(cur, 0, Cs)
+    ops.coef_apply(sl, coef[:, 0, :Cs], coef[:, 1, :Cs], sl, segs, act)
+    y1 = torch.full((segs.rows, 8), float("nan"), device=DEV)
+    run = ops.conv_call(ops.Rows(cur, Cs, Cin), segs, wp, ops.Rows(y1, 0, Cout), Cin=Cin, Cout=Cout, k=3, pad=1, shift=bias.to(DEV), tile=_lib.NARROW_TILE,
+                        gate=coef[:, 0, Cs:], gate_b=coef[:, 1, Cs:], gate_act=act)
+    run()
+    assert torch.equal(cur[:, :Cs], norm[:, :Cs]), "the slice pass differs from the whole-map normalise pass"
+    assert torch.equal(cur[:, Cs:], raw[:, Cs:]), "the predictor's slice must stay raw"
+    assert torch.equal(y1[:, :Cout], y0[:, :Cout]), "GroupNorm in the loader differs from GroupNorm in its own pass"
+    assert torch.isnan(y1[:, Cout:]).all()
+    # and against the definition (fp64)
+    for i, ((h, w), x) in enumerate(zip(hw, xs)):
+        n = F.group_norm(x.double(), G, gamma.double(), beta.double(), 1e-5)
+        n = {ACT_NONE: n, ACT_RELU: F.relu(n), ACT_SILU: F.silu(n)}[act]
+        r = F.conv2d(n[:, Cs:], wt.double(), bias.double(), 1, 1).float()
+        g = y1[segs.m_start[i]:segs.m_start[i + 1], :Cout].cpu().reshape(B, h, w, Cout).permute(0, 3, 1, 2)
+        np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=3e-5, atol=2e-5, err_msg=f"level {i}")
+    with pytest.raises(Exception, match="gate_b"):          # a bare multiplicative gate has no meaning on a padded conv: clean error, no launch
+        ops.conv_call(ops.Rows(cur, Cs, Cin), segs, wp, ops.Rows(y1, 0, Cout), Cin=Cin, Cout=Cout, k=3, pad=1, tile=_lib.NARROW_TILE, gate=coef[:, 0, Cs:])()
+
+
 @pytest.mark.parametrize("case", [(64, 256, 64, 3 * 33 * 17, True), (64, 256, 128, 2 * 40 * 40, True), (128, 512, 128, 1000, True), (32, 64, 64, 77, False),
                                   (256, 1024, 128, 513, True)])
 def test_conv1x1_back_to_back_is_bit_identical_to_two_launches(case):
@@ -1392,6 +1444,19 @@ def test_stem_with_fused_maxpool_is_bit_identical_to_two_launches(shape):
     ref = F.max_pool2d(torch.relu(F.conv2d(x.double(), w.double(), None, 2, 3) * sc.cpu().double()[None, :, None, None] + sf.cpu().double()[None, :, None, None]), 3, 2, 1)
     got = z.tensor().cpu().reshape(B, H2, W2, 64).permute(0, 3, 1, 2)
     np.testing.assert_allclose(got.numpy(), ref.float().numpy(), rtol=2e-5, atol=2e-5)
+    # fd_stem7x7_nchw3: both kernels with the reference's own [N, 3, H, W] tensor read by the patch loader (no [N][H][W][4] copy) -- the same values in the
+    # same order: bit-identical; the input sits inside a larger allocation whose neighbours are NaN
+    pad = torch.full((B * 3 * H * W + 32,), float("nan"), device=DEV)
+    xn = pad[16:16 + B * 3 * H * W].view(B, 3, H, W)
+    xn.copy_(x.to(DEV))
+    zb2 = torch.full((B * H2 * W2, 72), float("nan"), device=DEV)
+    ops.stem7x7_nchw(xn, wp, ops.Rows(zb2, 4, 64), sc, sf, pool=True)
+    assert torch.equal(zb2.nan_to_num(7.0), zb.nan_to_num(7.0))
+    y1n = ops.new_rows(B * H1 * W1, 64, DEV)
+    ops.stem7x7_nchw(xn, wp, y1n, sc, sf, ACT_RELU)
+    assert torch.equal(y1n.tensor(), y1.tensor())
+    with pytest.raises(Exception, match="contiguous fp32"):
+        ops.stem7x7_nchw(xn.permute(0, 1, 3, 2), wp, y1n, sc, sf, ACT_RELU)
 
 
 def test_conv3x3_winograd_f4x4_at_the_start_of_an_allocation():
