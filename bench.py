@@ -85,6 +85,13 @@ def pmc_traffic():
         return None, None
 
 
+def tower_launch_share(plan) -> float:
+    """Share of the head tower's work the TIMED launch does: 1.0, or -- when the plan runs the tower as whole rounds of workgroups + a tail launch
+    (engine.TOWER_TAIL_SPLIT; the mark, and so the HIP events, cover the whole rounds) -- its share of the non-empty workgroups."""
+    t = getattr(plan, "tail_of", {}).get("head.tower3x3")
+    return float(t["main_share"]) if t else 1.0
+
+
 def tower_roofline(plan, tower_flops: int, tower_ms: float) -> dict:
     """Roofline object of the dominant kernel, the fused cls_conv + reg_conv 3x3 head tower (5 levels, one launch).
     `achieved` / `frac` count the FLOPs the matrix pipe EXECUTES in the launch, over its HIP-event time, against the dense fp32-MFMA
@@ -101,7 +108,14 @@ def tower_roofline(plan, tower_flops: int, tower_ms: float) -> dict:
     achieved = executed_flops / (tower_ms * 1e-3) / 1e12
     traffic, tsrc = pmc_traffic()
     what = "head tower 3x3 (cls_conv+reg_conv fused, 5 levels)"
-    return {"bound": "mfma",
+    t = getattr(plan, "tail_of", {}).get("head.tower3x3")
+    launch = None
+    if t:
+        what += f", workgroups [0, {t['main']}) of {t['workgroups']}"
+        launch = (f"the layer runs as two launches of the same kernel: workgroups [0, {t['main']}) = {t['main'] // 256} whole rounds on 256 CUs (this launch: "
+                  f"{100 * t['main_share']:.2f} % of the layer's {t['live']} non-empty workgroups, FLOPs counted pro rata) and a {t['workgroups'] - t['main']}-workgroup tail launch "
+                  "(plan step head.tower3x3.tail, kernel instantiation TAG=0) beside which the other batch in flight runs (DESIGN 4.1k)")
+    return {"bound": "mfma", "launch": launch,
             "kernel": (f"conv3x3_wino4_kernel<TAG=1> {what}: Winograd F(4x4,3x3), fp32" if wino4 else
                        f"conv3x3_wino_kernel<TAG=1> {what}: Winograd F(2x2,3x3), fp32" if wino else
                        f"conv_igemm_kernel<...,TAG=1> {what}, tile id {tile}"),
@@ -442,7 +456,7 @@ def fast_mode(model, head, clip, x, args, ref_res, precision="f16x3"):
         dev_abs = max(float((a - b).abs().max()) for g1, g2 in zip(out, ref_out) for a, b in zip(g1, g2))
         dev_rel = max(float(((a - b).abs() / (b.abs() + 1.0)).max()) for g1, g2 in zip(out, ref_out) for a, b in zip(g1, g2))
         tower_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-        flops = 2 * plan.segs.rows * 512 * 256 * 9
+        flops = int(round(2 * plan.segs.rows * 512 * 256 * 9 * tower_launch_share(plan)))
         r = {"conv_precision": ("f16x3 (x = hi + lo*2^-11, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)" if precision == "f16x3" else
                                 "mixed: 1x1 layers f16x3, 3x3 stride-1 layers exact-fp32 Winograd F(2x2,3x3)"),
              "value": round(args.batch * args.steps / el, 2), "unit": "images/sec", "ms_per_step": round(el / args.steps * 1e3, 3), "batches_in_flight": 1,
@@ -827,7 +841,7 @@ def main():
     if args.layer_times:
         layer_times(plan, x, args.layer_times)
         return
-    tower_flops = 2 * plan.segs.rows * 512 * 256 * 9   # fused cls_conv + reg_conv 3x3, all 5 levels, this rank's batch
+    tower_flops = int(round(2 * plan.segs.rows * 512 * 256 * 9 * tower_launch_share(plan)))   # fused cls_conv + reg_conv 3x3, all 5 levels, this rank's batch (the timed launch's share)
     ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     nms_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 

@@ -187,9 +187,19 @@ typedef struct fd_conv_params {
      * layer1) is neither written nor read back.  x2 is an [batch][x2_H][x2_W] NHWC map; Cin % 32 == 0, x2_Cin % 32 == 0.  NULL = off. */
     const float* x2;
     int32_t x2_cs, x2_co, x2_Cin, x2_stride, x2_H, x2_W;
+    /* FD_TILE_WINOGRAD4 only: launch the workgroups [wg_first, wg_first + wg_count) of the layer's grid (fd_conv_workgroups(p) in all; wg_first % 8 == 0;
+     * no split-K) instead of all of them -- the layer as several launches whose union is the layer.  One workgroup of that kernel owns a CU, so a grid that
+     * is no multiple of the CU count ends in a round with most of the chip idle (the HISFCOS head tower at 16 x 640 x 640: 2 152 workgroups = 8.4 rounds
+     * on 256 CUs); launched as whole rounds + a tail, the caller can schedule other work beside the tail (pipeline.TwoLanePipeline).  wg_count = 0: all. */
+    int32_t wg_first, wg_count;
 } fd_conv_params;
 
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
+/* Workgroups (grid.x) of the launch `p` describes -- FD_TILE_WINOGRAD4 only (FD_E_UNSUPPORTED otherwise): the range wg_first / wg_count index. */
+int32_t fd_conv_workgroups(const fd_conv_params* p);
+/* ... and how many workgroups of the slice `p` names (wg_count = 0: of the whole grid) own a tile -- the grid is padded to 8 XCD shares of equal size, the
+ * padding workgroups exit at once: the work a slice does is live(slice) / live(all) of the layer's. */
+int32_t fd_conv_workgroups_live(const fd_conv_params* p);
 /* Two GEMM-addressed (1x1, stride 1, unpadded) layers back to back in ONE launch -- a ResNet bottleneck's conv3 + BN + residual + ReLU and the next
  * block's conv1 + BN + ReLU (torchvision Bottleneck.forward behind model/backbone/resnet50.py:68-80):
  *     y = act1(x . W1^T * scale1 + shift1 + res)   [rows][N1]   written to HBM (it is the next block's residual)

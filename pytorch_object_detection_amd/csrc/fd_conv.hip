@@ -393,6 +393,20 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 
 static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStream_t stream);
 
+extern "C" int32_t fd_conv_workgroups(const fd_conv_params* p) {
+    FD_REQUIRE(p && fd_segs_ok(&p->in) && p->dil >= 1 && p->Cout >= 1, FD_E_INVAL, "fd_conv_workgroups: bad arguments");
+    FD_REQUIRE(p->tile == FD_TILE_WINOGRAD4, FD_E_UNSUPPORTED, "fd_conv_workgroups: only FD_TILE_WINOGRAD4 launches can be sliced");
+    return fd_wino4_workgroups(p);
+}
+
+extern "C" int32_t fd_conv_workgroups_live(const fd_conv_params* p) {
+    FD_REQUIRE(p && fd_segs_ok(&p->in) && p->dil >= 1 && p->Cout >= 1, FD_E_INVAL, "fd_conv_workgroups_live: bad arguments");
+    FD_REQUIRE(p->tile == FD_TILE_WINOGRAD4, FD_E_UNSUPPORTED, "fd_conv_workgroups_live: only FD_TILE_WINOGRAD4 launches can be sliced");
+    const int all = fd_wino4_workgroups(p);
+    FD_REQUIRE(p->wg_count <= 0 || (p->wg_first >= 0 && (long)p->wg_first + p->wg_count <= all), FD_E_INVAL, "fd_conv_workgroups_live: slice outside the grid");
+    return p->wg_count > 0 ? fd_wino4_workgroups_live(p, p->wg_first, p->wg_count) : fd_wino4_workgroups_live(p, 0, all);
+}
+
 extern "C" int64_t fd_conv_workspace_bytes(int64_t out_rows, int32_t Cout, int32_t ksplit) {
     if (out_rows < 1 || Cout < 1 || ksplit < 1) return -1;
     return ksplit > 1 ? (int64_t)ksplit * out_rows * ((Cout + 3) & ~3) * 4 : 0;
@@ -421,6 +435,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
         FD_REQUIRE(p->stride == 1 && 2 * p->pad == p->dil * (p->KH - 1) && p->KH == p->KW, FD_E_INVAL,
                    "fd_conv2d: multi-level input needs stride 1 and 'same' padding");
 
+    FD_REQUIRE(p->wg_count <= 0 || p->tile == FD_TILE_WINOGRAD4, FD_E_UNSUPPORTED, "fd_conv2d: wg_first / wg_count (a slice of the layer's grid) exist for FD_TILE_WINOGRAD4 only");
     if (p->tile == FD_TILE_WINOGRAD) return fd_launch_conv_wino(p, stream);   // own argument block, own weight packing
     if (p->tile == FD_TILE_WINOGRAD4) return fd_launch_conv_wino4(p, stream);
     if (p->tile == FD_TILE_NARROW) return fd_launch_conv_narrow(p, stream);

@@ -47,6 +47,8 @@ int fd_launch_conv_patch(const ConvArgs& a, int tag, int split, hipStream_t stre
 int fd_launch_conv_wino(const fd_conv_params* p, hipStream_t stream);
 // fd_conv_wino4.hip: 3x3 stride-1 pad-1 conv as Winograd F(4x4, 3x3) (FD_TILE_WINOGRAD4; p->w is the fd_wino4_pack_weights_f32 packing)
 int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream);
+int fd_wino4_workgroups(const fd_conv_params* p);
+int fd_wino4_workgroups_live(const fd_conv_params* p, int first, int count);
 // fd_conv_narrow.hip: 3x3 stride-1 pad-1 conv with Cout <= 8 on the vector unit (FD_TILE_NARROW; p->w is the [Cin/16][3][4][3][NCO][4] packing)
 int fd_launch_conv_narrow(const fd_conv_params* p, hipStream_t stream);
 // fd_conv_wave.hip: GEMM-addressed layers as wave-autonomous 64 x 64 tiles (FD_TILE_WAVE64); wfrag = fd_pack_conv_weight_wave_f32 packing

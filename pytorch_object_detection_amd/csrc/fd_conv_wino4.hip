@@ -45,6 +45,7 @@ struct Wino4Args {
     float seg_param[FD_MAX_SEG];
     int T;                        // tiles in all
     int mtiles, ntiles, mt_per;   // M tiles (32 tiles each), N tiles (64 cout), M tiles per XCD
+    int blk0;                     // first workgroup of this launch in the layer's grid (fd_conv_params.wg_first; a multiple of 8: the XCD of a workgroup is unchanged)
     unsigned x_bytes, u_bytes;
     int dbg;                      // timing builds only (-DFD_W4_TIMING + FD_W4_DBG): 1 = no loader stages, 2 = no MFMAs, 4 = no epilogue (wrong results)
 };
@@ -130,7 +131,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     const int l31 = lane & 31, lh = lane >> 5;
 
     // XCD-aware order (as fd_conv_wino.hip): XCD x owns M tiles [x * mt_per, (x + 1) * mt_per) and walks them cout tile by cout tile
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int bx = blockIdx.x + a.blk0;
+    const int xcd = bx & 7, idx = bx >> 3;
     const int mt_lo = xcd * a.mt_per;
     const int cnt = min(a.mtiles - mt_lo, a.mt_per);
     if (cnt <= 0 || idx >= cnt * a.ntiles) return;
@@ -407,6 +409,30 @@ extern "C" int32_t fd_wino4_pack_weights_f32(const float* w, const float* scale,
     return FD_OK;
 }
 
+// workgroups of the layer's F(4x4) launch (grid.x; with split-K: per slice): what fd_conv_params.wg_first / wg_count index
+int fd_wino4_workgroups(const fd_conv_params* p) {
+    long t = 0;
+    for (int s = 0; s < p->in.nseg; ++s)
+        t += (long)p->in.batch * p->dil * p->dil * (((p->in.H[s] + p->dil - 1) / p->dil + 3) / 4) * (((p->in.W[s] + p->dil - 1) / p->dil + 3) / 4);
+    const long mtiles = (t + W4_TB - 1) / W4_TB;
+    return (int)(8 * ((mtiles + 7) / 8) * ((p->Cout + 63) / 64));
+}
+
+// ... and how many of the workgroups [first, first + count) of that grid are non-empty (the grid is padded to 8 XCDs x mt_per M tiles: the last XCD's share ends early)
+int fd_wino4_workgroups_live(const fd_conv_params* p, int first, int count) {
+    long t = 0;
+    for (int s = 0; s < p->in.nseg; ++s)
+        t += (long)p->in.batch * p->dil * p->dil * (((p->in.H[s] + p->dil - 1) / p->dil + 3) / 4) * (((p->in.W[s] + p->dil - 1) / p->dil + 3) / 4);
+    const int mtiles = (int)((t + W4_TB - 1) / W4_TB), mt_per = (mtiles + 7) / 8, ntiles = (p->Cout + 63) / 64;
+    int live = 0;
+    for (int b = first; b < first + count; ++b) {
+        const int xcd = b & 7, idx = b >> 3;
+        const int cnt = min(mtiles - xcd * mt_per, mt_per);
+        if (cnt > 0 && idx < cnt * ntiles) ++live;
+    }
+    return live;
+}
+
 int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
     FD_REQUIRE(p->KH == 3 && p->KW == 3 && p->stride == 1 && (p->dil == 1 || p->dil == 2) && p->pad == p->dil && p->Cin % 8 == 0 && p->Cout % 4 == 0 &&
                    p->precision == FD_PREC_F32 && p->out_H <= 0 && p->sc_H <= 0 && !p->gate && !p->gn_stats,
@@ -479,7 +505,16 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
         a.scale = a.shift = a.res = nullptr; a.act = FD_ACT_NONE; a.res_mask = 0;
     }
     const int nslice = (a.NC + a.nc_per - 1) / a.nc_per;
-    const dim3 grid((unsigned)(8 * a.mt_per * a.ntiles), (unsigned)nslice);
+    dim3 grid((unsigned)(8 * a.mt_per * a.ntiles), (unsigned)nslice);
+    a.blk0 = 0;
+    if (p->wg_count > 0) {
+        // a slice of the layer's grid (fd_conv_workgroups): the head tower's 2 152 workgroups are 8.4 rounds on 256 CUs -- launched as 8 whole rounds + a tail
+        // launch, the caller can let other work in beside the tail instead of idling 60 % of the chip for a round (pipeline.TwoLanePipeline)
+        FD_REQUIRE(ksplit <= 1 && p->wg_first >= 0 && p->wg_first % 8 == 0 && (long)p->wg_first + p->wg_count <= (long)grid.x, FD_E_INVAL,
+                   "fd_conv2d: wg_first = %d (a multiple of 8), wg_count = %d must lie inside the layer's %u workgroups, without split-K", p->wg_first, p->wg_count, grid.x);
+        a.blk0 = p->wg_first;
+        grid.x = (unsigned)p->wg_count;
+    }
     if (ksplit > 1) {
         static std::atomic<unsigned> ms{0};
         fd_set_max_lds_once(ms, reinterpret_cast<const void*>(conv3x3_wino4_kernel<0>), lds);

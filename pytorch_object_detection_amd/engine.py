@@ -34,6 +34,9 @@ AUTOTUNE = True   # per-conv block-tile lookup / timing at plan-build time (see 
 WINOGRAD = _os.environ.get("FD_WINOGRAD", "1") != "0"
 SE_GATE_IN_PROJECT = _os.environ.get("FD_SE_GATE_FUSED", "1") != "0"     # MBConv: SE gate applied by the project conv's loader ("0": a scaling pass)
 GN_FUSED_TOWER = _os.environ.get("FD_GN_FUSED_TOWER", "0") == "1"   # "1": the tower's statistics from its Winograd epilogue too (measured neutral, costs the tower launch 5 %)
+# "1": a head-tower F(4x4) launch whose grid is no multiple of the CU count runs as whole rounds of workgroups + a tail launch ("head.tower3x3.tail", after the mark):
+# TwoLanePipeline releases the other lane when the whole rounds are done, so the tail round (60 % of the chip idle at 16 x 640 x 640) has company
+TOWER_TAIL_SPLIT = _os.environ.get("FD_TOWER_TAIL_SPLIT", "1") != "0"
 TOWER_GN_SPLIT = _os.environ.get("FD_TOWER_GN_SPLIT", "1") != "0"   # "0": the tower's GroupNorm normalises both halves in its own pass (else the box half in the narrow predictor's loader)
 GN_FUSED = _os.environ.get("FD_GN_FUSED", "1") != "0"       # "0": HISFCOSHead's GroupNorms as three-pass launches (statistics / finalise / normalise)
 WAVE_TILE = _os.environ.get("FD_WAVE_TILE", "1") != "0"       # "0": the 1x1 layers never see FD_TILE_WAVE64 (wave-autonomous tiles, fd_conv_wave.hip)
@@ -188,6 +191,8 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     """conv (+folded BN / bias) (+res) (+act).  `weight`/`bias` override conv's own (fused multi-conv launches);
     `fold` = (scale, shift) overrides the epilogue constants altogether (convs with different BN / bias merged by hand)."""
     dev = plan.device
+    if getattr(plan, "tail_steps", None):
+        raise FdError("add_conv: a tail launch is still pending (_flush_tail_steps right after closing the mark of a tag = 1 conv)")
     w = conv.weight if weight is None else weight
     b = (conv.bias if bias is None else bias)
     k, stride, pad, dil = conv.kernel_size[0], conv.stride[0], conv.padding, conv.dilation[0]
@@ -266,7 +271,20 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
                          tile=_lib.NARROW_TILE if narrow else ((_lib.WINO4_TILE if wino4 else _lib.WINO_TILE) if wino else 0), ksplit=wino_ks if wino else 1,
                          gate=gate, w_frag=wfrag,
                          gate_b=gate_b, gate_act=gate_act, gn_stats=gn_stats, gn_groups=gn_groups, x2=x2, x2_stride=x2_stride, x2_hw=x2_hw)
+    tail = None
+    if tag == 1 and wino4 and wino_ks <= 1 and TOWER_TAIL_SPLIT:
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        total, live = ops.conv_workgroups(call)
+        full = total // ncu * ncu          # (one workgroup of that kernel owns a CU; ncu % 8 == 0: the slice starts on an XCD boundary)
+        if ncu % 8 == 0 and 4 * ncu <= full < total:
+            main = ops.conv_wg_slice(call, 0, full)
+            tail = ops.conv_wg_slice(call, full, total - full, tag=0)
+            tail_share = ops.conv_workgroups(tail)[1] / live
+            call = main
     plan.add(name, call)
+    if tail is not None:
+        plan.tail_of = getattr(plan, "tail_of", {})
+        plan.tail_of[name] = {"workgroups": total, "main": full, "live": live, "main_share": 1.0 - tail_share}
     if ws is not None:
         plan.pool.put(ws)
     if narrow:
@@ -290,11 +308,19 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         if gn_stats is not None and (plan.tiles[name] & 0xFF) not in (0, 2, 3, 4, 8, 9, _lib.WAVE_TILE):
             call.params.tile = plan.tiles[name] = 8      # the statistics epilogue exists for the one- / two-sub-tile tiles (and WAVE64 / Winograd)
     plan.flops += 2 * out.rows * co * Cin * k * k
+    info = {"k": k, "stride": stride, "dil": dil, "Cin": Cin, "Cout": co, "rows": out.rows,
+            "family": "narrow3x3 (vector unit)" if narrow else ("winograd3x3" if wino else ("1x1" if k == 1 else f"direct{k}x{k}")),
+            # multiplies saved on the matrix pipe: F(4x4,3x3) 36 per 16 outputs, F(2x2,3x3) 16 per 4, direct 9 per output
+            "mfma_div": 4.0 if wino4 else (2.25 if wino else 1.0)}
+    if tail is not None:       # the layer as two launches: FLOPs split by the share of non-empty workgroups
+        main_flops = int(round(2 * out.rows * co * Cin * k * k * (1.0 - tail_share)))
+        plan.step_flops[len(plan.steps) - 1] = main_flops
+        plan.step_info[len(plan.steps) - 1] = info
+        plan.tail_steps = getattr(plan, "tail_steps", [])
+        plan.tail_steps.append((name + ".tail", tail, 2 * out.rows * co * Cin * k * k - main_flops, dict(info)))
+        return out
     plan.step_flops[len(plan.steps) - 1] = 2 * out.rows * co * Cin * k * k
-    plan.step_info[len(plan.steps) - 1] = {"k": k, "stride": stride, "dil": dil, "Cin": Cin, "Cout": co, "rows": out.rows,
-                                           "family": "narrow3x3 (vector unit)" if narrow else ("winograd3x3" if wino else ("1x1" if k == 1 else f"direct{k}x{k}")),
-                                           # multiplies saved on the matrix pipe: F(4x4,3x3) 36 per 16 outputs, F(2x2,3x3) 16 per 4, direct 9 per output
-                                           "mfma_div": 4.0 if wino4 else (2.25 if wino else 1.0)}
+    plan.step_info[len(plan.steps) - 1] = info
     return out
 
 
@@ -692,6 +718,17 @@ def _out_convs(plan: Plan, head, tower: Rows, segs: Segs, F: int, ncls: int, reg
     return cls.slice(0, ncls), cr.slice(0, 1), cr.slice(1, 4)
 
 
+def _flush_tail_steps(plan: Plan) -> None:
+    """The tail launches add_conv set aside (TOWER_TAIL_SPLIT) become steps of their own -- called right AFTER the caller closed its mark, so that the mark
+    (= what TwoLanePipeline keeps exclusive and bench.py times as the roofline launch) covers the whole rounds only."""
+    for nm, fn, fl, info in getattr(plan, "tail_steps", []):
+        plan.add(nm, fn)
+        plan.step_flops[len(plan.steps) - 1] = fl
+        plan.step_info[len(plan.steps) - 1] = info
+        plan.tiles[nm] = _lib.WINO4_TILE
+    plan.tail_steps = []
+
+
 def _fused_gn(plan: Plan, name: str, x: Rows, segs: Segs, gns, act: int) -> None:
     """k GroupNorm(32, F) over k adjacent F-channel slices == one GroupNorm(32k, kF) with concatenated affine."""
     dev = plan.device
@@ -774,6 +811,7 @@ def build_his_head(plan: Plan, head, pyr: Rows, segs: Segs):
         rgs3 = pool.get(M, 2 * Gt)
         add_conv(plan, "head.tower3x3", z, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F, tag=1, gn_stats=rgs3.buf, gn_groups=Gt)
         plan.marks["head.tower3x3"] = (mark, len(plan.steps))
+        _flush_tail_steps(plan)
         reg_in_loader = TOWER_GN_SPLIT and _narrow_predictor(plan, head, segs, F)
         ws, gamma, beta, G, eps, coef = _gn_from_rowstats(plan, "head.tower_gn.stats", rgs3, segs, tgn, 2 * F, reg_in_loader)
         pool.put(rgs3)
@@ -788,6 +826,7 @@ def build_his_head(plan: Plan, head, pyr: Rows, segs: Segs):
     else:
         add_conv(plan, "head.tower3x3", z, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F, tag=1)
         plan.marks["head.tower3x3"] = (mark, len(plan.steps))
+        _flush_tail_steps(plan)
         if TOWER_GN_SPLIT and _narrow_predictor(plan, head, segs, F) and 256 % (F // 4) == 0:
             # statistics of both halves in one pass; the class half keeps a normalise pass (over half the bytes), the box half is normalised inside
             # the narrow predictor's patch loader (fd_conv_params.gate_b on FD_TILE_NARROW): same arithmetic, bit-identical outputs
@@ -859,6 +898,7 @@ def build_fcos_head(plan: Plan, head, pyr: Rows, segs: Segs):
     mark = len(plan.steps)
     add_conv(plan, "head.tower0", pyr, segs, head.cls_branch[0], cur, weight=w, Cout=2 * F)
     plan.marks["head.tower3x3"] = (mark, len(plan.steps))
+    _flush_tail_steps(plan)
     _fused_gn(plan, "head.tower0_gn", cur, segs, [head.cls_branch[1], head.reg_branch[1]], ACT_RELU)
     for k in (1, 2, 3):
         nxt = pool.get(M, 2 * F)
@@ -947,6 +987,7 @@ def build_mn_head(plan: Plan, head, pyr: Rows, segs: Segs):
     mark = len(plan.steps)
     add_conv(plan, "head.tower3x3", b2, segs, head.cls_conv[0], tower, weight=w, Cout=2 * F, tag=1)
     plan.marks["head.tower3x3"] = (mark, len(plan.steps))
+    _flush_tail_steps(plan)
     _fused_gn(plan, "head.tower_gn", tower, segs, [head.cls_conv[1], head.reg_conv[1]], ACT_SILU)
     pool.put(b2)
     return _out_convs(plan, head, tower, segs, F, ncls)

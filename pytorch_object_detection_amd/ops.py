@@ -255,6 +255,33 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     return run
 
 
+def conv_workgroups(run) -> Tuple[int, int]:
+    """(workgroups, non-empty workgroups) of the launch a conv_call() callable describes -- or of its slice, if it is one (FD_TILE_WINOGRAD4 only)."""
+    n = _lib.lib().fd_conv_workgroups(C.byref(run.params))
+    live = _lib.lib().fd_conv_workgroups_live(C.byref(run.params))
+    if n < 0 or live < 0:
+        raise FdError("fd_conv_workgroups: " + _lib.lib().fd_last_error().decode(errors="replace"), int(min(n, live)))
+    return (run.params.wg_count or n), live
+
+
+def conv_wg_slice(run, first: int, count: int, tag: Optional[int] = None) -> Callable[[], None]:
+    """The workgroups [first, first + count) of conv_call()'s launch as a launch of their own (fd_conv_params.wg_first / wg_count; FD_TILE_WINOGRAD4, first % 8 == 0).
+    The slices of a partition of the grid together compute the layer; `tag` overrides the kernel tag (1 = the instantiation rocprof lists as the head tower)."""
+    q = _lib.ConvParams()
+    C.memmove(C.byref(q), C.byref(run.params), C.sizeof(q))
+    q.wg_first, q.wg_count = first, count
+    if tag is not None:
+        q.tag = tag
+    fn = _lib.lib().fd_conv2d_nhwc_f32
+    ref = C.byref(q)
+
+    def run_slice(_keep=(run, q)):
+        check(fn(ref, _stream()), "fd_conv2d_nhwc_f32")
+
+    run_slice.params = q  # type: ignore[attr-defined]
+    return run_slice
+
+
 def b2b_ok(K1: int, N1: int, N2: int) -> bool:
     """Shapes fd_conv1x1_b2b_f32 covers (two 1x1 stride-1 convs back to back: a bottleneck's conv3 and the next block's conv1)."""
     return K1 % 32 == 0 and N1 % 64 == 0 and N2 in (64, 128)

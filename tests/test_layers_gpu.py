@@ -1485,3 +1485,43 @@ def test_conv3x3_winograd_f4x4_at_the_start_of_an_allocation():
         scale = float(ref.abs().max()) + 1.0
         assert float((got - ref).abs().max()) < 4e-5 * scale
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", [(64, 128, [(40, 40), (20, 20), (10, 10), (5, 5), (3, 3)], 3, 1), (32, 80, [(48, 36)], 2, 2), (64, 64, [(24, 20)], 1, 1)])
+def test_conv3x3_winograd_f4x4_as_slices_of_its_grid(case):
+    """fd_conv_params.wg_first / wg_count: an F(4x4) layer launched as several slices of its workgroup grid (the head tower as whole rounds on 256 CUs + a
+    tail launch, engine.TOWER_TAIL_SPLIT).  Any partition of [0, fd_conv_workgroups) at multiples of 8 must give, BIT FOR BIT, the one-launch result, every
+    slice must write only its own tiles, the non-empty workgroup counts of the slices must add up, and ranges outside the grid / off an XCD boundary /
+    on another tile are clean errors."""
+    from pytorch_object_detection_amd import _lib
+    Cin, Cout, hw, B, dil = case
+    gen = torch.Generator().manual_seed(Cin + Cout + len(hw) + dil)
+    segs = Segs.make(B, hw)
+    x = torch.randn(segs.rows, Cin, generator=gen).to(DEV)
+    wt = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout, generator=gen).to(DEV)
+    wp = ops.pack_conv_weight_wino4(wt.to(DEV))
+    y0 = ops.new_rows(segs.rows, Cout, DEV)
+    whole = ops.conv_call(ops.Rows(x), segs, wp, y0, Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, shift=bias, act=ACT_RELU, tile=_lib.WINO4_TILE)
+    whole()
+    total, live = ops.conv_workgroups(whole)
+    assert total % 8 == 0 and 0 < live <= total
+    yb = torch.full((segs.rows, Cout), float("nan"), device=DEV)
+    call = ops.conv_call(ops.Rows(x), segs, wp, ops.Rows(yb), Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, shift=bias, act=ACT_RELU, tile=_lib.WINO4_TILE)
+    cuts = sorted({0, total, (total // 3) // 8 * 8, (2 * total // 3) // 8 * 8, max(0, total - 8)})
+    parts = [ops.conv_wg_slice(call, a, b - a, tag=i & 1) for i, (a, b) in enumerate(zip(cuts, cuts[1:])) if b > a]
+    assert sum(ops.conv_workgroups(q)[1] for q in parts) == live
+    seen = torch.zeros(segs.rows, dtype=torch.bool, device=DEV)
+    for q in reversed(parts):                    # (any order)
+        q()
+        now = ~torch.isnan(yb).any(1)
+        assert bool((now | ~seen).all())           # nothing a previous slice wrote is touched again ...
+        assert torch.equal(yb[seen], y0.tensor()[seen])
+        seen = now
+    assert bool(seen.all()) and torch.equal(yb, y0.tensor())
+    for first, count in ((4, 8), (0, total + 8), (total, 8), (-8, 8)):
+        with pytest.raises(Exception, match="wg_"):
+            ops.conv_wg_slice(call, first, count)()
+    direct = ops.conv_call(ops.Rows(x), segs, ops.pack_conv_weight(wt.to(DEV)), ops.Rows(yb), Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, tile=4)
+    with pytest.raises(Exception, match="WINOGRAD4"):
+        ops.conv_wg_slice(direct, 0, 8)()

@@ -229,6 +229,10 @@ def test_full_size_batch16_shipped_plan_vs_oracle():
     plan = next(o for o in (built if isinstance(built, tuple) else (built,)) if hasattr(o, "tiles") and hasattr(o, "steps"))
     on4 = [n for n, t in plan.tiles.items() if (t & 0xFF) == 16]
     assert "head.tower3x3" in on4 and len(on4) >= 12, on4              # (this IS the shipped F(4x4) plan, not a forced variant)
+    # ... whose head tower runs as whole rounds of workgroups + a tail launch right behind the mark (engine.TOWER_TAIL_SPLIT): 2 176 = 8 x 256 + 128
+    lo, hi = plan.marks["head.tower3x3"]
+    assert hi == lo + 1 and plan.names[hi] == "head.tower3x3.tail" and plan.tail_of["head.tower3x3"]["main"] % 256 == 0
+    assert plan.step_flops[lo] + plan.step_flops[hi] == 2 * plan.segs.rows * 512 * 256 * 9 and 0.9 < plan.tail_of["head.tower3x3"]["main_share"] < 1.0
     worst = 0.0
     for name, o, r in zip(("cls", "cnt", "reg"), out, ref):
         for i in range(5):
