@@ -40,6 +40,7 @@ TOWER_TAIL_SPLIT = _os.environ.get("FD_TOWER_TAIL_SPLIT", "1") != "0"
 TOWER_GN_SPLIT = _os.environ.get("FD_TOWER_GN_SPLIT", "1") != "0"   # "0": the tower's GroupNorm normalises both halves in its own pass (else the box half in the narrow predictor's loader)
 GN_FUSED = _os.environ.get("FD_GN_FUSED", "1") != "0"       # "0": HISFCOSHead's GroupNorms as three-pass launches (statistics / finalise / normalise)
 WAVE_TILE = _os.environ.get("FD_WAVE_TILE", "1") != "0"       # "0": the 1x1 layers never see FD_TILE_WAVE64 (wave-autonomous tiles, fd_conv_wave.hip)
+B2B_MIN_ROWS = int(_os.environ.get("FD_B2B_MIN_ROWS", str(64 * 1024)))   # fewer rows than 1 024 waves of 64: the seam stays two workgroup-tiled launches
 DUAL_DS = _os.environ.get("FD_DUAL_DS", "1") != "0"      # "0": a block's downsample conv as its own launch, its output read back as conv3's residual
 # FD_B2B: the trunk layers (digits) whose conv3 -> next-block conv1 seams run as ONE back-to-back launch (fd_conv1x1_b2b_f32: the 4 * planes wide map is
 # written once and never read back); "" = none
@@ -453,7 +454,9 @@ def build_resnet50(plan: Plan, trunk, batch: int, H: int, W: int, image_ref: Lis
         out = pool.get(so.rows, 4 * planes)
         nxt = blocks_all[gi + 1][2] if gi + 1 < len(blocks_all) else None
         n2 = nxt.conv1.weight.shape[0] if nxt is not None else 0
-        if (str(li) in B2B_LAYERS and nxt is not None and plan.precision == "f32" and blk.conv3.bias is None and nxt.conv1.bias is None
+        # (the back-to-back kernel is wave-autonomous, 64 rows per wave: below ~4 waves per SIMD-quarter of the chip its workgroups leave most of every CU idle --
+        #  at batch 1 x 512 x 512 the seam was 0.053 ms against 0.016 + 0.018 as two launches: B2B_MIN_ROWS)
+        if (str(li) in B2B_LAYERS and so.rows >= B2B_MIN_ROWS and nxt is not None and plan.precision == "f32" and blk.conv3.bias is None and nxt.conv1.bias is None
                 and nxt.conv1.kernel_size[0] == 1 and nxt.conv1.stride[0] == 1 and nxt.conv1.weight.shape[1] == 4 * planes
                 and ops.b2b_ok(planes, 4 * planes, n2) and all(r.cs % 4 == 0 and r.co % 4 == 0 for r in (o2, out, idt))):
             # conv3 (+bn3 + identity, ReLU) and the NEXT block's conv1 (+bn1, ReLU) as one launch: `out` is written (next residual, downsample input)
@@ -599,7 +602,6 @@ def _his_block(plan: Plan, name: str, blk, x: Rows, segs: Segs, out: Rows) -> No
     sc, sf = ops.fold_bn(_dev(blk.bn2.weight, dev), _dev(blk.bn2.bias, dev), _dev(blk.bn2.running_mean, dev),
                          _dev(blk.bn2.running_var, dev), blk.bn2.eps)
     u = cat1.slice(0, half)
-    plan.add(name + ".conv1_1", lambda: ops.dwconv3x3(x1, wd, u, segs, sc, sf, ACT_RELU))
     se = blk.conv1_2.excitation
     w1 = _dev(se[0].weight, dev).reshape(se[0].weight.shape[0], -1).contiguous()
     b1 = _dev(se[0].bias, dev)
@@ -608,6 +610,9 @@ def _his_block(plan: Plan, name: str, blk, x: Rows, segs: Segs, out: Rows) -> No
     ws = ops.se_workspace(N, HW, half, dev)
     v = cat1.slice(half, half)
     cr = w1.shape[0]
+    # (the depthwise and the squeeze-excitation branch are independent -- HISFcos.py:100-104 -- but forking the second onto another stream costs the batch-1 plan
+    #  0.15 ms in cross-stream events for seven pairs: measured)
+    plan.add(name + ".conv1_1", lambda: ops.dwconv3x3(x1, wd, u, segs, sc, sf, ACT_RELU))
     plan.add(name + ".conv1_2", lambda: ops.se_scale(x1, w1, b1, w2, b2, v, N, HW, cr, ws))
     plan.keep += [wd, sc, sf, w1, b1, w2, b2, ws]
     add_conv(plan, name + ".conv3", cat1, segs, blk.conv3, cat2.slice(half, half), bn=blk.bn3, act=ACT_RELU)
