@@ -37,12 +37,14 @@ write_kib = sum(v["c"]["WRITE_SIZE"] for v in w) / len(w)
 cyc = [v["c"]["GRBM_GUI_ACTIVE"] / 8 for v in q]
 util = [v["c"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (c * 1024) for v, c in zip(q, cyc)]
 clk = [c / v["dur_ns"] for v, c in zip(q, cyc)]
-# calibration of the FETCH_SIZE factor on gn_apply (reads exactly what it writes)
+# calibration of the FETCH_SIZE factor on a normalise pass that reads exactly what it writes: gn_apply_kernel, or -- since the tower's GroupNorm is a slice
+# pass (round 4) -- coef_apply_kernel; the largest launch of it in the run
 cal = None
-gf = [v for v in fe if "gn_apply" in v["name"]]
-gw = [v for v in wr if "gn_apply" in v["name"]]
+gf = [v for v in fe if "gn_apply_kernel" in v["name"] or "coef_apply_kernel" in v["name"]]
+gw = [v for v in wr if "gn_apply_kernel" in v["name"] or "coef_apply_kernel" in v["name"]]
 if gf and gw:
-    cal = gf[0]["c"]["FETCH_SIZE"] / gw[0]["c"]["WRITE_SIZE"]
+    gf, gw = max(gf, key=lambda v: v["c"]["FETCH_SIZE"]), max(gw, key=lambda v: v["c"]["WRITE_SIZE"])
+    cal = gf["c"]["FETCH_SIZE"] / gw["c"]["WRITE_SIZE"]
 def biggest(rows, key):
     ks = [v for v in rows if key in v["name"]]
     return max(ks, key=lambda v: v["grid"]) if ks else None
@@ -64,7 +66,7 @@ out = {"tag": tag, "commit_of_the_working_tree_summarised": commit, "decode_kern
                            "hbm_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024),
                            "mfma_busy_frac": sum(util) / len(util), "clock_ghz": sum(clk) / len(clk),
                            "avg_dur_ms_under_pmc": sum(v["dur_ns"] for v in q) / len(q) / 1e6},
-       "fetch_size_calibration_gn_apply(read/written)": cal,
+       "fetch_size_calibration_normalise_pass(read/written)": cal,
        "source": f"rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline ({tag})"}
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
