@@ -177,6 +177,27 @@ def test_abi_argument_errors_without_gpu():
     assert lib.fd_groupnorm_workspace_bytes(ctypes.byref(_lib.Segs.make(2, [(8, 8), (4, 4)])), 32) == 2 * 2 * (256 + 1) * 32 * 16   # chunk partials + (mean, rstd)
 
 
+def test_winograd4_grid_queries_without_gpu():
+    """fd_conv_workgroups / fd_conv_workgroups_live are host arithmetic: the HISFCOS head tower at 16 x 640 x 640 (256 -> 512 over 80 / 40 / 20 / 10 / 5) is
+    8 608 tiles = 269 M tiles x 8 cout tiles = 2 152 workgroups in a grid of 2 176 (eight XCD shares of 34 M tiles); its first 2 048 workgroups -- 8 whole
+    rounds on 256 CUs, what engine.TOWER_TAIL_SPLIT launches as the main launch -- hold 2 040 of them."""
+    lib = _lib.lib()
+    p = _lib.ConvParams()
+    p.segs = _lib.Segs.make(16, [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)])
+    p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil, p.tile = 256, 512, 3, 3, 1, 1, 1, _lib.WINO4_TILE
+    assert lib.fd_conv_workgroups(ctypes.byref(p)) == 2176 and lib.fd_conv_workgroups_live(ctypes.byref(p)) == 2152
+    p.wg_first, p.wg_count = 0, 2048
+    assert lib.fd_conv_workgroups_live(ctypes.byref(p)) == 2040
+    p.wg_first, p.wg_count = 2048, 128
+    assert lib.fd_conv_workgroups_live(ctypes.byref(p)) == 112
+    p.wg_first, p.wg_count = 2048, 136
+    assert lib.fd_conv_workgroups_live(ctypes.byref(p)) < 0 and b"slice" in lib.fd_last_error()
+    p.wg_first, p.wg_count, p.dil, p.pad = 0, 0, 2, 2                 # dilation 2: four parity classes per image, tiles per class rounded up
+    assert lib.fd_conv_workgroups_live(ctypes.byref(p)) == -(-16 * 4 * (100 + 25 + 9 + 4 + 1) // 32) * 8
+    p.tile = 4
+    assert lib.fd_conv_workgroups(ctypes.byref(p)) < 0                  # only the F(4x4) kernel's grid can be sliced
+
+
 def test_backward_abi_argument_errors_without_gpu():
     """The train-step entry points validate on the host too (no launch happens for bad arguments)."""
     lib = _lib.lib()
