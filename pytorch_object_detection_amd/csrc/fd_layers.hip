@@ -765,8 +765,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 
 // pass 1b: chunk partials -> (mean, rstd) per (level, image, group), once (the apply workgroups used to redo this sum each):
 // 256 threads = G-lanes x chunk-lanes, every chunk-lane adds its chunks in index order, lanes are combined in lane order
+// coef != NULL: also the per-channel affine a consumer applies in its loader (the arithmetic of gn_apply_kernel) -- no launch of its own
 __global__ __launch_bounds__(256) void gn_finalize_kernel(int C, int G, float eps, SegTab tab, const double* __restrict__ part,
-                                                           double* __restrict__ gstat) {
+                                                           double* __restrict__ gstat, const float* __restrict__ gamma = nullptr,
+                                                           const float* __restrict__ beta = nullptr, float* __restrict__ coef = nullptr) {
     __shared__ double s_a[256], s_b[256];
     const int img = blockIdx.y;
     const int s = img / tab.s.batch;
@@ -789,8 +791,17 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(int C, int G, float ep
         const double mean = a / cnt;
         double var = b / cnt - mean * mean;
         if (var < 0) var = 0;
+        const double rstd = (double)(float)(1.0 / sqrt(var + (double)eps));
         gstat[((long)img * G + g) * 2] = mean;
-        gstat[((long)img * G + g) * 2 + 1] = (double)(float)(1.0 / sqrt(var + (double)eps));
+        gstat[((long)img * G + g) * 2 + 1] = rstd;
+        if (coef) {
+            const int cg = C / G;
+            for (int c = g * cg; c < (g + 1) * cg; ++c) {
+                const float sc = (float)rstd * gamma[c];
+                coef[((long)img * 2) * C + c] = sc;
+                coef[((long)img * 2 + 1) * C + c] = beta[c] - (float)mean * sc;       // the arithmetic of gn_apply_kernel
+            }
+        }
     }
 }
 
@@ -872,7 +883,8 @@ extern "C" int32_t fd_groupnorm_act_nhwc(const float* x, int32_t x_cs, int32_t x
 // squares) of group g's channels in row m.  Same two steps as above with the 8x .. 32x smaller rgs in place of the map: chunk partials
 // in fp64 (fixed order) in the layout gn_finalize_kernel reads, then (mean, rstd) per (level, image, group) -- so gn_apply_kernel, the
 // backward and fd_batchnorm_update_running work on the result unchanged -- and optionally the per-(level, image, channel) affine
-// coef[img][0][c] = rstd * gamma[c], coef[img][1][c] = beta[c] - mean * rstd * gamma[c] for a consumer that normalises in its loader.
+// coef[img][0][c] = rstd * gamma[c], coef[img][1][c] = beta[c] - mean * rstd * gamma[c] for a consumer that normalises in its loader
+// (written by the finalise step itself).
 __global__ __launch_bounds__(256) void gn_rowstats_partial_kernel(const float* __restrict__ rgs, int G, SegTab tab, double* __restrict__ part) {
     __shared__ double s_p[256];
     const int img = blockIdx.y;
@@ -902,17 +914,6 @@ __global__ __launch_bounds__(256) void gn_rowstats_partial_kernel(const float* _
     }
 }
 
-__global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__ gstat, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      int C, int G, float* __restrict__ coef) {
-    const int img = blockIdx.x, cg = C / G;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const double* p = gstat + ((long)img * G + c / cg) * 2;
-        const float sc = (float)p[1] * gamma[c];
-        coef[((long)img * 2) * C + c] = sc;
-        coef[((long)img * 2 + 1) * C + c] = beta[c] - (float)p[0] * sc;       // the arithmetic of gn_apply_kernel
-    }
-}
-
 extern "C" int32_t fd_groupnorm_from_rowstats(const float* rowstats, int32_t C, int32_t G, float eps, const float* gamma, const float* beta,
                                               const fd_segs* segs, void* workspace, float* coef, fd_stream_t stream) {
     FD_REQUIRE(fd_segs_ok(segs) && rowstats && workspace, FD_E_INVAL, "fd_groupnorm_from_rowstats: bad argument");
@@ -928,12 +929,8 @@ extern "C" int32_t fd_groupnorm_from_rowstats(const float* rowstats, int32_t C, 
     hipLaunchKernelGGL(gn_rowstats_partial_kernel, dim3(nchunk, imgs), dim3(256), 0, st, rowstats, G, tab, (double*)workspace);
     FD_CHECK_LAUNCH("fd_groupnorm_from_rowstats (partial)");
     double* gstat = (double*)workspace + (long)imgs * GN_MAXCHUNK * G * 2;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((G + 15) / 16, imgs), dim3(256), 0, st, C, G, eps, tab, (const double*)workspace, gstat);
-    FD_CHECK_LAUNCH("fd_groupnorm_from_rowstats (finalize)");
-    if (coef) {
-        hipLaunchKernelGGL(gn_coef_kernel, dim3(imgs), dim3(256), 0, st, (const double*)gstat, gamma, beta, C, G, coef);
-        FD_CHECK_LAUNCH("fd_groupnorm_from_rowstats (coef)");
-    }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((G + 15) / 16, imgs), dim3(256), 0, st, C, G, eps, tab, (const double*)workspace, gstat, gamma, beta, coef);
+    FD_CHECK_LAUNCH("fd_groupnorm_from_rowstats (finalize + coef)");
     return FD_OK;
 }
 
@@ -956,12 +953,8 @@ extern "C" int32_t fd_groupnorm_stats_nhwc(const float* x, int32_t x_cs, int32_t
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, imgs), dim3(256), 0, st, x, x_cs, x_co, C, G, tab, (double*)workspace);
     FD_CHECK_LAUNCH("fd_groupnorm_stats (partial)");
     double* gstat = (double*)workspace + (long)imgs * GN_MAXCHUNK * G * 2;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((G + 15) / 16, imgs), dim3(256), 0, st, C, G, eps, tab, (const double*)workspace, gstat);
-    FD_CHECK_LAUNCH("fd_groupnorm_stats (finalize)");
-    if (coef) {
-        hipLaunchKernelGGL(gn_coef_kernel, dim3(imgs), dim3(256), 0, st, (const double*)gstat, gamma, beta, C, G, coef);
-        FD_CHECK_LAUNCH("fd_groupnorm_stats (coef)");
-    }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((G + 15) / 16, imgs), dim3(256), 0, st, C, G, eps, tab, (const double*)workspace, gstat, gamma, beta, coef);
+    FD_CHECK_LAUNCH("fd_groupnorm_stats (finalize + coef)");
     return FD_OK;
 }
 
