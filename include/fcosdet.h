@@ -144,7 +144,11 @@ typedef struct fd_conv_params {
     int32_t precision; /* FD_PREC_F32 (exact fp32 MFMA) | FD_PREC_F16X3 (opt-in split-f16 products, see below) */
     int32_t res_mode;  /* what `res` does: 0 = added (residual connection); 1 = ReLU mask: y = res > 0 ? v : 0 -- the data
                           gradient of a layer whose input came out of a ReLU is masked in the epilogue that produces it
-                          (train step: removes the separate threshold pass) */
+                          (train step: removes the separate threshold pass); 2 = `res` is a HALF-resolution map [N][H / 2][W / 2] added
+                          AFTER the activation, y[n, i, j] = act(conv * scale + shift) + res[n, i / 2, j / 2]: an FPN lateral with the x2 nearest-
+                          neighbour upsampling of the coarser level and the add folded into its epilogue (HISFcos.py:155-165, Fcos.py:77-91:
+                          no upsample-add pass over the finer map).  fp32 1x1 stride-1 unpadded single-level convs with even H, W, Cin % 32 == 0,
+                          16-byte views, no split-K / scatter / gate / gn_stats / x2; tiles AUTO, 64x64, 128x64_SB, 64x128_SB */
     float seg_param[FD_MAX_SEG]; /* per-level scalar for FD_ACT_EXP */
     fd_segs in;     /* input geometry */
     /* Data gradient of a STRIDED conv as parity classes (train.py:175-181; the 3x3 s2 / 1x1 s2 layers of the ResNet trunk):

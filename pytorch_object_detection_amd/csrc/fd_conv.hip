@@ -19,7 +19,10 @@
 // H1 (with SPLIT): single-plane f16 -- operands rounded to f16 once, ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation: the
 // arithmetic of torch.autocast(float16) convolutions (FD_PREC_F16; the reference trains under AMP, train.py:33,175-181).
 // DUAL (with GEMM): K-tiles >= a.kt2 are gathered from a second 1x1 source a.x2 (K-concatenation: a bottleneck's conv3 and its downsample conv as one GEMM).
-template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT, bool GATE = false, bool GNS = false, bool H1 = false, bool GEMM = false, bool DUAL = false>
+// RUP (with GEMM): `res` is a half-resolution map read at (i / 2, j / 2) and added AFTER the activation: an FPN lateral conv with the x2-upsampled coarser level
+// folded into its epilogue (HISFcos.py:155-165, Fcos.py:77-91) -- the upsample-add pass over the finer map disappears.
+template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB, int TAG, bool SPLIT, bool GATE = false, bool GNS = false, bool H1 = false, bool GEMM = false, bool DUAL = false,
+          bool RUP = false>
 __global__ __launch_bounds__(WGM * WGN * 64, (TM * TN == 4) ? ((SPLIT || WGM * WGN == 8) ? 2 : (SB ? 3 : 1)) : 1)
 void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -373,7 +376,7 @@ int fd_launch_splitk_reduce(const ConvArgs& orig, const float* ws, int nslice, i
 }
 
 template <int WGM, int WGN, int TM, int TN, bool STEM, bool SB = false, int TAG = 0, bool SPLIT = false, bool GATE = false, bool GNS = false, bool H1 = false, bool GEMM = false,
-          bool DUAL = false>
+          bool DUAL = false, bool RUP = false>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int lds_ab = (SB ? 1 : 2) * (BM + BN) * 32 * 4;
@@ -383,7 +386,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT, GATE, GNS, H1, GEMM, DUAL>;
+    auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, STEM, SB, TAG, SPLIT, GATE, GNS, H1, GEMM, DUAL, RUP>;
     static std::atomic<unsigned> attr_mask{0};       // per kernel instantiation, one bit per device
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles, (a.KT + a.kt_per - 1) / a.kt_per), dim3(NT), lds, stream, b);
@@ -435,6 +438,8 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
         FD_REQUIRE(p->stride == 1 && 2 * p->pad == p->dil * (p->KH - 1) && p->KH == p->KW, FD_E_INVAL,
                    "fd_conv2d: multi-level input needs stride 1 and 'same' padding");
 
+    FD_REQUIRE(!(p->res && p->res_mode == 2) || p->tile == FD_TILE_AUTO || p->tile == FD_TILE_64x64 || p->tile == FD_TILE_128x64_SB || p->tile == FD_TILE_64x128_SB, FD_E_UNSUPPORTED,
+               "fd_conv2d: res_mode 2 is built for tiles 64x64, 128x64_SB, 64x128_SB (got %d)", p->tile);
     FD_REQUIRE(p->wg_count <= 0 || p->tile == FD_TILE_WINOGRAD4, FD_E_UNSUPPORTED, "fd_conv2d: wg_first / wg_count (a slice of the layer's grid) exist for FD_TILE_WINOGRAD4 only");
     if (p->tile == FD_TILE_WINOGRAD) return fd_launch_conv_wino(p, stream);   // own argument block, own weight packing
     if (p->tile == FD_TILE_WINOGRAD4) return fd_launch_conv_wino4(p, stream);
@@ -446,6 +451,8 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     a.Cin = p->Cin; a.Cout = p->Cout; a.KW = p->KW; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;
     a.act = p->act; a.act_c0 = p->act_c0;
     a.res_mask = (p->res && p->res_mode == 1) ? 1 : 0;
+    a.res_up = 0;
+    FD_REQUIRE(p->res_mode >= 0 && p->res_mode <= 2, FD_E_INVAL, "fd_conv2d: res_mode %d", p->res_mode);
     a.nseg = p->in.nseg;
     long mo = 0;
     for (int s = 0; s < FD_MAX_SEG; ++s) {
@@ -666,6 +673,21 @@ static int dispatch_conv(const fd_conv_params* p, ConvArgs& a, bool stem, hipStr
             case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true, 0, false, false, true>(a, stream);
             case FD_TILE_AUTO: case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true, 0, false, false, true>(a, stream);
             default: fd_set_error("fd_conv2d: gn_stats is built for tiles 64x64, 128x64(_SB), 64x128(_SB), WAVE64 and WINOGRAD (got %d)", p->tile); return FD_E_UNSUPPORTED;
+        }
+    }
+    if (p->res && p->res_mode == 2) {
+        // the upsampled addend of an FPN lateral: 1x1 stride-1 unpadded fp32 layers on one level with even H, W, vector epilogue, no split-K
+        FD_REQUIRE(a.is_gemm && p->in.nseg == 1 && p->Cin % 32 == 0 && p->precision == FD_PREC_F32 && p->ksplit <= 1 && !a.sc_on && p->out_H <= 0 && !p->gate &&
+                       !p->gn_stats && !p->x2 && a.vec_epi && p->tag != 1 && p->in.H[0] % 2 == 0 && p->in.W[0] % 2 == 0,
+                   FD_E_UNSUPPORTED, "fd_conv2d: res_mode 2 (half-resolution addend) needs an fp32 1x1 stride-1 unpadded single-level conv with even H, W, Cin %% 32 == 0, "
+                                     "16-byte views, no split-K / scatter / gate / gn_stats / x2");
+        FD_REQUIRE((long)p->in.batch * (p->in.H[0] / 2) * (p->in.W[0] / 2) * p->res_cs < (1L << 31), FD_E_UNSUPPORTED, "fd_conv2d: residual exceeds 2^31 elements");
+        a.res_up = 1;
+        switch (p->tile) {
+            case FD_TILE_64x64: return launch_conv<2, 2, 1, 1, false, false, 0, false, false, false, false, true, false, true>(a, stream);
+            case FD_TILE_128x64_SB: return launch_conv<2, 2, 2, 1, false, true, 0, false, false, false, false, true, false, true>(a, stream);
+            case FD_TILE_AUTO: case FD_TILE_64x128_SB: return launch_conv<2, 2, 1, 2, false, true, 0, false, false, false, false, true, false, true>(a, stream);
+            default: fd_set_error("fd_conv2d: res_mode 2 is built for tiles 64x64, 128x64_SB, 64x128_SB (got %d)", p->tile); return FD_E_UNSUPPORTED;
         }
     }
     // GEMM-addressed fp32 layers (1x1, stride 1, no padding, Cin % 32 == 0, no gate): the loader compiled without the tap / bounds arithmetic

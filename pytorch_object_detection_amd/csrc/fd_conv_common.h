@@ -26,6 +26,7 @@ struct ConvArgs {
     long slice_stride;  // elements between consecutive split-K slabs in the workspace
     unsigned x_bytes, w_bytes;   // extents of the input / packed-weight buffers (raw buffer descriptors: OOB reads return 0)
     int res_mask;  // 1: `res` is a ReLU mask (y = res > 0 ? v : 0) instead of an addend
+    int res_up;    // RUP kernels: `res` is a HALF-resolution map added AFTER the activation: y[n, i, j] = act(v) + res[n, i / 2, j / 2] (FPN top-down path)
     // output scatter (single level): output pixel (n, i, j) is written to row (n*sc_H + sc_sy*i + sc_oy)*sc_W + sc_sx*j + sc_ox of
     // y (and reads `res` there): one parity class of the data gradient of a strided conv lands interleaved in dX
     int sc_on, sc_sy, sc_sx, sc_oy, sc_ox, sc_H, sc_W;
@@ -63,6 +64,14 @@ __device__ __forceinline__ long out_row(const ConvArgs& a, int m) {
     const int n = m / hw, rem = m - n * hw;
     const int i = rem / a.Wo[0], j = rem - i * a.Wo[0];
     return ((long)n * a.sc_H + (a.sc_sy * i + a.sc_oy)) * a.sc_W + (a.sc_sx * j + a.sc_ox);
+}
+
+// RUP: the residual row of output row m = the pixel (i / 2, j / 2) of the [N][Ho / 2][Wo / 2] map (nearest-neighbour x2 upsampling read in place; single level)
+__device__ __forceinline__ long res_row_up(const ConvArgs& a, int m) {
+    const int W = a.Wo[0], hw = a.Ho[0] * W;
+    const int n = m / hw, rem = m - n * hw;
+    const int i = rem / W, j = rem - i * W;
+    return ((long)n * (a.Ho[0] >> 1) + (i >> 1)) * (W >> 1) + (j >> 1);
 }
 
 // LDS hand-off between lanes of ONE wave: the LDS pipe executes a wave's ds instructions in order, so later reads see

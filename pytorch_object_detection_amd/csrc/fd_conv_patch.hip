@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         }
     }
     constexpr bool GNS = false;
+    constexpr bool RUP = false;       // (no upsampled-residual form of this kernel)
 #include "fd_conv_epilogue.inc"
 }
 

@@ -37,6 +37,7 @@ GN_FUSED_TOWER = _os.environ.get("FD_GN_FUSED_TOWER", "0") == "1"   # "1": the t
 # "1": a head-tower F(4x4) launch whose grid is no multiple of the CU count runs as whole rounds of workgroups + a tail launch ("head.tower3x3.tail", after the mark):
 # TwoLanePipeline releases the other lane when the whole rounds are done, so the tail round (60 % of the chip idle at 16 x 640 x 640) has company
 TOWER_TAIL_SPLIT = _os.environ.get("FD_TOWER_TAIL_SPLIT", "1") != "0"
+FPN_UP_FUSED = _os.environ.get("FD_FPN_UP_FUSED", "1") != "0"   # "0": the top-down path's x2 upsample + add as its own pass over the finer map (else in the lateral conv's epilogue)
 TOWER_GN_SPLIT = _os.environ.get("FD_TOWER_GN_SPLIT", "1") != "0"   # "0": the tower's GroupNorm normalises both halves in its own pass (else the box half in the narrow predictor's loader)
 GN_FUSED = _os.environ.get("FD_GN_FUSED", "1") != "0"       # "0": HISFCOSHead's GroupNorms as three-pass launches (statistics / finalise / normalise)
 WAVE_TILE = _os.environ.get("FD_WAVE_TILE", "1") != "0"       # "0": the 1x1 layers never see FD_TILE_WAVE64 (wave-autonomous tiles, fd_conv_wave.hip)
@@ -188,7 +189,7 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
              Cout: Optional[int] = None, act_c0: int = 0, seg_param=None, tag: int = 0, fold=None,
              gate: Optional[torch.Tensor] = None, gate_b: Optional[torch.Tensor] = None, gate_act: int = ACT_NONE,
              gn_stats: Optional[torch.Tensor] = None, gn_groups: int = 0,
-             x2: Optional[Rows] = None, x2_stride: int = 1, x2_hw: Optional[Tuple[int, int]] = None) -> Segs:
+             x2: Optional[Rows] = None, x2_stride: int = 1, x2_hw: Optional[Tuple[int, int]] = None, res_up: bool = False) -> Segs:
     """conv (+folded BN / bias) (+res) (+act).  `weight`/`bias` override conv's own (fused multi-conv launches);
     `fold` = (scale, shift) overrides the epilogue constants altogether (convs with different BN / bias merged by hand)."""
     dev = plan.device
@@ -202,6 +203,8 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
     else:
         pad = pad[0]
     Cin, co = w.shape[1], (w.shape[0] if Cout is None else Cout)
+    if res_up and (plan.precision != "f32" or k != 1 or stride != 1 or pad != 0 or segs.nseg != 1 or res is None or gate is not None or gn_stats is not None or x2 is not None):
+        raise FdError("add_conv: res_up (a half-resolution addend behind the activation) needs an exact-fp32 1x1 stride-1 single-level conv with a residual")
     if x2 is not None and (plan.precision != "f32" or k != 1 or stride != 1 or segs.nseg != 1 or (Cin - x2.C) % 32 or x2.C % 32 or gate is not None or gn_stats is not None):
         raise FdError("add_conv: a K-concatenated second input needs an exact-fp32 1x1 stride-1 single-level conv with 32-aligned channel counts")
     if Cin % 4 and x.co == 0 and x.C == x.cs and x.C % 4 == 0 and 0 < x.C - Cin < 4:
@@ -238,7 +241,7 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         wp = ops.pack_conv_weight_f16x3(_dev(w, dev)) if split else ops.pack_conv_weight(_dev(w, dev))
     # GEMM-addressed fp32 layers also get their weights in MFMA fragment order: the wave-autonomous tile (FD_TILE_WAVE64) becomes selectable
     wfrag = None
-    if (not wino and not narrow and not split and x2 is None and WAVE_TILE and gate is None and ops.wave_ok(Cin, co, k, stride, pad) and act_c0 % 32 == 0
+    if (not wino and not narrow and not split and x2 is None and not res_up and WAVE_TILE and gate is None and ops.wave_ok(Cin, co, k, stride, pad) and act_c0 % 32 == 0
             and act in (ACT_NONE, ACT_RELU, ACT_SILU) and y.cs % 4 == 0 and y.co % 4 == 0 and (res is None or (res.cs % 4 == 0 and res.co % 4 == 0))):
         if w.shape[0] == co and w.shape[1] == Cin:
             wfrag = ops.pack_conv_weight_wave(_dev(w, dev))
@@ -271,7 +274,7 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
                          precision=1 if split else 0, workspace=ws.buf if ws is not None else None,
                          tile=_lib.NARROW_TILE if narrow else ((_lib.WINO4_TILE if wino4 else _lib.WINO_TILE) if wino else 0), ksplit=wino_ks if wino else 1,
                          gate=gate, w_frag=wfrag,
-                         gate_b=gate_b, gate_act=gate_act, gn_stats=gn_stats, gn_groups=gn_groups, x2=x2, x2_stride=x2_stride, x2_hw=x2_hw)
+                         gate_b=gate_b, gate_act=gate_act, gn_stats=gn_stats, gn_groups=gn_groups, x2=x2, x2_stride=x2_stride, x2_hw=x2_hw, res_up=res_up)
     tail = None
     if tag == 1 and wino4 and wino_ks <= 1 and TOWER_TAIL_SPLIT:
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -296,12 +299,17 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
         plan.tiles[name] = 0                 # (the library picks the tile of a gated conv)
     elif plan.autotune:
         hw = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
-        key = f"B{segs.batch}|{hw}|{Cin}>{co}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None)}|xcs{x.cs}|ycs{y.cs}"
+        # (res_up: the quarter-size addend costs next to nothing -- the plain layer's measured tile, mapped below onto the tiles that form is built for)
+        key = f"B{segs.batch}|{hw}|{Cin}>{co}|k{k}s{stride}p{pad}d{dil}|res{int(res is not None and not res_up)}|xcs{x.cs}|ycs{y.cs}"
         if split:
             key = "f16x3|" + key
         if x2 is not None:
             key += f"|x2s{x2_stride}c{x2.C}"
         plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co, -(-Cin // 32) * k * k, pair=plan.pair_tuned and tag != 1)
+        if res_up:
+            t = {1: 8, 2: 8, 3: 9, 4: 4, 7: 8, 8: 8, 9: 9}.get(plan.tiles[name] & 0xFF, 9)
+            call.params.tile, call.params.ksplit = t, 1
+            plan.tiles[name] = t
         if x2 is not None:         # the dual-source loader is built for the tiles the bottleneck expansions use: map the choice onto them, no split-K
             t = {1: 7, 2: 8, 3: 9, 4: 4, 7: 7, 8: 8, 9: 9}.get(plan.tiles[name] & 0xFF, 8)
             call.params.tile, call.params.ksplit = t, 1
@@ -653,14 +661,21 @@ def build_his_fpn(plan: Plan, fpn, feats):
     _his_block(plan, "fpn.HisBlock1", fpn.HisBlock1, a, s5, t3)
     pool.put(a)
     l4 = pool.get(s4.rows, F)
-    add_conv(plan, "fpn.tf2", c4, s4, fpn.tf2, l4, bn=fpn.gn2, act=ACT_RELU)
-    plan.add("fpn.up1_add", lambda: ops.upsample2x_add(t3, l4, l4, B, hw[2][0], hw[2][1]))
+    up_fused = FPN_UP_FUSED and plan.precision == "f32" and all(h % 2 == 0 and w % 2 == 0 for h, w in hw[:2]) and fpn.tf2.weight.shape[1] % 32 == 0 and fpn.tf3.weight.shape[1] % 32 == 0
+    if up_fused:       # relu(gn2(tf2(c4))) + Up_sample1(t3) in one launch: the coarser level is read at (i / 2, j / 2) by the lateral's epilogue (HISFcos.py:155-159)
+        add_conv(plan, "fpn.tf2+up1_add", c4, s4, fpn.tf2, l4, bn=fpn.gn2, act=ACT_RELU, res=t3, res_up=True)
+    else:
+        add_conv(plan, "fpn.tf2", c4, s4, fpn.tf2, l4, bn=fpn.gn2, act=ACT_RELU)
+        plan.add("fpn.up1_add", lambda: ops.upsample2x_add(t3, l4, l4, B, hw[2][0], hw[2][1]))
     t4 = pool.get(s4.rows, F)
     _his_block(plan, "fpn.HisBlock2", fpn.HisBlock2, l4, s4, t4)
     pool.put(l4)
     l3 = pool.get(s3.rows, F)
-    add_conv(plan, "fpn.tf3", c3, s3, fpn.tf3, l3, bn=fpn.gn2, act=ACT_RELU)  # gn2 again: HISFcos.py:163
-    plan.add("fpn.up2_add", lambda: ops.upsample2x_add(t4, l3, l3, B, hw[1][0], hw[1][1]))
+    if up_fused:
+        add_conv(plan, "fpn.tf3+up2_add", c3, s3, fpn.tf3, l3, bn=fpn.gn2, act=ACT_RELU, res=t4, res_up=True)  # gn2 again: HISFcos.py:163
+    else:
+        add_conv(plan, "fpn.tf3", c3, s3, fpn.tf3, l3, bn=fpn.gn2, act=ACT_RELU)  # gn2 again: HISFcos.py:163
+        plan.add("fpn.up2_add", lambda: ops.upsample2x_add(t4, l3, l3, B, hw[1][0], hw[1][1]))
     _his_block(plan, "fpn.HisBlock3", fpn.HisBlock3, l3, s3, level(0))
     pool.put(l3)
     i4 = pool.get(s4.rows, F)

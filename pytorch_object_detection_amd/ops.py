@@ -197,7 +197,7 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
               out_hw: Optional[Tuple[int, int]] = None, scatter: Optional[Tuple[int, int, int, int, int, int]] = None,
               gate: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None, gn_stats: Optional[torch.Tensor] = None,
               gn_groups: int = 0, gate_b: Optional[torch.Tensor] = None, gate_act: int = ACT_NONE,
-              x2: Optional[Rows] = None, x2_stride: int = 1, x2_hw: Optional[Tuple[int, int]] = None) -> Callable[[], None]:
+              x2: Optional[Rows] = None, x2_stride: int = 1, x2_hw: Optional[Tuple[int, int]] = None, res_up: bool = False) -> Callable[[], None]:
     """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream.
     w_frag: the same weights in FD_TILE_WAVE64's fragment order (pack_conv_weight_wave), which makes that tile selectable."""
     _need_gpu(w_packed, scale, shift)
@@ -217,6 +217,10 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     p.act, p.act_c0, p.mode = act, act_c0, (_lib.CONV_STEM if stem else _lib.CONV_GENERIC)
     p.tile, p.tag, p.precision, p.ksplit = tile, tag, precision, ksplit
     p.res_mode = 1 if (res_mask and res is not None) else 0
+    if res_up:        # `res` = the coarser level [batch, H / 2, W / 2]: added after the activation at (i / 2, j / 2) (fd_conv_params.res_mode 2)
+        if res is None or res_mask or segs.nseg != 1 or res.rows != segs.batch * (segs.H[0] // 2) * (segs.W[0] // 2):
+            raise FdError("conv_call: res_up needs a single-level conv and a residual of batch * (H / 2) * (W / 2) rows, no mask")
+        p.res_mode = 2
     if gate is not None:             # [levels * batch, >= Cin] fp32: per-(level, image, input channel) gate applied in the loader (1x1 convs)
         _need_gpu(gate, gate_b)
         if gate.dim() != 2 or gate.shape[0] != segs.batch * segs.nseg or gate.stride(1) != 1 or gate.dtype != torch.float32:

@@ -1525,3 +1525,42 @@ def test_conv3x3_winograd_f4x4_as_slices_of_its_grid(case):
     direct = ops.conv_call(ops.Rows(x), segs, ops.pack_conv_weight(wt.to(DEV)), ops.Rows(yb), Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, tile=4)
     with pytest.raises(Exception, match="WINOGRAD4"):
         ops.conv_wg_slice(direct, 0, 8)()
+
+
+@pytest.mark.parametrize("case", [(1024, 256, 2, 40, 40, 9), (512, 256, 1, 80, 80, 8), (64, 96, 3, 6, 10, 4), (128, 64, 2, 14, 2, 0)])
+def test_conv1x1_with_the_upsampled_coarser_level_added_in_its_epilogue(case):
+    """fd_conv_params.res_mode 2: an FPN lateral -- relu(bn(conv1x1(c))) + Upsample(x2, nearest)(coarser) (HISFcos.py:155-165; without the activation: Fcos.py:77-91)
+    -- as ONE launch: the epilogue reads the half-resolution map at (i / 2, j / 2) and adds it AFTER the activation.  Must equal, BIT FOR BIT, the conv launch
+    followed by fd_upsample2x_add_nhwc (same two addends per element), and F.interpolate + F.conv2d in fp64; channel views with NaN neighbours; odd sizes / other
+    tiles / split-K are clean errors."""
+    Cin, Cout, B, H, W, tile = case
+    gen = torch.Generator().manual_seed(Cin + Cout + H)
+    segs = Segs.make(B, [(H, W)])
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    up = torch.randn(B, Cout, H // 2, W // 2, generator=gen)
+    wt = torch.randn(Cout, Cin, 1, 1, generator=gen) / Cin ** 0.5
+    sc, sf = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen) * 0.3
+    xb = torch.full((segs.rows, Cin + 8), float("nan"), device=DEV)
+    xb[:, 4:4 + Cin] = x.permute(0, 2, 3, 1).reshape(-1, Cin).to(DEV)
+    ub = torch.full((B * (H // 2) * (W // 2), Cout + 4), float("nan"), device=DEV)
+    ub[:, :Cout] = up.permute(0, 2, 3, 1).reshape(-1, Cout).to(DEV)
+    wp = ops.pack_conv_weight(wt.to(DEV))
+    # two launches
+    y0 = ops.new_rows(segs.rows, Cout, DEV)
+    ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y0, Cin=Cin, Cout=Cout, k=1, scale=sc.to(DEV), shift=sf.to(DEV), act=ACT_RELU, tile=tile)()
+    ops.upsample2x_add(ops.Rows(ub, 0, Cout), y0, y0, B, H // 2, W // 2)
+    # one launch
+    yb = torch.full((segs.rows, Cout + 8), float("nan"), device=DEV)
+    ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(yb, 4, Cout), Cin=Cin, Cout=Cout, k=1, scale=sc.to(DEV), shift=sf.to(DEV), act=ACT_RELU, tile=tile,
+                  res=ops.Rows(ub, 0, Cout), res_up=True)()
+    assert torch.isnan(yb[:, :4]).all() and torch.isnan(yb[:, 4 + Cout:]).all(), "wrote outside its channel view"
+    assert torch.equal(yb[:, 4:4 + Cout], y0.tensor()), float((yb[:, 4:4 + Cout] - y0.tensor()).abs().max())
+    ref = (F.relu(F.conv2d(x.double(), wt.double()) * sc.double()[None, :, None, None] + sf.double()[None, :, None, None])
+           + F.interpolate(up.double(), scale_factor=2, mode="nearest")).float()
+    got = yb[:, 4:4 + Cout].cpu().reshape(B, H, W, Cout).permute(0, 3, 1, 2)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    for bad in (dict(tile=1), dict(tile=9, ksplit=2, workspace=torch.empty(1 << 22, device=DEV))):
+        with pytest.raises(Exception, match="res_mode 2"):
+            ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(yb, 4, Cout), Cin=Cin, Cout=Cout, k=1, res=ops.Rows(ub, 0, Cout), res_up=True, **bad)()
+    with pytest.raises(Exception, match="res_up"):           # a residual of the wrong size never reaches the library
+        ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(yb, 4, Cout), Cin=Cin, Cout=Cout, k=1, res=y0, res_up=True)
