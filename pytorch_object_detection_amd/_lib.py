@@ -22,7 +22,9 @@ PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2     # include/fcosdet.h FD_PREC_*
 WINO_TILE = 14      # Winograd F(2x2, 3x3) kernel (own weight packing: ops.pack_conv_weight_wino); not a member of TILES
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfcosdet_hip.so")
+# FD_LIB: another build of the SAME library (development A/B runs: tools/gpu_ab.sh keeps its variants outside the package and never overwrites the product
+# library).  It must export every entry point below -- there is still no fallback of any kind.
+LIB_PATH = os.environ.get("FD_LIB") or os.path.join(_HERE, "csrc", "libfcosdet_hip.so")
 
 
 class FdError(RuntimeError):

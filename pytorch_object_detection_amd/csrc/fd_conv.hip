@@ -438,8 +438,19 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
         FD_REQUIRE(p->stride == 1 && 2 * p->pad == p->dil * (p->KH - 1) && p->KH == p->KW, FD_E_INVAL,
                    "fd_conv2d: multi-level input needs stride 1 and 'same' padding");
 
-    FD_REQUIRE(!(p->res && p->res_mode == 2) || p->tile == FD_TILE_AUTO || p->tile == FD_TILE_64x64 || p->tile == FD_TILE_128x64_SB || p->tile == FD_TILE_64x128_SB, FD_E_UNSUPPORTED,
-               "fd_conv2d: res_mode 2 is built for tiles 64x64, 128x64_SB, 64x128_SB (got %d)", p->tile);
+    FD_REQUIRE(p->res_mode >= 0 && p->res_mode <= 2, FD_E_INVAL, "fd_conv2d: res_mode %d", p->res_mode);
+    if (p->res && p->res_mode == 2) {
+        // The half-resolution addend has M / 4 rows: every kernel that is NOT an RUP instantiation would read `res` at all M output rows (out of bounds).  The whole
+        // precondition therefore sits HERE, in front of every early return below (gate, x2, split-K, f16 / f16x3, gn_stats, tag 1 and the stem never reach an RUP kernel).
+        FD_REQUIRE(p->tile == FD_TILE_AUTO || p->tile == FD_TILE_64x64 || p->tile == FD_TILE_128x64_SB || p->tile == FD_TILE_64x128_SB, FD_E_UNSUPPORTED,
+                   "fd_conv2d: res_mode 2 is built for tiles 64x64, 128x64_SB, 64x128_SB (got %d)", p->tile);
+        FD_REQUIRE(!stem && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0 && p->in.nseg == 1 && p->Cin % 32 == 0 && p->precision == FD_PREC_F32 &&
+                       p->ksplit <= 1 && p->sc_H <= 0 && p->out_H <= 0 && p->out_W <= 0 && !p->gate && !p->gn_stats && !p->x2 && p->tag != 1 &&
+                       p->in.H[0] % 2 == 0 && p->in.W[0] % 2 == 0 && p->Cout % 4 == 0 && p->y_cs % 4 == 0 && p->y_co % 4 == 0 && ((uintptr_t)p->y & 15) == 0 &&
+                       p->res_cs % 4 == 0 && p->res_co % 4 == 0 && ((uintptr_t)p->res & 15) == 0,
+                   FD_E_UNSUPPORTED, "fd_conv2d: res_mode 2 (half-resolution addend) needs an fp32 1x1 stride-1 unpadded single-level conv with even H, W, Cin %% 32 == 0, "
+                                     "16-byte views, no split-K / scatter / gate / gn_stats / x2 / tag 1");
+    }
     FD_REQUIRE(p->wg_count <= 0 || p->tile == FD_TILE_WINOGRAD4, FD_E_UNSUPPORTED, "fd_conv2d: wg_first / wg_count (a slice of the layer's grid) exist for FD_TILE_WINOGRAD4 only");
     if (p->tile == FD_TILE_WINOGRAD) return fd_launch_conv_wino(p, stream);   // own argument block, own weight packing
     if (p->tile == FD_TILE_WINOGRAD4) return fd_launch_conv_wino4(p, stream);
@@ -452,7 +463,6 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     a.act = p->act; a.act_c0 = p->act_c0;
     a.res_mask = (p->res && p->res_mode == 1) ? 1 : 0;
     a.res_up = 0;
-    FD_REQUIRE(p->res_mode >= 0 && p->res_mode <= 2, FD_E_INVAL, "fd_conv2d: res_mode %d", p->res_mode);
     a.nseg = p->in.nseg;
     long mo = 0;
     for (int s = 0; s < FD_MAX_SEG; ++s) {

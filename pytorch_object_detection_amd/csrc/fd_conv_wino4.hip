@@ -29,6 +29,8 @@
 // DESIGN 4.1d has the measurements (head tower 1.39 -> 0.92 ms against F(2x2)) and what did and did not matter on the way there.
 #include "fd_conv_common.h"
 #include <type_traits>
+#include <vector>
+#include <cstdio>
 
 struct Wino4Args {
     const float* x; const float* u; const float* scale; const float* shift; const float* res; float* y;
@@ -48,12 +50,15 @@ struct Wino4Args {
     int blk0;                     // first workgroup of this launch in the layer's grid (fd_conv_params.wg_first; a multiple of 8: the XCD of a workgroup is unchanged)
     unsigned x_bytes, u_bytes;
     int dbg;                      // timing builds only (-DFD_W4_TIMING + FD_W4_DBG): 1 = no loader stages, 2 = no MFMAs, 4 = no epilogue (wrong results)
+    long long* ts;                // timing builds only (FD_W4_TS=<file>): per workgroup, the 100 MHz wall clock at entry / set-up done / prologue done / chunk loop done / end
 };
 // The shipped library never skips parts of the kernel: the timing switches exist only in a build compiled with -DFD_W4_TIMING (tools/pmc_wino.sh).
 #ifdef FD_W4_TIMING
 #define W4_DBG(a) ((a).dbg)
+#define W4_TS(a, k) do { if ((a).ts && threadIdx.x == 0) (a).ts[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
 #else
 #define W4_DBG(a) 0
+#define W4_TS(a, k) do { } while (0)
 #endif
 
 #define W4_TB 32
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = wave & 3, ch = wave >> 2;
     const int l31 = lane & 31, lh = lane >> 5;
+    W4_TS(a, 0);
 
     // XCD-aware order (as fd_conv_wino.hip): XCD x owns M tiles [x * mt_per, (x + 1) * mt_per) and walks them cout tile by cout tile
     const int bx = blockIdx.x + a.blk0;
@@ -212,6 +218,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     };
 
     const int NC = min(a.NC, c0 + a.nc_per) - c0;               // this slice's chunks [c0, c0 + NC)
+    W4_TS(a, 1);
     // ---- prologue: the patch rows of chunks 0, 1, 2 are requested together (ONE global round trip, not three: the accumulators are not live yet,
     // registers are plenty), then R(0) R(1) | C(0): V[0] holds chunk 0, scratch[1] chunk 1's row pass, the patch registers chunk 2 ----
     {
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     __syncthreads();
     if (ldr) stage_C(0);
     __syncthreads();
+    W4_TS(a, 2);
 
     // Main loop: one 8-channel chunk per iteration and workgroup barrier.  The loader stages of the NEXT chunks are cut into slices that sit between
     // the nine MFMA groups of this chunk (pinned with sched_barriers): issued in the shadow of the 64-cycle MFMAs instead of in front of them
@@ -289,7 +297,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     // ---- epilogue: two halves of the 32 tiles in turn through the (now free) LDS, both channel blocks and all eight waves at once ----
     // Accumulator rows 0..15 are registers e = 0..7 of every f32x16, rows 16..31 registers 8..15: half h is dead in the register file once written, so
     // the output pass of half 0 runs beside 72 live accumulator registers only (the whole-tile variant spilled, the block-by-block one idled four waves).
-    if (W4_DBG(a) & 4) return;
+    W4_TS(a, 3);
+    if (W4_DBG(a) & 4) { W4_TS(a, 4); return; }
     float* Ms = reinterpret_cast<float*>(smem);                          // [2 ch][36 f][16 tiles][32 cout]
     // output role: thread = (channel block, row pair of the 4 x 4 outputs, tile of the half, cout quad)
     int te = tid;
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
         const Tile4 ep = wino4_decode(a, tile0 + 16 * h + et);
         const int eH = a.H[ep.s], eW = a.W[ep.s];
         const float eprm = a.seg_param[ep.s];
-        if (ep.ok && nn < a.Cout) {
+        if (ep.ok && nn < a.Cout && !(W4_DBG(a) & 16)) {       // (timing builds, 16: dump + barriers only)
             // Y = A^T M A, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]: per frequency row i the column pass r_i[y], then
             // Y[x][y] += A^T[x][i] * r_i[y] for this thread's two rows x = 2 eh, 2 eh + 1 (eh is wave-uniform; the zero entries of A^T cost nothing)
             float4 Y[2][4];
@@ -375,11 +384,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                         if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, eprm);
                         if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, eprm);
                     }
+                    if ((W4_DBG(a) & 8) && v.x != 12345.678f) continue;          // (timing builds: the epilogue without its global stores)
                     *reinterpret_cast<float4*>(a.y + (size_t)blockIdx.y * a.slice_stride + m_ * a.y_cs + a.y_co + nn) = v;
                 }
             }
         }
     }
+#ifdef FD_W4_TIMING
+    __syncthreads();
+    W4_TS(a, 4);
+#endif
 }
 
 // U = G g G^T per filter (fd_wino4_pack_one, fd_conv_common.h): one (n, k) filter per thread.
@@ -476,6 +490,7 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
 #else
     a.dbg = 0;
 #endif
+    a.ts = nullptr;
     a.mtiles = (a.T + W4_TB - 1) / W4_TB;
     a.ntiles = (p->Cout + 63) / 64;
     a.mt_per = (a.mtiles + 7) / 8;
@@ -522,6 +537,41 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
         FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (Winograd F(4x4,3x3), split-K)");
         return fd_launch_splitk_reduce(o, (const float*)p->workspace, nslice, ldw, slab, stream);
     }
+#ifdef FD_W4_TIMING
+    // FD_W4_TS=<file>: every launch is followed by a device synchronisation and one line of per-workgroup phase times (development builds only)
+    static const char* ts_path = getenv("FD_W4_TS");
+    static long long* ts_dev = nullptr;
+    const size_t ts_n = (size_t)grid.x * grid.y * 8;
+    if (ts_path) {
+        if (!ts_dev) (void)hipMalloc((void**)&ts_dev, (size_t)(1 << 16) * 8 * sizeof(long long));
+        if (ts_n <= (size_t)(1 << 16) * 8) { a.ts = ts_dev; (void)hipMemsetAsync(ts_dev, 0, ts_n * sizeof(long long), stream); }
+    }
+    struct TsDump {
+        const char* path; long long* dev; size_t n; hipStream_t st; const Wino4Args& a;
+        ~TsDump() {
+            if (!path || !a.ts) return;
+            (void)hipStreamSynchronize(st);
+            std::vector<long long> h(n);
+            (void)hipMemcpy(h.data(), dev, n * sizeof(long long), hipMemcpyDeviceToHost);
+            long long first = 0, last = 0; double ph[4] = {0, 0, 0, 0}, tot = 0, totmax = 0; size_t live = 0;
+            for (size_t b = 0; b < n / 8; ++b) {
+                const long long* t = &h[b * 8];
+                if (!t[0] || !t[4]) continue;
+                if (!live || t[0] < first) first = t[0];
+                if (!live || t[4] > last) last = t[4];
+                for (int k = 0; k < 4; ++k) ph[k] += (double)(t[k + 1] - t[k]);
+                tot += (double)(t[4] - t[0]); if ((double)(t[4] - t[0]) > totmax) totmax = (double)(t[4] - t[0]);
+                ++live;
+            }
+            if (FILE* f = fopen(path, "a")) {
+                const double u = 0.01 / (live ? live : 1);     // 100 MHz ticks -> us, mean over the live workgroups
+                fprintf(f, "w4ts Cin %d Cout %d T %d wgs %zu live %zu dbg %d | span_us %.2f | per-wg us: setup %.2f prologue %.2f loop %.2f epilogue %.2f total %.2f max %.2f\n",
+                        a.Cin, a.Cout, a.T, n / 8, live, a.dbg, (double)(last - first) * 0.01, ph[0] * u, ph[1] * u, ph[2] * u, ph[3] * u, tot * u, totmax * 0.01);
+                fclose(f);
+            }
+        }
+    } ts_dump{ts_path, ts_dev, ts_n, stream, a};
+#endif
     if (p->tag == 1) {
         static std::atomic<unsigned> m1{0};
         fd_set_max_lds_once(m1, reinterpret_cast<const void*>(conv3x3_wino4_kernel<1>), lds);

@@ -1562,5 +1562,15 @@ def test_conv1x1_with_the_upsampled_coarser_level_added_in_its_epilogue(case):
     for bad in (dict(tile=1), dict(tile=9, ksplit=2, workspace=torch.empty(1 << 22, device=DEV))):
         with pytest.raises(Exception, match="res_mode 2"):
             ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(yb, 4, Cout), Cin=Cin, Cout=Cout, k=1, res=ops.Rows(ub, 0, Cout), res_up=True, **bad)()
+    # ... and so is every combination whose kernel is not an RUP instantiation (it would read the quarter-size map at all M rows): rejected in front of the
+    # library's early returns (gate, f16 / f16x3, gn_stats, tag 1), nothing is launched and the output keeps its contents
+    before = yb.clone()
+    gate = torch.ones(B, Cin, device=DEV)
+    for bad in (dict(gate=gate), dict(precision=1), dict(precision=2), dict(tag=1), dict(tag=1, tile=8),
+                dict(gn_stats=torch.zeros(segs.rows, 32, 2, device=DEV), gn_groups=32)):
+        with pytest.raises(Exception, match="res_mode 2"):
+            ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(yb, 4, Cout), Cin=Cin, Cout=Cout, k=1, res=ops.Rows(ub, 0, Cout), res_up=True, **bad)()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(yb, nan=-7.0), torch.nan_to_num(before, nan=-7.0))
     with pytest.raises(Exception, match="res_up"):           # a residual of the wrong size never reaches the library
         ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(yb, 4, Cout), Cin=Cin, Cout=Cout, k=1, res=y0, res_up=True)

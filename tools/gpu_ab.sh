@@ -1,10 +1,9 @@
-# same-box A/B of two builds of the library: csrc/_build/libold.so (previous commit) against the current one
+# same-box A/B of two builds of the library: tools/_ab/libold.so (a previous build, copied there by hand: `cp csrc/libfcosdet_hip.so tools/_ab/libold.so` before the
+# change) against the current one.  The variants are selected through FD_LIB (pytorch_object_detection_amd/_lib.py): the product library is never overwritten.
 cd $GRAFT_REPO_ROOT
-L=pytorch_object_detection_amd/csrc
-cp $L/libfcosdet_hip.so /tmp/libnew.so
 for round in 1 2; do
   for which in new old; do
-    if [ $which = old ]; then cp $L/_build/libold.so $L/libfcosdet_hip.so; else cp /tmp/libnew.so $L/libfcosdet_hip.so; fi
+    if [ $which = old ]; then export FD_LIB=$PWD/tools/_ab/libold.so; else unset FD_LIB; fi
     echo "== $which (round $round)"
     timeout -k 10 300 python bench.py --no-fast-mode --no-train-step --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-110
     if [ $round = 1 ]; then
@@ -13,4 +12,3 @@ for round in 1 2; do
     fi
   done
 done
-cp /tmp/libnew.so $L/libfcosdet_hip.so
