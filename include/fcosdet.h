@@ -196,7 +196,19 @@ typedef struct fd_conv_params {
      * is no multiple of the CU count ends in a round with most of the chip idle (the HISFCOS head tower at 16 x 640 x 640: 2 152 workgroups = 8.4 rounds
      * on 256 CUs); launched as whole rounds + a tail, the caller can schedule other work beside the tail (pipeline.TwoLanePipeline).  wg_count = 0: all. */
     int32_t wg_first, wg_count;
+    /* FD_TILE_WINOGRAD4 only: the PERSISTENT stream-K form of the launch.  sk_wgs > 0 (a multiple of 8, at most the CU count: 256 on MI355X): that many workgroups, each
+     * walks a contiguous, equally long range of the layer's (tile block, 8-channel chunk) units; an item cut by a range boundary is finished by the workgroup that holds its
+     * first chunks, which adds the other parts' partial outputs (workspace slots, signalled through flags) in a fixed order -- deterministic, and bit-identical to the plain
+     * launch for every item that is not cut.  The layer then takes total-work / CUs instead of whole rounds of workgroups (HISFCOS cls_logits, HISFcos.py:207: 538 items on
+     * 256 CUs = 2.1 rounds that ran as 3), and a CU's items follow each other without a dispatch in between.  `workspace` = fd_conv_sk_workspace_bytes(sk_wgs) bytes,
+     * 256-byte aligned, its first 8192 bytes (slot flags + the XCDs' queue heads: a fixed header, so launches with different sk_wgs may share a workspace that is large
+     * enough for the largest) ZERO before the first launch (every launch leaves them zero); one workspace per concurrently running launch.  No split-K,
+     * no wg_first / wg_count.  0: off. */
+    int32_t sk_wgs;
+    int32_t reserved1;
 } fd_conv_params;
+/* Workspace bytes of the persistent stream-K form (flags + one 128 KB slot per workgroup); -1: sk_wgs not a multiple of 8 in 8 .. 1024. */
+int64_t fd_conv_sk_workspace_bytes(int32_t sk_wgs);
 
 int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t stream);
 /* Workgroups (grid.x) of the launch `p` describes -- FD_TILE_WINOGRAD4 only (FD_E_UNSUPPORTED otherwise): the range wg_first / wg_count index. */

@@ -88,7 +88,7 @@ class ConvParams(C.Structure):
                 ("gate", C.c_void_p), ("gate_cs", C.c_int32), ("reserved0", C.c_int32), ("w_frag", C.c_void_p),
                 ("gn_stats", C.c_void_p), ("gn_groups", C.c_int32), ("gate_act", C.c_int32), ("gate_b", C.c_void_p),
                 ("x2", C.c_void_p), ("x2_cs", C.c_int32), ("x2_co", C.c_int32), ("x2_Cin", C.c_int32), ("x2_stride", C.c_int32), ("x2_H", C.c_int32),
-                ("x2_W", C.c_int32), ("wg_first", C.c_int32), ("wg_count", C.c_int32)]
+                ("x2_W", C.c_int32), ("wg_first", C.c_int32), ("wg_count", C.c_int32), ("sk_wgs", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class PackJob(C.Structure):
@@ -117,6 +117,7 @@ _SIGS = {
     "fd_conv_workgroups_live": (_I, [C.POINTER(ConvParams)]),
     "fd_conv1x1_b2b_f32": (_I, [C.POINTER(B2BParams), _P]),
     "fd_conv_workspace_bytes": (_L, [_L, _I, _I]),
+    "fd_conv_sk_workspace_bytes": (_L, [_I]),
     "fd_conv_wgrad_workspace_bytes": (_L, [_L, _I, _I, _I, _I]),
     "fd_pack_conv_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fd_pack_conv_weights_batch_f32": (_I, [_P, _I, _L, _P]),

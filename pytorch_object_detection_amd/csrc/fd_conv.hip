@@ -452,6 +452,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
                                      "16-byte views, no split-K / scatter / gate / gn_stats / x2 / tag 1");
     }
     FD_REQUIRE(p->wg_count <= 0 || p->tile == FD_TILE_WINOGRAD4, FD_E_UNSUPPORTED, "fd_conv2d: wg_first / wg_count (a slice of the layer's grid) exist for FD_TILE_WINOGRAD4 only");
+    FD_REQUIRE(p->sk_wgs <= 0 || p->tile == FD_TILE_WINOGRAD4, FD_E_UNSUPPORTED, "fd_conv2d: sk_wgs (the persistent stream-K form) exists for FD_TILE_WINOGRAD4 only");
     if (p->tile == FD_TILE_WINOGRAD) return fd_launch_conv_wino(p, stream);   // own argument block, own weight packing
     if (p->tile == FD_TILE_WINOGRAD4) return fd_launch_conv_wino4(p, stream);
     if (p->tile == FD_TILE_NARROW) return fd_launch_conv_narrow(p, stream);

@@ -49,18 +49,30 @@ struct Wino4Args {
     int mtiles, ntiles, mt_per;   // M tiles (32 tiles each), N tiles (64 cout), M tiles per XCD
     int blk0;                     // first workgroup of this launch in the layer's grid (fd_conv_params.wg_first; a multiple of 8: the XCD of a workgroup is unchanged)
     unsigned x_bytes, u_bytes;
+    // persistent stream-K form (SK kernels; fd_conv_params.sk_wgs): 8 * wpx workgroups, each walks a contiguous range of its XCD's (item, chunk) units
+    int wpx;                      // workgroups per XCD
+    int sk_P;                     // pieces a remainder item is queued as
+    float4* ws;                   // partial outputs, one slot of [16][512] float4 per workgroup
+    int* flags;                   // [1024] one per slot (1 = complete), [8] the XCDs' queue heads: all zero before and after every launch
     int dbg;                      // timing builds only (-DFD_W4_TIMING + FD_W4_DBG): 1 = no loader stages, 2 = no MFMAs, 4 = no epilogue (wrong results)
     long long* ts;                // timing builds only (FD_W4_TS=<file>): per workgroup, the 100 MHz wall clock at entry / set-up done / prologue done / chunk loop done / end
 };
 // The shipped library never skips parts of the kernel: the timing switches exist only in a build compiled with -DFD_W4_TIMING (tools/pmc_wino.sh).
 #ifdef FD_W4_TIMING
 #define W4_DBG(a) ((a).dbg)
-#define W4_TS(a, k) do { if ((a).ts && threadIdx.x == 0) (a).ts[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+// phase clocks: k = 0 entry, 1 .. 3 ACCUMULATE the time since the previous call over the segments of the workgroup (set-up | prologue | chunk loop), 4 = end: the record
+// holds entry, entry + set-up, ... + prologue, ... + loop, end -- the rest up to `end` is epilogue (+ flag waits, segment barriers)
+#define W4_TS(a, k) do { const long long n_ = wall_clock64(); if ((k) == 0) w4_t0 = n_; else if ((k) < 4) w4_acc[(k) - 1] += n_ - w4_last; w4_last = n_; \
+        if ((k) == 4 && (a).ts && threadIdx.x == 0) { long long* r_ = (a).ts + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8; r_[0] = w4_t0; r_[1] = w4_t0 + w4_acc[0]; \
+            r_[2] = r_[1] + w4_acc[1]; r_[3] = r_[2] + w4_acc[2]; r_[4] = n_; r_[6] = w4_segs; } } while (0)
 #else
 #define W4_DBG(a) 0
 #define W4_TS(a, k) do { } while (0)
 #endif
 
+// workspace header of the persistent form -- FIXED, whatever the grid: launches with different sk_wgs may share one workspace (with a header sized by sk_wgs, the slots
+// of a 240-workgroup launch lay over the queue heads of the 256-workgroup layout: garbage claims, a memory fault on the first mixed use)
+#define W4_SK_MAX_WGS 1024
 #define W4_TB 32
 #define W4_KC 8
 #define W4_PLANE (W4_TB * W4_KC)            // floats per frequency plane of V
@@ -126,25 +138,49 @@ __device__ __forceinline__ void w4_bt(const float4 (&d)[6], float4 (&t)[6]) {
 #undef W4_BT1
 }
 
-template <int TAG>
+// SK = false: one workgroup per (M tile, N tile) item (and split-K slice), grid = items.
+// SK = true: a PERSISTENT grid of 8 * wpx workgroups (at most one per CU) that CLAIM their work from one queue per XCD (an atomic counter in the workspace):
+//   * the queue of an XCD holds its `items` (M tile, N tile) items in the order of the plain launch (so the workgroups of an XCD always work on a window of neighbouring
+//     items: same 64-cout slice of U, neighbouring input rows -- static contiguous ranges per workgroup put all N tiles' U slices, 19 MB on the head tower, through a 4 MB
+//     L2 and were no faster than the plain launch; static round-robin lost the dynamic balance of the hardware dispatcher: CUs differ by ~5 % in speed);
+//   * the last items % wpx items -- the round of the plain launch that leaves most of the chip idle -- are queued as P PIECES each (P = sk_P, chosen by the host so that
+//     the pieces fill the chip once): piece pp = chunks [pp * NC / P, (pp + 1) * NC / P).  Pieces pp > 0 are PARTS: output-transformed, unscaled accumulators to the
+//     workspace slot (item, pp), then a flag; piece 0 is queued LAST of its item and FINISHES it: waits for the item's flags, adds the slots in chunk order, applies the
+//     epilogue.  A part never waits, and when piece 0 is claimed every part of its item has been claimed by a running workgroup: the grid drains whatever the dispatch
+//     order or the number of CUs it got.  Which workgroup computes what varies from run to run; WHAT is computed, and the order of every sum, does not: deterministic, and
+//     bit-identical to the plain launch for every item that is not cut.
+//   * the next claim is issued at the start of an epilogue and read at its end: no atomic round trip between two items.
+template <int TAG, bool SK>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Vs = reinterpret_cast<float*>(smem);                  // [2][36][32][8]
     float* Ss = Vs + 2 * W4_STAGE;                               // [2][32 tiles][2 q] blocks of W4_SBLK float4: [6 j'][6 i] + pad
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = wave & 3, ch = wave >> 2;
-    const int l31 = lane & 31, lh = lane >> 5;
+#ifdef FD_W4_TIMING
+    long long w4_t0 = 0, w4_last = 0, w4_acc[3] = {0, 0, 0}, w4_segs = 0;
+#endif
     W4_TS(a, 0);
 
     // XCD-aware order (as fd_conv_wino.hip): XCD x owns M tiles [x * mt_per, (x + 1) * mt_per) and walks them cout tile by cout tile
     const int bx = blockIdx.x + a.blk0;
-    const int xcd = bx & 7, idx = bx >> 3;
-    const int mt_lo = xcd * a.mt_per;
-    const int cnt = min(a.mtiles - mt_lo, a.mt_per);
-    if (cnt <= 0 || idx >= cnt * a.ntiles) return;
-    const int nt = idx / cnt, mt = mt_lo + (idx - nt * cnt);
-    const int tile0 = mt * W4_TB, n0 = nt * 64;
-    const int c0 = blockIdx.y * a.nc_per;                        // split-K: first chunk of this slice
+    const int xcd = bx & 7, jx = bx >> 3;
+    // (SK: the M tiles are dealt out evenly, mtiles / 8 or one more per XCD -- the plain grid's last XCD share is up to 7 tiles short, and the SK form's pieces are sized for all XCDs at once)
+    const int mt_lo = SK ? xcd * (a.mtiles >> 3) + min(xcd, a.mtiles & 7) : xcd * a.mt_per;
+    const int cnt = SK ? (a.mtiles >> 3) + (xcd < (a.mtiles & 7) ? 1 : 0) : min(a.mtiles - mt_lo, a.mt_per);
+    // SK: the XCD's queue = sk_W whole items, then the pieces of the remaining items; u = the unit this workgroup holds
+    int sk_W = 0, sk_units = 0, u = 0;
+    int* const sk_ctr = a.flags + (SK ? W4_SK_MAX_WGS + xcd : 0);
+    int* const claim_lds = reinterpret_cast<int*>(smem + (2 * W4_STAGE + 2 * W4_SSTAGE) * 4);
+    if constexpr (SK) {
+        const int items = max(cnt, 0) * a.ntiles;
+        const int rem = items % a.wpx;
+        sk_W = items - rem; sk_units = sk_W + rem * a.sk_P;
+        // the first unit of workgroup j is unit j (no atomic before the first prologue); claim v of the queue is unit wpx + v.  Every workgroup that got a unit makes
+        // exactly one claim that fails, so the queue sees exactly `sk_units` claims: the one that draws v = sk_units - 1 zeroes the counter for the next launch.
+        u = jx;
+        if (u >= sk_units) return;
+    } else {
+        if (cnt <= 0 || jx >= cnt * a.ntiles) return;
+    }
 
     constexpr unsigned OOB = 0xC0000000u;
     // The input resource starts ONE patch pixel before the tensor: the six columns of a patch row are then column j = 1's byte offset (per lane, or OOB)
@@ -152,11 +188,51 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     const int px_b = a.x_cs * 4 * a.dil;                         // bytes between neighbouring patch pixels of one row
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x - px_b), (short)0, (int)(a.x_bytes + (unsigned)px_b), 0x00020000);
     const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, (short)0, (int)a.u_bytes, 0x00020000);
+    // SK: the part slots.  Every access to them (and to the flags) is a DEVICE-scope access (sc1: served at the memory side of the L2s) -- the hand-over between two
+    // workgroups then needs no cache-wide operation: an agent-scope release / acquire FENCE writes back and invalidates the whole L2 of the XCD, and with it the weights and
+    // input rows all its workgroups re-use (measured: every layer 10 - 50 % slower than the plain launch).
+    constexpr int SC1 = 16;                                      // gfx940+ cache policy: scope bit 1 = agent scope
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.ws, (short)0, SK ? (int)(gridDim.x * (16 * 512 * 16)) : 0, 0x00020000);
 
+  for (;;) {                                                     // SK: the segments of this workgroup's range; else exactly one pass
+    // Every per-thread role constant is derived HERE, from an opaque copy of the thread index: nothing but scalars is carried from one segment into the next, so the
+    // epilogue (the most register-hungry part: 72 live accumulator registers beside the output pass) keeps no address of the next segment's loader alive.
+    int tid = threadIdx.x;
+    if constexpr (SK) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = wave & 3, ch = wave >> 2;
+    const int l31 = lane & 31, lh = lane >> 5;
     // ---- loader role (threads 0 .. 383): (tile lt, line pr, channel quad q); pr = patch row i in G / R, column j' in C ----
     const bool ldr = __builtin_amdgcn_readfirstlane(tid) < 384 && !(W4_DBG(a) & 1);       // wave-uniform: scalar branches around the loader slices
     // one line pr per WAVE, (tile, quad) per lane: every scratch / V instruction of a wave then walks 64 different blocks at one in-block offset
     const int q = tid & 1, lt = (tid >> 1) & 31, pr = min(tid >> 6, 5);
+    // scratch: S[lt][q][j'][i] float4 -- R writes element (j', i = pr) for j' = 0..5; C reads (j' = pr, i = 0..5): 6 consecutive float4
+    const int s_wr = ((lt * 2 + q) * W4_SBLK + pr) * 4;          // + j' * 24 floats
+    const int s_rd = ((lt * 2 + q) * W4_SBLK + pr * 6) * 4;      // + i * 4 floats
+    // V[f = 6 i' + j'][tile][8 c], plain: with one patch line per wave both the writes (64 lanes = one plane) and the MFMA reads are conflict-free
+    const int v_wr = (pr * W4_TB + lt) * W4_KC + 4 * q;          // + i' * 6 * W4_PLANE.  (A wave's 64 lanes = the 64 float4s of one plane: no bank is hit twice.)
+    const int v_half = 4 * lh;
+    int idx, c0, NC;                                             // item of the XCD's list, first chunk, chunks of this segment
+    bool part = false;                                           // SK: this segment is a PART (its item's head lies in an earlier workgroup)
+    int nparts = 0;                                              // SK: parts the following workgroups hold of the item this segment is the head of
+    int slot = 0;                                                // SK: this part's slot / the first slot of the item this segment finishes (per XCD)
+    if constexpr (SK) {
+        if ((unsigned)u >= (unsigned)sk_units) break;            // (unsigned: a queue head that was not zero at launch ends the workgroup instead of addressing tiles that do not exist)
+        if (u < sk_W) { idx = u; c0 = 0; NC = a.NC; }            // a whole item
+        else {                                                   // piece pp of the remainder item ri (pieces are queued tail first: ... 2, 1, 0)
+            const int k = u - sk_W, ri = k / a.sk_P, pp = a.sk_P - 1 - (k - ri * a.sk_P);
+            idx = sk_W + ri; c0 = pp * a.NC / a.sk_P; NC = (pp + 1) * a.NC / a.sk_P - c0;
+            part = pp > 0;
+            slot = ri * (a.sk_P - 1) + (part ? pp - 1 : 0);
+            if (!part) nparts = a.sk_P - 1;
+        }
+    } else {
+        idx = jx; c0 = blockIdx.y * a.nc_per;                    // split-K: first chunk of this slice
+        NC = min(a.NC, c0 + a.nc_per) - c0;                      // this slice's chunks [c0, c0 + NC)
+    }
+    const int nt = idx / cnt, mt = mt_lo + (idx - nt * cnt);
+    const int tile0 = mt * W4_TB, n0 = nt * 64;
+
     // patch row pr of tile lt: one base offset per thread; the six columns differ by a uniform pixel stride (buffer soffset) and a validity bit each
     unsigned a_off[6];                                           // a_base where the column is inside the image, OOB elsewhere
     {
@@ -169,23 +245,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) a_off[j] = (row_ok && (unsigned)((p.w0 - 1 + j) * a.dil + p.pw) < (unsigned)W) ? a_base : OOB;
     }
-    // scratch: S[lt][q][j'][i] float4 -- R writes element (j', i = pr) for j' = 0..5; C reads (j' = pr, i = 0..5): 6 consecutive float4
-    const int s_wr = ((lt * 2 + q) * W4_SBLK + pr) * 4;          // + j' * 24 floats
-    const int s_rd = ((lt * 2 + q) * W4_SBLK + pr * 6) * 4;      // + i * 4 floats
-    // V[f = 6 i' + j'][tile][8 c], plain: with one patch line per wave both the writes (64 lanes = one plane) and the MFMA reads are conflict-free
-    const int v_wr = (pr * W4_TB + lt) * W4_KC + 4 * q;          // + i' * 6 * W4_PLANE.  (A wave's 64 lanes = the 64 float4s of one plane: no bank is hit twice.)
 
     // ---- MFMA role ----
     const int nb = (n0 >> 5) + ch;
     const bool nb_ok = nb * 32 < ((a.Cout + 31) & ~31);
     const unsigned u_off0 = nb_ok ? ((unsigned)(nb * a.NC) * 36u + 9u * g) * 1024u + (unsigned)(l31 * 32 + lh * 16) : OOB;
-    const int v_half = 4 * lh;
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
     float4 pv[6], bq[9];
     auto load_G = [&](float4 (&dst)[6], int cc) {                 // global -> registers
@@ -217,21 +281,32 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
         bq[fi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (int)u_off0, ((c0 + cc) * 36 + fi) * 1024, 0));
     };
 
-    const int NC = min(a.NC, c0 + a.nc_per) - c0;               // this slice's chunks [c0, c0 + NC)
     W4_TS(a, 1);
     // ---- prologue: the patch rows of chunks 0, 1, 2 are requested together (ONE global round trip, not three: the accumulators are not live yet,
     // registers are plenty), then R(0) R(1) | C(0): V[0] holds chunk 0, scratch[1] chunk 1's row pass, the patch registers chunk 2 ----
-    {
+    // (Both paths define every patch register: inside the segment loop of the SK form a register that one path leaves undefined is "the value of the previous
+    // segment" to the compiler -- 72 registers carried through the epilogue and spilled.)
+    if (ldr) {
         float4 p0[6], p1[6];
-        if (ldr) { load_G(p0, 0); load_G(p1, min(1, NC - 1)); stage_G(min(2, NC - 1)); }
+        load_G(p0, 0); load_G(p1, min(1, NC - 1)); stage_G(min(2, NC - 1));
 #pragma unroll
         for (int fi = 0; fi < 9; ++fi) load_u(0, fi);
-        if (ldr) { row_pass(p0, 0); row_pass(p1, 1); }
+        row_pass(p0, 0); row_pass(p1, 1);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) pv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int fi = 0; fi < 9; ++fi) load_u(0, fi);
     }
     __syncthreads();
     if (ldr) stage_C(0);
     __syncthreads();
     W4_TS(a, 2);
+    f32x16 acc[9];                                               // (zeroed behind the prologue: its three chunks of patch rows need the registers)
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
     // Main loop: one 8-channel chunk per iteration and workgroup barrier.  The loader stages of the NEXT chunks are cut into slices that sit between
     // the nine MFMA groups of this chunk (pinned with sched_barriers): issued in the shadow of the 64-cycle MFMAs instead of in front of them
@@ -298,7 +373,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
     // Accumulator rows 0..15 are registers e = 0..7 of every f32x16, rows 16..31 registers 8..15: half h is dead in the register file once written, so
     // the output pass of half 0 runs beside 72 live accumulator registers only (the whole-tile variant spilled, the block-by-block one idled four waves).
     W4_TS(a, 3);
+#ifdef FD_W4_TIMING
+    ++w4_segs;
+#endif
+    int sk_next = 0;
     if (W4_DBG(a) & 4) { W4_TS(a, 4); return; }
+    if constexpr (SK) {
+        // the next claim goes out now and is read behind the epilogue
+        if (tid == 0) sk_next = __hip_atomic_fetch_add(sk_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // piece 0 of a cut item: wait for its parts (all claimed before this piece was; the flags are lowered again here: zero after the launch)
+        if (nparts && tid == 0) {
+#ifdef FD_W4_TIMING
+            const long long tw = wall_clock64();
+#endif
+            for (int p = 0; p < nparts; ++p) {
+                int* f = a.flags + xcd + 8 * (slot + p);
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+                __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#ifdef FD_W4_TIMING
+            if (a.ts) a.ts[(size_t)blockIdx.x * 8 + 5] = wall_clock64() - tw;
+#endif
+        }
+    }
     float* Ms = reinterpret_cast<float*>(smem);                          // [2 ch][36 f][16 tiles][32 cout]
     // output role: thread = (channel block, row pair of the 4 x 4 outputs, tile of the half, cout quad)
     int te = tid;
@@ -360,6 +457,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                     }
                 }
             }
+            if constexpr (SK) {
+                // slot layout [half][row x][column y][512 threads] float4: the writer and the finisher are the same thread of their workgroups
+                if (part) {
+                    const int so = ((xcd + 8 * slot) * 16 + h * 8) * (512 * 16);
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 4; ++y)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, Y[x][y]), wrsrc, te * 16,
+                                                                   so + (x * 4 + y) * (512 * 16), SC1);
+                    continue;
+                }
+                for (int p = 0; p < nparts; ++p) {
+                    const int so = ((xcd + 8 * (slot + p)) * 16 + h * 8) * (512 * 16);
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) {
+                            const float4 o = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, te * 16, so + (x * 4 + y) * (512 * 16), SC1));
+                            Y[x][y].x += o.x; Y[x][y].y += o.y; Y[x][y].z += o.z; Y[x][y].w += o.w;
+                        }
+                }
+            }
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 const int hh = (ep.h0 + 2 * eh + x) * a.dil + ep.ph;
@@ -390,6 +510,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
             }
         }
     }
+    if constexpr (!SK) break;
+    if (part) __builtin_amdgcn_s_waitcnt(0x0f70);                        // vmcnt(0): this wave's device-scope stores to the slot have been acknowledged
+    if (tid == 0) {
+        if (sk_next == sk_units - 1) __hip_atomic_store(sk_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the queue's last claim: ready for the next launch
+        *claim_lds = sk_next + a.wpx;
+    }
+    __syncthreads();                                                     // (also: the output pass has read its planes -- the next segment's prologue reuses the LDS)
+    if (part && tid == 0) __hip_atomic_store(a.flags + xcd + 8 * slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the slot is complete: raise its flag
+    u = __builtin_amdgcn_readfirstlane(*claim_lds);
+#ifdef FD_W4_TIMING
+    w4_last = wall_clock64();                                            // (the epilogue is not part of the next segment's set-up time)
+#endif
+  }
 #ifdef FD_W4_TIMING
     __syncthreads();
     W4_TS(a, 4);
@@ -421,6 +554,14 @@ extern "C" int32_t fd_wino4_pack_weights_f32(const float* w, const float* scale,
     hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, w, scale, out, N, K, mode);
     FD_CHECK_LAUNCH("fd_wino4_pack_weights_f32");
     return FD_OK;
+}
+
+// workspace of the persistent form: [8 KB header: 1024 slot flags, then the 8 XCDs' queue heads (ints)][slots: 16 x 512 float4 = 128 KB per workgroup]
+#define W4_SK_FLAG_BYTES(wgs) 8192L
+static int64_t fd_wino4_sk_workspace_bytes_impl(int wgs) { return W4_SK_FLAG_BYTES(wgs) + (int64_t)wgs * 16 * 512 * 16; }
+extern "C" int64_t fd_conv_sk_workspace_bytes(int32_t sk_wgs) {
+    if (sk_wgs < 8 || sk_wgs % 8 || sk_wgs > 1024) return -1;
+    return fd_wino4_sk_workspace_bytes_impl(sk_wgs);
 }
 
 // workgroups of the layer's F(4x4) launch (grid.x; with split-K: per slice): what fd_conv_params.wg_first / wg_count index
@@ -455,6 +596,8 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
                    (!p->res || (p->res_cs % 4 == 0 && p->res_co % 4 == 0 && ((uintptr_t)p->res & 15) == 0)) &&
                    (!p->scale || ((uintptr_t)p->scale & 15) == 0) && (!p->shift || ((uintptr_t)p->shift & 15) == 0),
                FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_WINOGRAD4 needs 16-byte addressable input / output / residual / scale / shift views");
+    FD_REQUIRE(p->sk_wgs <= 0 || (p->ksplit <= 1 && p->wg_count <= 0 && p->sk_wgs % 8 == 0 && p->sk_wgs <= 1024), FD_E_INVAL,
+               "fd_conv2d: sk_wgs = %d must be a multiple of 8, at most 1024, without split-K / wg_count", p->sk_wgs);
     Wino4Args a;
     a.x = p->x; a.u = p->w; a.scale = p->scale; a.shift = p->shift; a.res = p->res; a.y = p->y;
     a.x_cs = p->x_cs; a.x_co = p->x_co; a.res_cs = p->res_cs; a.res_co = p->res_co; a.y_cs = p->y_cs; a.y_co = p->y_co;
@@ -494,7 +637,7 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
     a.mtiles = (a.T + W4_TB - 1) / W4_TB;
     a.ntiles = (p->Cout + 63) / 64;
     a.mt_per = (a.mtiles + 7) / 8;
-    constexpr int lds = (2 * W4_STAGE + 2 * W4_SSTAGE) * 4;        // 146 KB
+    constexpr int lds = (2 * W4_STAGE + 2 * W4_SSTAGE) * 4 + 16;   // 146 KB + the SK form's claim word
     a.nc_per = a.NC; a.slice_stride = 0;
     const int ksplit = p->ksplit > 1 ? p->ksplit : 1;
     ConvArgs o = {};
@@ -522,6 +665,46 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
     const int nslice = (a.NC + a.nc_per - 1) / a.nc_per;
     dim3 grid((unsigned)(8 * a.mt_per * a.ntiles), (unsigned)nslice);
     a.blk0 = 0;
+    a.wpx = 0; a.sk_P = 1; a.ws = nullptr; a.flags = nullptr;
+    if (p->sk_wgs > 0) {
+        // persistent stream-K form: sk_wgs workgroups (a multiple of 8, one per CU at most) share the layer's (item, chunk) units evenly -- no last round with most of the chip
+        // idle (cls_logits: 538 items on 256 CUs ran as 3 rounds for 2.1 rounds of work), no workgroup dispatch / set-up between the items of a CU
+        a.wpx = p->sk_wgs / 8;
+        FD_REQUIRE((long)a.mt_per * a.ntiles * 16 < (1L << 30), FD_E_UNSUPPORTED, "fd_conv2d: sk_wgs: too many items per XCD");
+        {   // pieces per remainder item: the choice that gets the remainder of the fullest XCD through in the least time -- ceil(rem * P / wpx) passes of
+            // (NC / P chunks + the fixed cost of a segment), in units of one chunk's time (fixed cost ~ 6.5 chunks: profiles/r05_wino4_fixed_cost.txt); the slots of an XCD
+            // (rem * (P - 1)) must fit the workspace's wpx
+            static const int force_p = getenv("FD_W4_SK_P") ? atoi(getenv("FD_W4_SK_P")) : 0;
+            // (every XCD has its own remainder -- the last one owns fewer M tiles: the slot bound must hold for each, the time is the slowest XCD's)
+            int best = 1; double best_t = 1e30; bool any_rem = false;
+            for (int P = 1; P <= 4 && P <= a.NC; ++P) {          // (more than 4 pieces: the finisher's serial slot reads cost more than the pieces save -- layer1.conv2 at P = 8: 0.176 against 0.145 ms)
+                double t = 0.0; bool ok = true;
+                for (int x = 0; x < 8; ++x) {
+                    const int cx = (a.mtiles >> 3) + (x < (a.mtiles & 7) ? 1 : 0);
+                    if (cx <= 0) continue;
+                    const int items = cx * a.ntiles, rem = items % a.wpx;
+                    any_rem = any_rem || rem > 0;
+                    if (P > 1 && rem * (P - 1) > a.wpx) ok = false;
+                    const double tx = (double)(items / a.wpx) * (a.NC + 6.5) + (double)((rem * P + a.wpx - 1) / a.wpx) * ((double)a.NC / P + 6.5 + 1.5 * (P - 1));
+                    t = tx > t ? tx : t;
+                }
+                if (ok && t < best_t - 1e-9) { best_t = t; best = P; }
+            }
+            a.sk_P = any_rem ? best : 1;
+            bool force_ok = force_p > 0 && force_p <= a.NC && force_p <= 16;
+            for (int x = 0; x < 8 && force_ok; ++x) {
+                const int cx = (a.mtiles >> 3) + (x < (a.mtiles & 7) ? 1 : 0);
+                if (cx > 0 && force_p > 1 && (cx * a.ntiles % a.wpx) * (force_p - 1) > a.wpx) force_ok = false;
+            }
+            if (force_ok) a.sk_P = force_p;
+        }
+        const int64_t need = fd_wino4_sk_workspace_bytes_impl(p->sk_wgs);
+        FD_REQUIRE(p->workspace && ((uintptr_t)p->workspace & 255) == 0 && p->workspace_bytes >= need, FD_E_INVAL,
+                   "fd_conv2d: sk_wgs = %d needs a 256-byte aligned workspace of fd_conv_sk_workspace_bytes() = %ld bytes whose first 8192 bytes are zero", p->sk_wgs, (long)need);
+        a.flags = (int*)p->workspace;
+        a.ws = (float4*)((char*)p->workspace + W4_SK_FLAG_BYTES(p->sk_wgs));
+        grid.x = (unsigned)p->sk_wgs;
+    }
     if (p->wg_count > 0) {
         // a slice of the layer's grid (fd_conv_workgroups): the head tower's 2 152 workgroups are 8.4 rounds on 256 CUs -- launched as 8 whole rounds + a tail
         // launch, the caller can let other work in beside the tail instead of idling 60 % of the chip for a round (pipeline.TwoLanePipeline)
@@ -532,8 +715,8 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
     }
     if (ksplit > 1) {
         static std::atomic<unsigned> ms{0};
-        fd_set_max_lds_once(ms, reinterpret_cast<const void*>(conv3x3_wino4_kernel<0>), lds);
-        hipLaunchKernelGGL(conv3x3_wino4_kernel<0>, grid, dim3(512), lds, stream, a);
+        fd_set_max_lds_once(ms, reinterpret_cast<const void*>(conv3x3_wino4_kernel<0, false>), lds);
+        hipLaunchKernelGGL((conv3x3_wino4_kernel<0, false>), grid, dim3(512), lds, stream, a);
         FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (Winograd F(4x4,3x3), split-K)");
         return fd_launch_splitk_reduce(o, (const float*)p->workspace, nslice, ldw, slab, stream);
     }
@@ -565,21 +748,33 @@ int fd_launch_conv_wino4(const fd_conv_params* p, hipStream_t stream) {
             }
             if (FILE* f = fopen(path, "a")) {
                 const double u = 0.01 / (live ? live : 1);     // 100 MHz ticks -> us, mean over the live workgroups
-                fprintf(f, "w4ts Cin %d Cout %d T %d wgs %zu live %zu dbg %d | span_us %.2f | per-wg us: setup %.2f prologue %.2f loop %.2f epilogue %.2f total %.2f max %.2f\n",
-                        a.Cin, a.Cout, a.T, n / 8, live, a.dbg, (double)(last - first) * 0.01, ph[0] * u, ph[1] * u, ph[2] * u, ph[3] * u, tot * u, totmax * 0.01);
+                double wait = 0, waitmax = 0, segs = 0;
+                for (size_t b = 0; b < n / 8; ++b) { wait += (double)h[b * 8 + 5]; if ((double)h[b * 8 + 5] > waitmax) waitmax = (double)h[b * 8 + 5]; segs += (double)h[b * 8 + 6]; }
+                fprintf(f, "w4ts Cin %d Cout %d T %d wgs %zu live %zu dbg %d sk %d | span_us %.2f | per-wg us (sum over %.2f segments): setup %.2f prologue %.2f loop %.2f epilogue+rest %.2f total %.2f max %.2f | flag wait %.2f max %.2f\n",
+                        a.Cin, a.Cout, a.T, n / 8, live, a.dbg, a.wpx * 8, (double)(last - first) * 0.01, segs / (live ? live : 1), ph[0] * u, ph[1] * u, ph[2] * u, ph[3] * u, tot * u, totmax * 0.01, wait * u, waitmax * 0.01);
                 fclose(f);
             }
         }
     } ts_dump{ts_path, ts_dev, ts_n, stream, a};
 #endif
-    if (p->tag == 1) {
+    if (p->sk_wgs > 0) {
+        if (p->tag == 1) {
+            static std::atomic<unsigned> k1{0};
+            fd_set_max_lds_once(k1, reinterpret_cast<const void*>(conv3x3_wino4_kernel<1, true>), lds);
+            hipLaunchKernelGGL((conv3x3_wino4_kernel<1, true>), grid, dim3(512), lds, stream, a);
+        } else {
+            static std::atomic<unsigned> k0{0};
+            fd_set_max_lds_once(k0, reinterpret_cast<const void*>(conv3x3_wino4_kernel<0, true>), lds);
+            hipLaunchKernelGGL((conv3x3_wino4_kernel<0, true>), grid, dim3(512), lds, stream, a);
+        }
+    } else if (p->tag == 1) {
         static std::atomic<unsigned> m1{0};
-        fd_set_max_lds_once(m1, reinterpret_cast<const void*>(conv3x3_wino4_kernel<1>), lds);
-        hipLaunchKernelGGL(conv3x3_wino4_kernel<1>, grid, dim3(512), lds, stream, a);
+        fd_set_max_lds_once(m1, reinterpret_cast<const void*>(conv3x3_wino4_kernel<1, false>), lds);
+        hipLaunchKernelGGL((conv3x3_wino4_kernel<1, false>), grid, dim3(512), lds, stream, a);
     } else {
         static std::atomic<unsigned> m0{0};
-        fd_set_max_lds_once(m0, reinterpret_cast<const void*>(conv3x3_wino4_kernel<0>), lds);
-        hipLaunchKernelGGL(conv3x3_wino4_kernel<0>, grid, dim3(512), lds, stream, a);
+        fd_set_max_lds_once(m0, reinterpret_cast<const void*>(conv3x3_wino4_kernel<0, false>), lds);
+        hipLaunchKernelGGL((conv3x3_wino4_kernel<0, false>), grid, dim3(512), lds, stream, a);
     }
     FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (Winograd F(4x4,3x3))");
     return FD_OK;

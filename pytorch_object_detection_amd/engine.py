@@ -276,7 +276,18 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
                          gate=gate, w_frag=wfrag,
                          gate_b=gate_b, gate_act=gate_act, gn_stats=gn_stats, gn_groups=gn_groups, x2=x2, x2_stride=x2_stride, x2_hw=x2_hw, res_up=res_up)
     tail = None
-    if tag == 1 and wino4 and wino_ks <= 1 and TOWER_TAIL_SPLIT:
+    sk = 0
+    if wino4 and wino_ks <= 1 and ops.W4_SK:
+        # the persistent form of the F(4x4) launch (work queue per XCD, the last partial round of items cut into pieces) where it was measured faster
+        if getattr(plan, "sk_ws", None) is None:
+            plan.sk_ws = ops.sk_workspace(256, dev)         # one per plan: the launches of a plan are stream-ordered; every lane of the pipeline has its own plan
+        hw_ = "+".join(f"{h}x{w}" for h, w in segs.level_hw())
+        sk = ops.wino4_sk_choice(call, f"B{segs.batch}|{hw_}|{Cin}>{co}|d{dil}|res{int(res is not None)}", plan.sk_ws)
+        if sk:
+            call = ops.conv_sk(call, sk, plan.sk_ws)
+            plan.sk_of = getattr(plan, "sk_of", {})
+            plan.sk_of[name] = sk
+    if tag == 1 and wino4 and wino_ks <= 1 and TOWER_TAIL_SPLIT and not sk:
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         total, live = ops.conv_workgroups(call)
         full = total // ncu * ncu          # (one workgroup of that kernel owns a CU; ncu % 8 == 0: the slice starts on an XCD boundary)

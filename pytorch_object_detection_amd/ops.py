@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import sys
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -197,7 +198,8 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
               out_hw: Optional[Tuple[int, int]] = None, scatter: Optional[Tuple[int, int, int, int, int, int]] = None,
               gate: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None, gn_stats: Optional[torch.Tensor] = None,
               gn_groups: int = 0, gate_b: Optional[torch.Tensor] = None, gate_act: int = ACT_NONE,
-              x2: Optional[Rows] = None, x2_stride: int = 1, x2_hw: Optional[Tuple[int, int]] = None, res_up: bool = False) -> Callable[[], None]:
+              x2: Optional[Rows] = None, x2_stride: int = 1, x2_hw: Optional[Tuple[int, int]] = None, res_up: bool = False,
+              sk_wgs: int = 0) -> Callable[[], None]:
     """Build the argument block once; the returned closure launches fd_conv2d_nhwc_f32 on the current stream.
     w_frag: the same weights in FD_TILE_WAVE64's fragment order (pack_conv_weight_wave), which makes that tile selectable."""
     _need_gpu(w_packed, scale, shift)
@@ -244,6 +246,8 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     if workspace is not None:
         _need_gpu(workspace)
         p.workspace, p.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    if sk_wgs:                       # FD_TILE_WINOGRAD4 as a persistent stream-K grid of sk_wgs workgroups; workspace = sk_workspace(sk_wgs) (zeroed flags)
+        p.sk_wgs = sk_wgs
     if seg_param is not None:
         for i, v in enumerate(seg_param):
             p.seg_param[i] = float(v)
@@ -257,6 +261,74 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
 
     run.params = p  # type: ignore[attr-defined]   (autotuning rewrites p.tile in place)
     return run
+
+
+def sk_workspace(sk_wgs: int, device) -> torch.Tensor:
+    """Workspace of the persistent stream-K form of an F(4x4) launch (fd_conv_params.sk_wgs): flags (zero, and left zero by every launch) + one 128 KB slot per
+    workgroup.  One per concurrently running launch; launches on one stream may share it."""
+    n = _lib.lib().fd_conv_sk_workspace_bytes(sk_wgs)
+    if n < 0:
+        raise FdError(f"fd_conv_sk_workspace_bytes({sk_wgs}): sk_wgs must be a multiple of 8 in 8 .. 1024")
+    ws = torch.empty((n + 3) // 4, dtype=torch.float32, device=device)
+    ws[:2048].zero_()            # the fixed 8 KB header
+    return ws
+
+
+# F(4x4) launches as a persistent grid with a work queue per XCD (fd_conv_params.sk_wgs): FD_W4_SK=0 keeps every layer on the plain launch
+W4_SK = os.environ.get("FD_W4_SK", "1") != "0"
+
+
+def conv_sk(run, sk_wgs: int, ws: torch.Tensor) -> Callable[[], None]:
+    """conv_call()'s F(4x4) launch in its persistent form: sk_wgs workgroups, workspace ws = sk_workspace(>= sk_wgs)."""
+    q = _lib.ConvParams()
+    C.memmove(C.byref(q), C.byref(run.params), C.sizeof(q))
+    q.sk_wgs, q.wg_first, q.wg_count = sk_wgs, 0, 0
+    q.workspace, q.workspace_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+    fn = _lib.lib().fd_conv2d_nhwc_f32
+    ref = C.byref(q)
+
+    def run_sk(_keep=(run, q, ws)):
+        check(fn(ref, _stream()), "fd_conv2d_nhwc_f32")
+
+    run_sk.params = q  # type: ignore[attr-defined]
+    return run_sk
+
+
+def wino4_sk_choice(run, key: str, ws: torch.Tensor, reps: int = 5) -> int:
+    """Plain launch (0) or the persistent form with 240 / 256 workgroups for one F(4x4) layer: the committed table first ("w4sk|" keys of
+    tuned/gfx950_tiles.json, measured on MI355X); a miss is timed on the spot under FD_AUTOTUNE, else stays plain.  The persistent form wins where the
+    plain grid ends in a mostly idle round of workgroups and the chunk loop is long enough to carry the pieces' fixed cost (cls_logits, the dilated
+    HisBlock conv4, the head tower); elsewhere it costs ~2 % (an extra barrier and a queue claim per item)."""
+    if not W4_SK:
+        return 0
+    table = _tune_table()
+    key = "w4sk|" + key
+    if _TUNE_MODE != "force" and key in table:
+        return int(table[key])
+    if _TUNE_MODE == "0":
+        return 0
+    best, best_t = 0, float("inf")
+    trace = os.environ.get("FD_W4_SK_TRACE")
+    for wgs in (0, 256, 240):
+        call = conv_sk(run, wgs, ws) if wgs else run
+        if trace:
+            p_ = run.params
+            print(f"[w4sk] {key} sk_wgs {wgs} x_cs {p_.x_cs} x_co {p_.x_co} y_cs {p_.y_cs} y_co {p_.y_co} res {bool(p_.res)} act {p_.act} tag {p_.tag} ksplit {p_.ksplit} "
+                  f"wg_count {p_.wg_count}", file=sys.stderr, flush=True)
+            call()
+            torch.cuda.synchronize()
+            print("[w4sk]   ok", file=sys.stderr, flush=True)
+        try:
+            call()
+        except FdError as e:
+            if e.rc != _lib.E_UNSUPPORTED:
+                raise
+            continue
+        t = min(_time_launches(call, reps, False) for _ in range(3))
+        if t < best_t * 0.98:
+            best, best_t = wgs, t
+    table[key] = best
+    return best
 
 
 def conv_workgroups(run) -> Tuple[int, int]:

@@ -321,3 +321,59 @@ def test_fderror_carries_the_numeric_return_code():
         _lib.check(_lib.E_UNSUPPORTED, "probe")
     assert ei.value.rc == _lib.E_UNSUPPORTED == -2 and "(-2)" in str(ei.value)
     assert _lib.FdError("host-side").rc is None
+
+
+def test_bench_roofline_object_describes_the_marked_launch():
+    """bench.tower_roofline reads tile / FLOPs / Winograd divisor from the plan step the 'head.tower3x3' mark actually covers (FCOS names
+    its fused tower launch head.tower0: looking up a fixed name found nothing, took tile 0 = "direct" and printed frac 2.2 for an F(4x4) launch), reports the
+    whole layer beside a split grid's main launch, and attaches PMC traffic only to the workload the PMC passes were made for."""
+    import types
+    import bench
+    rows, Cin, Cout = 16 * 8525, 256, 512
+    alg = 2 * rows * Cout * Cin * 9
+
+    def plan(name, tile, div, share=1.0, tail=False, sk=0):
+        p = types.SimpleNamespace()
+        p.names = ["x.pre", name] + ([name + ".tail"] if tail else []) + ["x.post"]
+        p.marks = {"head.tower3x3": (1, 2)}
+        p.tiles = {name: tile}
+        p.step_flops = {1: int(alg * share)}
+        p.step_info = {1: {"Cin": Cin, "Cout": Cout, "mfma_div": div, "family": "winograd3x3"}}
+        p.segs = types.SimpleNamespace(nseg=5, rows=rows)
+        if tail:
+            p.step_flops[2] = alg - int(alg * share)
+            p.step_info[2] = dict(p.step_info[1])
+            p.tail_of = {name: {"workgroups": 2176, "main": 2048, "live": 2152, "main_share": share}}
+        if sk:
+            p.sk_of = {name: sk}
+        return p
+
+    wl = {"model": "FCOS", "batch": 16, "height": 640, "width": 640}
+    ms = 0.9
+    r = bench.tower_roofline(plan("head.tower0", 16, 4.0), ms, wl, layer_ms=ms)
+    assert r["flops_per_launch"] == alg // 4 and r["algorithmic_flops_per_launch"] == alg
+    assert abs(r["frac"] - alg / 4 / (ms * 1e-3) / 1e12 / bench.PEAK_F32_MFMA_TFLOPS) < 1e-3 and r["frac"] < 1.0
+    assert "F(4x4" in r["kernel"] and "head.tower0" in r["kernel"] and r["layer_frac"] == r["frac"]
+    assert r["traffic"] is None and r["traffic_source"] is None          # another model than the PMC passes' -> no traffic figure
+    # a direct-convolution launch: executed = algorithmic
+    r = bench.tower_roofline(plan("head.tower0", 7, 1.0), 4 * ms, wl)
+    assert r["flops_per_launch"] == alg and "direct" in r["flops_basis"] and "layer_frac" not in r
+    # the split grid: frac describes the main launch (pro-rata FLOPs), layer_frac both launches with the full FLOPs
+    share = 2040 / 2152
+    p = plan("head.tower3x3", 16, 4.0, share=share, tail=True)
+    med = [0.1, 0.83, 0.11, 0.2]
+    layer = bench.tower_layer_ms(p, med)
+    assert abs(layer - 0.94) < 1e-9
+    r = bench.tower_roofline(p, 0.83, dict(bench.PMC_WORKLOAD), layer_ms=layer)
+    assert abs(r["frac"] - alg * share / 4 / 0.83e-3 / 1e12 / bench.PEAK_F32_MFMA_TFLOPS) < 1e-3
+    assert abs(r["layer_frac"] - alg / 4 / 0.94e-3 / 1e12 / bench.PEAK_F32_MFMA_TFLOPS) < 1e-3 and r["layer_frac"] < r["frac"]
+    assert "two launches" in r["launch"]
+    r = bench.tower_roofline(plan("head.tower3x3", 16, 4.0, sk=256), ms, dict(bench.PMC_WORKLOAD), layer_ms=ms)
+    assert "persistent" in r["launch"] and "SK" in r["kernel"]
+    # traffic: only for the PMC passes' own workload, and only for the kernel family they saw
+    t, src = bench.pmc_traffic(dict(bench.PMC_WORKLOAD))
+    rec = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    assert (t is not None) == os.path.exists(rec)
+    for other in ({"model": "FCOS-B3"}, {"batch": 1}, {"height": 512, "width": 512}):
+        assert bench.pmc_traffic({**bench.PMC_WORKLOAD, **other}) == (None, None)
+    assert bench.pmc_traffic(dict(bench.PMC_WORKLOAD), "igemm") == (None, None)

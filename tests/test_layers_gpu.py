@@ -1527,6 +1527,80 @@ def test_conv3x3_winograd_f4x4_as_slices_of_its_grid(case):
         ops.conv_wg_slice(direct, 0, 8)()
 
 
+@pytest.mark.parametrize("case", [(64, 128, [(40, 40), (20, 20), (10, 10), (5, 5), (3, 3)], 3, 1, 64), (32, 80, [(48, 36)], 2, 2, 32), (64, 64, [(24, 20)], 1, 1, 8),
+                                  (256, 80, [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)], 4, 1, 256), (128, 128, [(80, 80)], 16, 1, 256), (64, 192, [(32, 32)], 2, 2, 120), (64, 64, [(64, 64)], 33, 1, 256), (64, 64, [(64, 64)], 32, 1, 256)])
+def test_conv3x3_winograd_f4x4_as_a_persistent_stream_k_grid(case):
+    """fd_conv_params.sk_wgs: the F(4x4) layer as a persistent grid -- whole rounds of items round-robin, the last (partial) round's (tile block, chunk) units shared
+    evenly by the workgroups (the head tower and cls_logits of HISFcos.py:196-209 on 256 CUs without a last, mostly idle round; cases: pyramids, dilation 2, XCDs without
+    tiles, a remainder with fewer units than workgroups, no remainder at all).  Items that no range boundary cuts must equal the plain launch BIT FOR BIT; a cut item is
+    the sum of its parts' output transforms (fixed order): within the F(4x4) bound of the fp64 reference and of the plain launch, identical from run to run; the flags are
+    zero again after every launch (the workspace is reused without clearing); channel views with NaN neighbours; bad grids / workspaces are clean errors."""
+    from pytorch_object_detection_amd import _lib
+    Cin, Cout, hw, B, dil, wgs = case
+    gen = torch.Generator().manual_seed(Cin + Cout + len(hw) + dil)
+    segs = Segs.make(B, hw)
+    x = torch.randn(segs.rows, Cin, generator=gen)
+    wt = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    sc, bias = (torch.rand(Cout, generator=gen) + 0.5).to(DEV), torch.randn(Cout, generator=gen).to(DEV)
+    res = torch.randn(segs.rows, Cout, generator=gen).to(DEV)
+    wp = ops.pack_conv_weight_wino4(wt.to(DEV))
+    xb = torch.full((segs.rows, Cin + 8), float("nan"), device=DEV)
+    xb[:, 4:4 + Cin] = x.to(DEV)
+    kw = dict(Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, scale=sc, shift=bias, res=ops.Rows(res), act=ACT_RELU, tile=_lib.WINO4_TILE)
+    y0 = ops.new_rows(segs.rows, Cout, DEV)
+    ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, y0, **kw)()
+    ws = ops.sk_workspace(wgs, DEV)
+    yb = torch.full((segs.rows, Cout + 8), float("nan"), device=DEV)
+    run = ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(yb, 4, Cout), sk_wgs=wgs, workspace=ws, **kw)
+    run()
+    torch.cuda.synchronize()
+    assert int(ws[:2048].view(torch.int32).abs().sum()) == 0, "a slot flag / queue head was left non-zero"
+    if wgs > 16:                   # launches with different grids share one workspace (a fixed header): a smaller grid in between must not disturb the next launch
+        ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(yb, 4, Cout), sk_wgs=wgs - 16, workspace=ws, **kw)()
+        yb.fill_(float("nan"))
+        run()
+        torch.cuda.synchronize()
+        assert int(ws[:2048].view(torch.int32).abs().sum()) == 0
+    assert torch.isnan(yb[:, :4]).all() and torch.isnan(yb[:, 4 + Cout:]).all(), "wrote outside its channel view"
+    got = yb[:, 4:4 + Cout].clone()
+    assert not torch.isnan(got).any(), "an output pixel was never written"
+    same = (got == y0.tensor()).all(1)
+    scale = float(y0.tensor().abs().max()) + 1.0
+    assert float((got - y0.tensor()).abs().max()) < 1e-5 * scale            # cut items: another summation order of the same products
+    # expected cut structure: per XCD, the interior range boundaries that do not fall on an item boundary cut one item each
+    NC, T = Cin // 8, sum(B * dil * dil * (((h + dil - 1) // dil + 3) // 4) * (((w + dil - 1) // dil + 3) // 4) for h, w in hw)
+    mtiles, ntiles = (T + 31) // 32, (Cout + 63) // 64
+    mt_per, wpx, cut_items = (mtiles + 7) // 8, wgs // 8, 0
+    for xcd in range(8):           # per XCD (mtiles / 8 M tiles or one more): only the items % wpx last items of its queue may be cut into pieces
+        cnt = mtiles // 8 + (1 if xcd < mtiles % 8 else 0)
+        cut_items += cnt * ntiles % wpx
+    rows_per_item_max = 32 * 16
+    assert int((~same).sum()) <= cut_items * rows_per_item_max, (int((~same).sum()), cut_items)
+    if cut_items == 0:
+        assert bool(same.all())
+    # per-level fp64 reference
+    for i, (h, w) in enumerate(hw):
+        lo, hi = segs.m_start[i], segs.m_start[i + 1]
+        xi = x[lo:hi].reshape(B, h, w, Cin).permute(0, 3, 1, 2).double()
+        r = F.conv2d(xi, wt.double(), None, 1, dil, dil) * sc.cpu().double()[None, :, None, None] + bias.cpu().double()[None, :, None, None]
+        r = F.relu(r + res[lo:hi].cpu().double().reshape(B, h, w, Cout).permute(0, 3, 1, 2)).float()
+        g = got[lo:hi].cpu().reshape(B, h, w, Cout).permute(0, 3, 1, 2)
+        s_ = float(r.abs().max()) + 1.0
+        assert float((g - r).abs().max()) < 4e-5 * s_
+    for _ in range(3):                         # same workspace, no clearing: deterministic
+        yb.fill_(float("nan"))
+        run()
+        assert torch.equal(yb[:, 4:4 + Cout], got)
+    for bad in (dict(sk_wgs=12, workspace=ws), dict(sk_wgs=wgs, workspace=None), dict(sk_wgs=wgs, workspace=ws[:1024]), dict(sk_wgs=wgs, workspace=ws, ksplit=2),
+                dict(sk_wgs=2048, workspace=ws)):
+        with pytest.raises(Exception, match="sk_wgs"):
+            ops.conv_call(ops.Rows(xb, 4, Cin), segs, wp, ops.Rows(yb, 4, Cout), **kw, **bad)()
+    direct = ops.conv_call(ops.Rows(xb, 4, Cin), segs, ops.pack_conv_weight(wt.to(DEV)), ops.Rows(yb, 4, Cout), Cin=Cin, Cout=Cout, k=3, pad=dil, dil=dil, tile=4, sk_wgs=8,
+                           workspace=ws)
+    with pytest.raises(Exception, match="WINOGRAD4"):
+        direct()
+
+
 @pytest.mark.parametrize("case", [(1024, 256, 2, 40, 40, 9), (512, 256, 1, 80, 80, 8), (64, 96, 3, 6, 10, 4), (128, 64, 2, 14, 2, 0)])
 def test_conv1x1_with_the_upsampled_coarser_level_added_in_its_epilogue(case):
     """fd_conv_params.res_mode 2: an FPN lateral -- relu(bn(conv1x1(c))) + Upsample(x2, nearest)(coarser) (HISFcos.py:155-165; without the activation: Fcos.py:77-91)
