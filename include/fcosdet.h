@@ -205,7 +205,11 @@ typedef struct fd_conv_params {
      * enough for the largest) ZERO before the first launch (every launch leaves them zero); one workspace per concurrently running launch.  No split-K,
      * no wg_first / wg_count.  0: off. */
     int32_t sk_wgs;
-    int32_t reserved1;
+    /* FD_PREC_F16 only: AMP activations stored as f16 in HBM (train.py:33,175-181 trains under torch.autocast: its convolutions read and write fp16 tensors).
+     * Bit 0: `x` holds _Float16 elements, bit 1: `y`, bit 2: `res` (added or used as ReLU mask).  Channel strides / offsets stay in ELEMENTS; the loader fetches a
+     * lane's four channels as 8 bytes and stores them to LDS unconverted, the epilogue rounds the fp32 accumulator result once (round to nearest even).  Plain
+     * implicit-GEMM tiles (incl. split-K and the output scatter of strided data gradients); no gate / gn_stats / x2 / Winograd / narrow / wave / patch tiles.  0: fp32 maps. */
+    int32_t io_f16;
 } fd_conv_params;
 /* Workspace bytes of the persistent stream-K form (flags + one 128 KB slot per workgroup); -1: sk_wgs not a multiple of 8 in 8 .. 1024. */
 int64_t fd_conv_sk_workspace_bytes(int32_t sk_wgs);
@@ -278,7 +282,8 @@ typedef struct fd_conv_wgrad_params {
     fd_segs in;      /* forward INPUT geometry */
     int32_t precision; /* FD_PREC_F32 (exact, default) | FD_PREC_F16: x and dy rounded to f16 on their way to LDS, v_mfma_f32_32x32x16_f16, fp32
                           accumulation -- the weight gradient of a convolution under torch.autocast(float16) (train.py:175-181) */
-    int32_t reserved;
+    int32_t io_f16;    /* FD_PREC_F16 with Cout > 32 only: bit 0: `x` holds _Float16 elements, bit 1: `dy` (AMP activations / gradients stored as f16: fetched as 8 bytes
+                          per lane and staged without conversion; strides / offsets stay in elements).  0: fp32 maps */
 } fd_conv_wgrad_params;
 
 int64_t fd_conv_wgrad_workspace_bytes(int64_t out_rows, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
@@ -450,6 +455,10 @@ int32_t fd_act_nhwc(const float* x, int32_t x_cs, int32_t x_co, float* y, int32_
                     int32_t act, float param, fd_stream_t stream);
 int32_t fd_act_bwd_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* dy, int32_t dy_cs, int32_t dy_co, float* dx,
                         int32_t dx_cs, int32_t dx_co, int64_t rows, int32_t C, int32_t act, float param, fd_stream_t stream);
+/* The same pass over f16 maps (x, dy, dx hold _Float16 elements; 8-byte aligned views): AMP activations / gradients stored as f16 (train.py:175-181);
+ * the derivative is evaluated in fp32 and the product rounded once. */
+int32_t fd_act_bwd_nhwc_h(const void* x, int32_t x_cs, int32_t x_co, const void* dy, int32_t dy_cs, int32_t dy_co, void* dx,
+                          int32_t dx_cs, int32_t dx_co, int64_t rows, int32_t C, int32_t act, float param, fd_stream_t stream);
 
 /* Backward of fd_maxpool_nhwc (x = the forward input): dx[p] = sum of dy over the windows whose first maximum is p (the
  * argmax torch's max_pool2d keeps).  Gather form, deterministic.  The fused "+ add" passes dy through unchanged.

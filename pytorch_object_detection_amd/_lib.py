@@ -88,7 +88,7 @@ class ConvParams(C.Structure):
                 ("gate", C.c_void_p), ("gate_cs", C.c_int32), ("reserved0", C.c_int32), ("w_frag", C.c_void_p),
                 ("gn_stats", C.c_void_p), ("gn_groups", C.c_int32), ("gate_act", C.c_int32), ("gate_b", C.c_void_p),
                 ("x2", C.c_void_p), ("x2_cs", C.c_int32), ("x2_co", C.c_int32), ("x2_Cin", C.c_int32), ("x2_stride", C.c_int32), ("x2_H", C.c_int32),
-                ("x2_W", C.c_int32), ("wg_first", C.c_int32), ("wg_count", C.c_int32), ("sk_wgs", C.c_int32), ("reserved1", C.c_int32)]
+                ("x2_W", C.c_int32), ("wg_first", C.c_int32), ("wg_count", C.c_int32), ("sk_wgs", C.c_int32), ("io_f16", C.c_int32)]
 
 
 class PackJob(C.Structure):
@@ -102,7 +102,7 @@ class WgradParams(C.Structure):
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("dil", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("nsplit", C.c_int32), ("layout", C.c_int32),
-                ("scale", C.c_void_p), ("segs", Segs), ("precision", C.c_int32), ("reserved", C.c_int32)]
+                ("scale", C.c_void_p), ("segs", Segs), ("precision", C.c_int32), ("io_f16", C.c_int32)]
 
 
 _lib = None
@@ -160,6 +160,7 @@ _SIGS = {
     "fd_se_scale_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "fd_act_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _L, _I, _I, _F, _P]),
     "fd_act_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _L, _I, _I, _F, _P]),
+    "fd_act_bwd_nhwc_h": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _L, _I, _I, _F, _P]),
     "fd_maxpool_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fd_upsample2x_bwd_nhwc": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fd_batchnorm_update_running": (_I, [_P, _L, _I, _F, _F, _P, _P, _P]),

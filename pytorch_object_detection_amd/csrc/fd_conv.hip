@@ -56,6 +56,9 @@ void conv_igemm_kernel(ConvArgs a) {
     // adds, two compares and a select.
     const int lrow = tid >> 3, chunk = tid & 7;
     constexpr unsigned OOB = 0xC0000000u;       // >= any buffer size (host checks < 3 GiB): reads as zero
+    // H1 with a.x16: the input map holds f16 elements (AMP activations stored as f16): byte offsets are element offsets << 1, a lane fetches its four channels as
+    // 8 bytes and they go to LDS as they are -- half the bytes, no conversion.  `esh` is uniform; in every other kernel it is the constant 2.
+    const int esh = (H1 && a.x16) ? 1 : 2;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, (int)a.w_bytes, 0x00020000);
     unsigned a_off[AP];                         // byte offset of tap (0, 0), channel chunk 0 (may wrap below zero)
@@ -76,13 +79,13 @@ void conv_igemm_kernel(ConvArgs a) {
         }
         if constexpr (GEMM) {   // compiled for 1x1 unpadded layers with Cin % 32 == 0: a row has ONE input address, the K-tile goes in the scalar offset
             if (a.is_gemm) {    // stride 1: the input row is the output row
-                a_off[i] = (m < a.M) ? ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) * 4u : OOB;
+                a_off[i] = (m < a.M) ? ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) << esh : OOB;
                 a_wcs[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = 1; a_W[i] = 1;
                 continue;
             }                   // strided 1x1 (the ResNet downsample convs): the decode below gives the row's address once; rows past M read zeros
         }
         if (a.is_gemm) {  // 1x1, stride 1, no padding: the input row IS the output row (no divisions)
-            a_off[i] = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) * 4u;
+            a_off[i] = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 4)) << esh;
             a_wcs[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = (m < a.M) ? 1 : 0; a_W[i] = 1;
             continue;
         }
@@ -100,9 +103,9 @@ void conv_igemm_kernel(ConvArgs a) {
         a_wi0[i] = wo * a.stride - a.pad;
         a_H[i] = (m < a.M) ? H : 0;  // H = 0 makes every tap invalid for rows past M
         a_W[i] = W;
-        a_wcs[i] = W * a.x_cs * 4;   // bytes per input image row
+        a_wcs[i] = (W * a.x_cs) << esh;   // bytes per input image row
         a_off[i] = ((unsigned)(a.m_in[s] + n * H * W + a_hi0[i] * W + a_wi0[i]) * (unsigned)a.x_cs +
-                    (unsigned)(a.x_co + chunk * 4)) * 4u;
+                    (unsigned)(a.x_co + chunk * 4)) << esh;
         if constexpr (GEMM) { if (m >= a.M) a_off[i] = OOB; }
     }
     // DUAL: the second source's row addresses (single level; output pixel (n, i, j) reads x2[n, s * i, s * j]) and its buffer descriptor
@@ -127,6 +130,15 @@ void conv_igemm_kernel(ConvArgs a) {
     }
 
     float4 ra[AP], rb[BP], rg[GATE ? AP : 1], rgb[GATE ? AP : 1];
+    // one lane's four input channels: 16 bytes of fp32 -- or (H1, a.x16) 8 bytes of f16, kept as bits in .x / .y
+    auto ld_x = [&](unsigned voff, int soff) -> float4 {
+        if (H1 && a.x16) {
+            // (the WHOLE result is bit-cast: indexing the builtin's vector element-wise made the compiler fetch one dword and use it twice)
+            const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)voff, soff, 0));
+            return make_float4(v.x, v.y, 0.f, 0.f);
+        }
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)voff, soff, 0));
+    };
     // k-tile order = (32-channel chunk, tap): the 9 taps of one channel chunk are consecutive, so the shifted re-reads
     // of the same input pixels hit L1/L2 instead of travelling from the Infinity Cache.  load_tile() is called with
     // consecutive kt, so (chunk, filter row, filter column) advance as counters (no divisions in the K loop).
@@ -134,6 +146,7 @@ void conv_igemm_kernel(ConvArgs a) {
     auto load_tile = [&](int kt) {
         if constexpr (GEMM) {      // no per-row arithmetic: lane offsets fixed, K-tile kt = 128 bytes further along every row (scalar offset)
             const int kb = kt * 128;
+            const int kbx = kt << (5 + esh);            // the input's K-tile step in bytes (64 for an f16 map)
             if (GATE) {
 #pragma unroll
                 for (int i = 0; i < AP; ++i) {
@@ -147,7 +160,7 @@ void conv_igemm_kernel(ConvArgs a) {
                 for (int i = 0; i < AP; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x2rsrc, (int)a2_off[DUAL ? i : 0], kb2, 0));
             } else {
 #pragma unroll
-                for (int i = 0; i < AP; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)a_off[i], kb, 0));
+                for (int i = 0; i < AP; ++i) ra[i] = ld_x(a_off[i], kbx);
             }
 #pragma unroll
             for (int j = 0; j < BP; ++j) rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)b_off[j], kb, 0));
@@ -161,7 +174,7 @@ void conv_igemm_kernel(ConvArgs a) {
         else {
             dr = ld_r * a.dil;
             dq = ld_q * a.dil;
-            dbytes = (unsigned)(dq * a.x_cs + ld_cc * 32) * 4u;
+            dbytes = (unsigned)(dq * a.x_cs + ld_cc * 32) << esh;
             c_ok = ld_cc * 32 + chunk * 4 < a.Cin;
             if (GATE) {
 #pragma unroll
@@ -178,7 +191,7 @@ void conv_igemm_kernel(ConvArgs a) {
             bool ok = (unsigned)hi < (unsigned)a_H[i] && (unsigned)wi < (unsigned)a_W[i] && c_ok;
             if (STEM) ok = ok && (chunk < 7);
             const unsigned off = a_off[i] + (unsigned)__mul24(dr, a_wcs[i]) + dbytes;
-            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(ok ? off : OOB), 0, 0));
+            ra[i] = ld_x(ok ? off : OOB, 0);
         }
         const unsigned kb = (unsigned)kt * 128u;
 #pragma unroll
@@ -195,7 +208,8 @@ void conv_igemm_kernel(ConvArgs a) {
             for (int i = 0; i < AP; ++i) {
                 const int row = lrow + RPP * i;
                 const f32x4 v = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-                const h4 hi = __builtin_convertvector(v, h4);                       // round to nearest
+                h4 hi = __builtin_convertvector(v, h4);                             // round to nearest
+                if (H1 && a.x16) hi = fd_h4_bits(ra[i].x, ra[i].y);      // (uniform) already f16: the bits as loaded
                 const int off = row * 32 + ((((chunk >> 1) ^ ((row >> 2) & 3)) << 3) | ((chunk & 1) << 2));
                 *reinterpret_cast<h4*>(Ahi + off) = hi;
                 if constexpr (!H1) {
@@ -359,10 +373,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, const fl
             float r = o[e] * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
             const size_t mo = (size_t)out_row(a, (int)m);
             if (a.res) {
-                const float rv = a.res[mo * a.res_cs + a.res_co + n];
+                const float rv = a.res16 ? (float)reinterpret_cast<const _Float16*>(a.res)[mo * a.res_cs + a.res_co + n] : a.res[mo * a.res_cs + a.res_co + n];
                 r = a.res_mask ? (rv > 0.f ? r : 0.f) : r + rv;
             }
-            a.y[mo * a.y_cs + a.y_co + n] = fd_act(r, n >= a.act_c0 ? a.act : FD_ACT_NONE, prm);
+            const float ov = fd_act(r, n >= a.act_c0 ? a.act : FD_ACT_NONE, prm);
+            if (a.y16) reinterpret_cast<_Float16*>(a.y)[mo * a.y_cs + a.y_co + n] = (_Float16)ov;
+            else a.y[mo * a.y_cs + a.y_co + n] = ov;
         }
     }
 }
@@ -453,11 +469,14 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
     }
     FD_REQUIRE(p->wg_count <= 0 || p->tile == FD_TILE_WINOGRAD4, FD_E_UNSUPPORTED, "fd_conv2d: wg_first / wg_count (a slice of the layer's grid) exist for FD_TILE_WINOGRAD4 only");
     FD_REQUIRE(p->sk_wgs <= 0 || p->tile == FD_TILE_WINOGRAD4, FD_E_UNSUPPORTED, "fd_conv2d: sk_wgs (the persistent stream-K form) exists for FD_TILE_WINOGRAD4 only");
+    FD_REQUIRE(!p->io_f16 || (p->tile != FD_TILE_WINOGRAD && p->tile != FD_TILE_WINOGRAD4 && p->tile != FD_TILE_NARROW), FD_E_UNSUPPORTED,
+               "fd_conv2d: io_f16 (f16 activation maps) is built for the FD_PREC_F16 implicit-GEMM tiles only");
     if (p->tile == FD_TILE_WINOGRAD) return fd_launch_conv_wino(p, stream);   // own argument block, own weight packing
     if (p->tile == FD_TILE_WINOGRAD4) return fd_launch_conv_wino4(p, stream);
     if (p->tile == FD_TILE_NARROW) return fd_launch_conv_narrow(p, stream);
 
     ConvArgs a;
+    a.x16 = a.y16 = a.res16 = 0;
     a.x = p->x; a.w = p->w; a.scale = p->scale; a.shift = p->shift; a.res = p->res; a.y = p->y;
     a.x_cs = p->x_cs; a.x_co = p->x_co; a.res_cs = p->res_cs; a.res_co = p->res_co; a.y_cs = p->y_cs; a.y_co = p->y_co;
     a.Cin = p->Cin; a.Cout = p->Cout; a.KW = p->KW; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;
@@ -538,6 +557,14 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
             default: fd_set_error("fd_conv2d: `x2` is built for tiles 64x64, 128x64_SB, 64x128_SB, 128x128_SB (got %d)", p->tile); return FD_E_UNSUPPORTED;
         }
     }
+    if (p->io_f16) {     // AMP activations stored as f16 (train.py:175-181 autocast): the single-plane f16 kernels read / write them directly
+        FD_REQUIRE(p->precision == FD_PREC_F16 && !stem && !p->gate && !p->gn_stats && !p->x2 && (p->io_f16 & ~7) == 0 && p->tile != FD_TILE_WAVE64 && p->tile != FD_TILE_128x128_PATCH,
+                   FD_E_UNSUPPORTED, "fd_conv2d: io_f16 (f16 activation maps) needs FD_PREC_F16 on the plain conv tiles, no gate / gn_stats / x2");
+        FD_REQUIRE(a.vec_epi || !(p->io_f16 & 6), FD_E_UNSUPPORTED, "fd_conv2d: f16 output / residual maps need 4-channel aligned views (Cout, y_cs, y_co, res_cs, res_co multiples of 4)");
+        FD_REQUIRE(!(p->io_f16 & 4) || p->res, FD_E_INVAL, "fd_conv2d: io_f16 names an f16 residual but res is NULL");
+        a.x16 = p->io_f16 & 1; a.y16 = (p->io_f16 >> 1) & 1; a.res16 = (p->io_f16 >> 2) & 1;
+        if (a.x16) a.x_bytes = (unsigned)((long)p->in.m_start[p->in.nseg] * p->x_cs * 2);
+    }
     a.gate = nullptr; a.gate_cs = 0; a.gate_hw = 1; a.gate_b = nullptr; a.gate_act = FD_ACT_NONE; a.gate_batch = p->in.batch;
     a.gn_stats = nullptr; a.gn_G = 1; a.gn_cg = 4;
     if (p->gn_stats) {   // row-group statistics of the stored output (GroupNorm fused into the producer)
@@ -599,6 +626,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
         a.kt_per = (a.KT + ksplit - 1) / ksplit;
         a.y = (float*)p->workspace; a.y_cs = ldw; a.y_co = 0; a.slice_stride = slab; a.Cout_epi = ldw;
         a.scale = a.shift = a.res = nullptr; a.act = FD_ACT_NONE; a.vec_epi = 1; a.sc_on = 0;
+        a.y16 = a.res16 = 0;                         // (the slabs are fp32; the combine launch writes the f16 map)
         const int rc = dispatch_conv(p, a, stem, stream);
         if (rc != FD_OK) return rc;
         return fd_launch_splitk_reduce(orig, (const float*)p->workspace, (a.KT + a.kt_per - 1) / a.kt_per, ldw, slab, stream);

@@ -35,6 +35,7 @@ struct WgradArgs {
     long slab;                   // elements per split slab (= Cout * Ktot)
     unsigned x_bytes, dy_bytes;
     int is_gemm;
+    int x16, dy16;               // conv_wgrad_f16_kernel: the operand maps hold f16 elements (AMP activations / gradients stored as f16: fd_conv_wgrad_params.io_f16)
 };
 
 // floor(n / d) for 0 <= n < 2^31 with (m, sh) from magic_div(): m = ceil(2^(31+l) / d), l = ceil(log2 d), sh = l - 1
@@ -228,16 +229,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(WgradArgs a) {
     const int g_shh = a.sh_hw[gs], g_shw = a.sh_w[gs];
 
     float4 ra[4], rb[4];
+    const int xsh = a.x16 ? 1 : 2, ysh = a.dy16 ? 1 : 2;        // (uniform) element size of the operand maps: f16 maps are fetched 8 bytes per lane and staged unconverted
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, bool f16) -> float4 {
+        if (f16) {
+            const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0));      // (whole-vector cast: see fd_conv.hip)
+            return make_float4(v.x, v.y, 0.f, 0.f);
+        }
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+    };
     auto load_tile = [&](int m0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + srow + 8 * i;
-            const unsigned off = ((unsigned)m * (unsigned)a.dy_cs + (unsigned)(a.dy_co + co0 + sc4 * 4)) * 4u;
-            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(yrsrc, (int)((m < m_end && a_col_ok) ? off : OOB), 0, 0));
+            const unsigned off = ((unsigned)m * (unsigned)a.dy_cs + (unsigned)(a.dy_co + co0 + sc4 * 4)) << ysh;
+            ra[i] = ld4(yrsrc, (m < m_end && a_col_ok) ? off : OOB, a.dy16 != 0);
             unsigned xo = OOB;
             if (m < m_end && b_col_ok) {
                 if (a.is_gemm) {
-                    xo = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + sc4 * 4)) * 4u;
+                    xo = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + sc4 * 4)) << xsh;
                 } else {
                     const int local = m - g_mout;
                     const int n = fast_div(local, g_mgh, g_shh);
@@ -245,10 +254,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(WgradArgs a) {
                     const int ho = fast_div(rem, g_mgw, g_shw), wo = rem - ho * g_Wo;
                     const int hi = ho * a.stride - a.pad + fr * a.dil, wi = wo * a.stride - a.pad + fq * a.dil;
                     if ((unsigned)hi < (unsigned)g_H && (unsigned)wi < (unsigned)g_W)
-                        xo = ((unsigned)(g_min + (n * g_H + hi) * g_W + wi) * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + sc4 * 4)) * 4u;
+                        xo = ((unsigned)(g_min + (n * g_H + hi) * g_W + wi) * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + sc4 * 4)) << xsh;
                 }
             }
-            rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)xo, 0, 0));
+            rb[i] = ld4(xrsrc, xo, a.x16 != 0);
         }
     };
     auto store_tile = [&]() {
@@ -257,8 +266,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(WgradArgs a) {
             const int row = srow + 8 * i;
             const int off = wg16_off(row, sc4 >> 1) + 8 * (sc4 & 1);
             const f32x4 va = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, vb = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
-            *reinterpret_cast<h4*>(As + off) = __builtin_convertvector(va, h4);       // round to nearest
-            *reinterpret_cast<h4*>(Bs + off) = __builtin_convertvector(vb, h4);
+            h4 ha = __builtin_convertvector(va, h4), hb = __builtin_convertvector(vb, h4);       // round to nearest
+            if (a.dy16) ha = fd_h4_bits(ra[i].x, ra[i].y);               // (already f16: the bits as loaded)
+            if (a.x16) hb = fd_h4_bits(rb[i].x, rb[i].y);
+            *reinterpret_cast<h4*>(As + off) = ha;
+            *reinterpret_cast<h4*>(Bs + off) = hb;
         }
     };
 
@@ -533,7 +545,10 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
     a.m_out[FD_MAX_SEG] = (int)mo;
     FD_REQUIRE(mo > 0 && mo < (1L << 31), FD_E_INVAL, "fd_conv2d_bwd_weight: row count out of range");
     a.M = (int)mo;
-    const long xb = (long)p->in.m_start[p->in.nseg] * p->x_cs * 4, yb = mo * p->dy_cs * 4;
+    FD_REQUIRE((p->io_f16 & ~3) == 0 && (!p->io_f16 || (p->precision == FD_PREC_F16 && p->Cout > 32)), FD_E_UNSUPPORTED,
+               "fd_conv2d_bwd_weight: io_f16 (f16 operand maps) needs FD_PREC_F16 and Cout > 32");
+    a.x16 = p->io_f16 & 1; a.dy16 = (p->io_f16 >> 1) & 1;
+    const long xb = (long)p->in.m_start[p->in.nseg] * p->x_cs * (a.x16 ? 2 : 4), yb = mo * p->dy_cs * (a.dy16 ? 2 : 4);
     FD_REQUIRE(xb < 0xC0000000L && yb < 0xC0000000L, FD_E_UNSUPPORTED, "fd_conv2d_bwd_weight: buffer exceeds 3 GiB");
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     a.is_gemm = (p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0) ? 1 : 0;

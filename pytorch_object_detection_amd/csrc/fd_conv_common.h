@@ -38,7 +38,26 @@ struct ConvArgs {
     // DUAL kernels: K-tiles >= kt2 come from a second 1x1 source (its own row addresses, sampled with x2_stride): conv3 + downsample as one GEMM
     const float* x2; int x2_cs, x2_co, x2_stride, x2_H, x2_W, kt2; unsigned x2_bytes;
     int p_halo;    // patch kernel (fd_conv_patch.hip): input rows staged on either side of an M-tile = dil * (max level width + 1)
+    // FD_PREC_F16 (H1 kernels) only -- activations stored as f16 in HBM (fd_conv_params.io_f16): x / y / res hold _Float16 elements; views stay in ELEMENTS
+    int x16, y16, res16;
 };
+
+// four fp32 values <-> four consecutive f16 (8 bytes), round to nearest even -- the storage form of AMP activations
+__device__ __forceinline__ float4 fd_ld_h4(const void* p) {
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+// four f16 whose bits travelled as two 32-bit registers (an 8-byte f16 fetch kept in a float4's .x / .y).  (Through HIP's float2 CLASS the bit cast duplicated the
+// first register: ext-vector types only.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h4 fd_h4_bits(float lo, float hi) {
+    const f32x2 t = {lo, hi};
+    return __builtin_bit_cast(h4, t);
+}
+__device__ __forceinline__ void fd_st_h4(void* p, const float4& v) {
+    const f32x4 f = {v.x, v.y, v.z, v.w};
+    *reinterpret_cast<h4*>(p) = __builtin_convertvector(f, h4);
+}
 
 // fd_conv_patch.hip: 3x3 stride-1 'same' conv with the (tile + halo) input patch staged ONCE per 32-channel chunk in LDS
 #define FD_PATCH_BM 128

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     }
     constexpr bool GNS = false;
     constexpr bool RUP = false;       // (no upsampled-residual form of this kernel)
+    constexpr bool H1 = false;        // (no f16-storage form either)
 #include "fd_conv_epilogue.inc"
 }
 

@@ -144,6 +144,35 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 
 static inline bool view_ok(const void* p, int cs, int co, int C);
 
+// the same pass over f16 maps (AMP activations / gradients stored as f16): 8-byte accesses, the derivative evaluated in fp32, one rounding of the product
+__global__ __launch_bounds__(256) void act_bwd_h_kernel(const _Float16* __restrict__ x, int x_cs, int x_co, const _Float16* __restrict__ dy,
+                                                         int dy_cs, int dy_co, _Float16* __restrict__ dx, int dx_cs, int dx_co, int C4,
+                                                         int act, float prm, long total) {
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int q;
+        const long m = fd_div(i, C4, q);
+        const h4_t v = *reinterpret_cast<const h4_t*>(x + m * x_cs + x_co + 4 * q);
+        const h4_t g = *reinterpret_cast<const h4_t*>(dy + m * dy_cs + dy_co + 4 * q);
+        h4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (_Float16)((float)g[e] * fd_act_deriv((float)v[e], act, prm));
+        *reinterpret_cast<h4_t*>(dx + m * dx_cs + dx_co + 4 * q) = o;
+    }
+}
+
+extern "C" int32_t fd_act_bwd_nhwc_h(const void* x, int32_t x_cs, int32_t x_co, const void* dy, int32_t dy_cs, int32_t dy_co, void* dx,
+                                     int32_t dx_cs, int32_t dx_co, int64_t rows, int32_t C, int32_t act, float param, fd_stream_t stream) {
+    auto ok = [](const void* p, int cs, int co, int C_) { return p && C_ >= 4 && C_ % 4 == 0 && cs % 4 == 0 && co % 4 == 0 && cs >= co + C_ && ((uintptr_t)p & 7) == 0; };
+    FD_REQUIRE(ok(x, x_cs, x_co, C) && ok(dy, dy_cs, dy_co, C) && ok(dx, dx_cs, dx_co, C) && rows >= 1, FD_E_INVAL, "fd_act_bwd_h: bad pointer / channel view (C=%d)", C);
+    FD_REQUIRE(act >= FD_ACT_NONE && act <= FD_ACT_SIGMOID, FD_E_INVAL, "fd_act_bwd_h: unknown activation %d", act);
+    const long total = (long)rows * (C / 4);
+    hipLaunchKernelGGL(act_bwd_h_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, x_cs, x_co, (const _Float16*)dy, dy_cs, dy_co,
+                       (_Float16*)dx, dx_cs, dx_co, C / 4, act, param, total);
+    FD_CHECK_LAUNCH("fd_act_bwd_nhwc_h");
+    return FD_OK;
+}
+
 extern "C" int32_t fd_act_nhwc(const float* x, int32_t x_cs, int32_t x_co, float* y, int32_t y_cs, int32_t y_co, int64_t rows,
                                int32_t C, int32_t act, float param, fd_stream_t stream) {
     FD_REQUIRE(view_ok(x, x_cs, x_co, C) && view_ok(y, y_cs, y_co, C) && rows >= 1, FD_E_INVAL, "fd_act: bad pointer / channel view (C=%d)", C);

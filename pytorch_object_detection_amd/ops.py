@@ -36,11 +36,12 @@ def _need_gpu(*ts: torch.Tensor) -> None:
 
 
 class Rows:
-    """Channel view [rows, C] of a [rows, cs] fp32 buffer starting at channel `co`."""
+    """Channel view [rows, C] of a [rows, cs] buffer starting at channel `co`: fp32, or f16 (AMP activations stored as f16: the FD_PREC_F16 conv
+    launches and the f16 forms of the elementwise kernels read / write them directly; cs / co stay in elements)."""
     __slots__ = ("buf", "cs", "co", "C")
 
     def __init__(self, buf: torch.Tensor, co: int = 0, C_: Optional[int] = None):
-        assert buf.dim() == 2 and buf.dtype == torch.float32 and buf.is_contiguous()
+        assert buf.dim() == 2 and buf.dtype in (torch.float32, torch.float16) and buf.is_contiguous()
         _need_gpu(buf)
         self.buf, self.cs, self.co = buf, buf.shape[1], co
         self.C = buf.shape[1] - co if C_ is None else C_
@@ -53,6 +54,10 @@ class Rows:
     @property
     def rows(self) -> int:
         return self.buf.shape[0]
+
+    @property
+    def f16(self) -> bool:
+        return self.buf.dtype == torch.float16
 
     def slice(self, co: int, C_: int) -> "Rows":
         return Rows(self.buf, self.co + co, C_)
@@ -246,6 +251,11 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
     if workspace is not None:
         _need_gpu(workspace)
         p.workspace, p.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    io = (1 if x.f16 else 0) | (2 if y.f16 else 0) | (4 if (res is not None and res.f16) else 0)
+    if io:                           # f16 activation maps (AMP): the FD_PREC_F16 kernels read / write them directly (fd_conv_params.io_f16)
+        if precision != _lib.PREC_F16:
+            raise FdError("conv_call: f16 input / output / residual maps need precision = FD_PREC_F16")
+        p.io_f16 = io
     if sk_wgs:                       # FD_TILE_WINOGRAD4 as a persistent stream-K grid of sk_wgs workgroups; workspace = sk_workspace(sk_wgs) (zeroed flags)
         p.sk_wgs = sk_wgs
     if seg_param is not None:
@@ -578,6 +588,7 @@ def conv_wgrad(x: Rows, dy: Rows, segs_in: Segs, *, Cin: int, Cout: int, k: int,
     p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     p.segs = segs_in
     p.precision = precision
+    p.io_f16 = (1 if x.f16 else 0) | (2 if dy.f16 else 0)       # (f16 operand maps: FD_PREC_F16, Cout > 32 -- the library rejects anything else)
     check(_lib.lib().fd_conv2d_bwd_weight_f32(C.byref(p), _stream()), "fd_conv2d_bwd_weight_f32")
     return dw
 
@@ -1033,6 +1044,12 @@ def act(x: Rows, y: Rows, act_id: int, param: float = 0.0) -> None:
 
 
 def act_bwd(x: Rows, dy: Rows, dx: Rows, act_id: int, param: float = 0.0) -> None:
+    if x.f16 or dy.f16 or dx.f16:          # f16 maps (AMP): all three, or none
+        if not (x.f16 and dy.f16 and dx.f16):
+            raise FdError("act_bwd: x, dy and dx must all be f16 maps or all fp32")
+        check(_lib.lib().fd_act_bwd_nhwc_h(x.ptr, x.cs, x.co, dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, x.rows, x.C, act_id, float(param),
+                                           _stream()), "fd_act_bwd_nhwc_h")
+        return
     check(_lib.lib().fd_act_bwd_nhwc(x.ptr, x.cs, x.co, dy.ptr, dy.cs, dy.co, dx.ptr, dx.cs, dx.co, x.rows, x.C, act_id, float(param),
                                      _stream()), "fd_act_bwd_nhwc")
 

@@ -34,8 +34,14 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SILU, Rows
 # computing in fp32: inputs are cast up on entry, autocast is off inside, gradients come back in fp32.
 _fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _bwd = torch.amp.custom_bwd(device_type="cuda")
+_fwd_keep = torch.amp.custom_fwd(device_type="cuda")      # nodes that handle f16 / fp32 inputs themselves (AMP_F16_STORE): no cast on entry
 
 AMP_F16 = os.environ.get("FD_AMP_F16", "1") != "0"      # "0": the HIP nodes compute in fp32 under torch.autocast too (wider than the reference)
+# Under autocast the reference's convolutions read and write fp16 TENSORS (train.py:175-181): with FD_AMP_F16_STORE (default on) the nodes that are built for it keep
+# their activations -- and the gradients flowing back through them -- in HBM as f16 (fd_conv_params.io_f16: the FD_PREC_F16 kernels fetch / store f16 without a
+# conversion pass; GradScaler keeps the gradients in f16's range exactly as it does for the reference).  Today: the ResNet bottlenecks (_BottleneckRows); the other
+# nodes take fp32 and torch.amp's cast on entry converts at the boundary.  "0": fp32 maps everywhere (round 3's AMP step).
+AMP_F16_STORE = os.environ.get("FD_AMP_F16_STORE", "1") != "0"
 
 
 def amp_prec() -> int:
@@ -359,7 +365,7 @@ def _strided_dgrad(g: torch.Tensor, weight: torch.Tensor, scale: Optional[torch.
     B, (H, W) = segs.batch, segs.level_hw()[0]
     Cin = weight.shape[1]
     empty_class = any(T == 0 for _, T, _ in ops.strided_dgrad_classes(k, stride, pad))
-    gx = (torch.zeros if empty_class else torch.empty)(B * H * W, Cin, dtype=torch.float32, device=g.device)
+    gx = (torch.zeros if empty_class else torch.empty)(B * H * W, Cin, dtype=g.dtype, device=g.device)      # (f16 maps under AMP_F16_STORE: the gradient's own type)
     ok = ops.conv_dgrad_strided(_r(g), weight, scale, _r(gx), B, H, W, k, stride, pad, res=_r(res) if res is not None else None,
                                 res_mask=res_mask, precision=prec)
     if not ok:
@@ -465,21 +471,23 @@ class _BottleneckRows(torch.autograd.Function):
     in conv1's data-gradient epilogue (res_mode 0): per block 1 elementwise pass instead of 3 masks + 1 add."""
 
     @staticmethod
-    @_fwd32
+    @_fwd_keep
     def forward(ctx, x, w1, w2, w3, wd, c1, c2, c3, cd, segs, stride, prec=0):
-        x = x.contiguous()
+        # (no cast on entry: under AMP the node takes an f16 map as it is -- the previous bottleneck's output -- or an fp32 one, and keeps its own maps in f16)
         h = bool(prec)
+        st = torch.float16 if (h and AMP_F16_STORE) else torch.float32          # storage type of this node's activations and gradients
+        x = x.contiguous() if (x.dtype == st or (h and AMP_F16_STORE and x.dtype == torch.float32)) else x.to(st).contiguous()
         dev = x.device
         so = ops.conv_out_segs(segs, 3, stride, 1, 1)
         P, C4 = w1.shape[0], w3.shape[0]
-        y1 = torch.empty(segs.rows, P, dtype=torch.float32, device=dev)
-        y2 = torch.empty(so.rows, P, dtype=torch.float32, device=dev)
-        out = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
+        y1 = torch.empty(segs.rows, P, dtype=st, device=dev)
+        y2 = torch.empty(so.rows, P, dtype=st, device=dev)
+        out = torch.empty(so.rows, C4, dtype=st, device=dev)
         _conv_launch(x, segs, PACKS.get(w1, f16=h), y1, k=1, stride=1, pad=0, dil=1, scale=c1[0], shift=c1[1], act=ACT_RELU)
         _conv_launch(y1, segs, PACKS.get(w2, wino=_wino(P, P, 3, stride, 1, 1, segs, prec), f16=h), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0],
                      shift=c2[1], act=ACT_RELU)
         if wd is not None:
-            idt = torch.empty(so.rows, C4, dtype=torch.float32, device=dev)
+            idt = torch.empty(so.rows, C4, dtype=st, device=dev)
             _conv_launch(x, segs, PACKS.get(wd, f16=h), idt, k=1, stride=stride, pad=0, dil=1, scale=cd[0], shift=cd[1])
         else:
             idt = x
@@ -497,7 +505,7 @@ class _BottleneckRows(torch.autograd.Function):
         h = bool(prec)
         need_x = ctx.needs_input_grad[0]
         P, Cin, C4 = w1.shape[0], w1.shape[1], w3.shape[0]
-        g = relu_mask(gout.contiguous(), out)                                        # the one elementwise pass of the block
+        g = relu_mask(gout.contiguous() if gout.dtype == out.dtype else gout.to(out.dtype), out)      # the one elementwise pass of the block
         gw1 = gw2 = gw3 = gwd = gx = None
         wg = lambda xx, gg, sg, Ci, Co, k, st, pad, sc: ops.conv_wgrad(_r(xx), _r(gg), sg, Cin=Ci, Cout=Co, k=k, stride=st,  # noqa: E731
                                                                      pad=pad, dil=1, scale=sc, oihw=True, precision=prec)

@@ -61,6 +61,54 @@ def test_conv_f16_operands_fp32_accumulate(case):
     assert float((F.conv2d(h(xs[0]), h(w), None, stride, pad, dil) - ref32).abs().max()) > 1e-4
 
 
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("io", [(True, True, True), (True, False, False), (False, True, True)])
+def test_conv_f16_activation_maps_in_hbm(case, io):
+    """fd_conv_params.io_f16: under autocast the reference's convolutions read and write fp16 TENSORS (train.py:175-181), so AMP activations can live in HBM as f16:
+    the loader fetches f16 and feeds the MFMA without conversion, the epilogue rounds the fp32 result once.  Must equal, BIT FOR BIT, the fp32-map launch of the
+    same kernel on the same (already f16-valued) inputs followed by one rounding of its output -- for f16 inputs, outputs and residuals in any combination, over
+    pyramids / strides / dilation, with channel views whose neighbours are NaN, with the residual as ReLU mask, and through split-K."""
+    Cin, Cout, k, stride, pad, dil, hw, act, use_res = case
+    x16, y16, r16 = io
+    gen = torch.Generator().manual_seed(Cin + Cout + k + 7)
+    B = 2
+    segs = Segs.make(B, hw)
+    so = ops.conv_out_segs(segs, k, stride, pad, dil)
+    x = h(torch.randn(segs.rows, Cin, generator=gen)).to(DEV)                      # f16-representable values in both forms
+    r = h(torch.randn(so.rows, Cout, generator=gen)).to(DEV)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * k * k)
+    scale, shift = (torch.rand(Cout, generator=gen) + 0.5).to(DEV), torch.randn(Cout, generator=gen).to(DEV)
+    wp = ops.pack_conv_weight_hip(w.to(DEV), f16=True)
+    for res_mask in ((False, True) if use_res else (False,)):
+        kw = dict(Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift, act=act, precision=_lib.PREC_F16, res_mask=res_mask)
+        y0 = ops.new_rows(so.rows, Cout, DEV)
+        ops.conv_call(ops.Rows(x), segs, wp, y0, res=ops.Rows(r) if use_res else None, **kw)()
+        want = y0.tensor().half() if y16 else y0.tensor()
+
+        def buf(t, f16, co, C_):
+            b = torch.full((t.shape[0], C_ + 12), float("nan"), dtype=torch.float16 if f16 else torch.float32, device=DEV)
+            b[:, co:co + C_] = t
+            return b
+        xb, rb = buf(x, x16, 8, Cin), buf(r, r16, 4, Cout)
+        yb = torch.full((so.rows, Cout + 12), float("nan"), dtype=torch.float16 if y16 else torch.float32, device=DEV)
+        for ks in (1, 2):
+            if ks > 1 and (Cin // 32) * k * k < 4:
+                continue
+            yb.fill_(float("nan"))
+            ws = torch.empty(ks * so.rows * Cout + 64, device=DEV) if ks > 1 else None
+            ops.conv_call(ops.Rows(xb, 8, Cin), segs, wp, ops.Rows(yb, 4, Cout), res=ops.Rows(rb, 4, Cout) if use_res else None, ksplit=ks, workspace=ws, tile=2, **kw)()
+            assert torch.isnan(yb[:, :4]).all() and torch.isnan(yb[:, 4 + Cout:]).all(), "wrote outside its channel view"
+            got = yb[:, 4:4 + Cout]
+            if ks == 1:
+                ops.conv_call(ops.Rows(x), segs, wp, y0, res=ops.Rows(r) if use_res else None, tile=2, **kw)()      # same tile: same summation order
+                want = y0.tensor().half() if y16 else y0.tensor()
+                assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+            else:
+                np.testing.assert_allclose(got.float().cpu().numpy(), want.float().cpu().numpy(), atol=2e-3 if y16 else 2e-5, rtol=2e-3 if y16 else 2e-5)
+    with pytest.raises(Exception, match="FD_PREC_F16"):
+        ops.conv_call(ops.Rows(x.half()), segs, ops.pack_conv_weight(w.to(DEV)), ops.new_rows(so.rows, Cout, DEV), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil)
+
+
 def test_pack_f16_pair_format():
     gen = torch.Generator().manual_seed(1)
     w = torch.randn(96, 64, 3, 3, generator=gen)
@@ -105,6 +153,51 @@ def test_autocast_conv_node_forward_and_data_gradient(k, stride):
     gw_f16 = torch.nn.grad.conv2d_weight(h(x), conv.weight.shape, h(dy), stride, k // 2)
     err_exact, err_f16 = float((gw - gw_exact).abs().max()), float((gw - gw_f16).abs().max())
     assert err_f16 < 5e-5 * float(gw_exact.abs().max()) + 1e-5 and err_f16 < err_exact, (err_exact, err_f16)      # the f16-operand weight gradient
+
+
+@pytest.mark.parametrize("cfg", [(256, 64, 1, False, torch.float32), (256, 128, 2, True, torch.float32), (512, 128, 1, False, torch.float16), (512, 256, 2, True, torch.float16)])
+def test_bottleneck_node_keeps_its_maps_in_f16_under_autocast(cfg):
+    """train_ops.AMP_F16_STORE: under autocast a ResNet bottleneck keeps y1, y2, the identity branch, its output and every gradient that flows back through it in HBM
+    as f16 (the reference's autocast convolutions produce fp16 tensors, train.py:175-181).  Against the SAME node with fp32 maps (round 3's AMP step: identical f16
+    products, activations rounded on their way to LDS instead of once when stored): outputs within f16 rounding, input and weight gradients with cosine > 0.999 and fewer than 1 % of the
+    elements off by more than 2 % of the maximum (ReLU-mask flips, see below); f16 and fp32 inputs; the dtype contract (f16 out, gradient of the input in the input's own type)."""
+    from pytorch_object_detection_amd.model.backbone.resnet50 import _Bottleneck
+    Cin, P, stride, ds, xdt = cfg
+    torch.manual_seed(Cin + P + stride)
+    blk = _Bottleneck(Cin, P, stride, ds).to(DEV)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+            m.weight.requires_grad_(False); m.bias.requires_grad_(False)
+    blk.eval()                      # frozen BatchNorm (HISFcos.py:57-68)
+    B, H, W = 2, 18, 14
+    x0 = torch.randn(B, Cin, H, W, device=DEV).to(memory_format=torch.channels_last)
+    gy = torch.randn(B, 4 * P, (H - 1) // stride + 1, (W - 1) // stride + 1, device=DEV).to(memory_format=torch.channels_last) * 64.0     # (a GradScaler-sized gradient)
+    res = {}
+    for store in (False, True):
+        T.AMP_F16_STORE = store
+        try:
+            blk.zero_grad(set_to_none=True)
+            x = x0.to(xdt).detach().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                y = T.bottleneck(blk, x)
+            assert y.dtype == (torch.float16 if store else torch.float32)
+            y.backward(gy.to(y.dtype))
+            assert x.grad.dtype == xdt
+            res[store] = (y.detach().float(), x.grad.float(), [p.grad.float().clone() for p in blk.parameters() if p.requires_grad])
+        finally:
+            T.AMP_F16_STORE = True
+    y0, gx0, gw0 = res[False]
+    y1, gx1, gw1 = res[True]
+    assert float((y1 - y0).abs().max()) <= 2e-3 * (float(y0.abs().max()) + 1.0)
+    # The identity branch reaches the block's ReLU rounded to f16 (as in torch's autocast) instead of in fp32: a pre-activation within 1e-3 of zero can land on the
+    # other side, and one flipped mask element moves a whole row of the gradients upstream by |dy| * w (measured: 59 of 32 256 elements of one layer's gradient,
+    # all in one pixel row).  So: direction and bulk agreement, not an element-wise bound.
+    for a, b in [(gx1, gx0)] + list(zip(gw1, gw0)):
+        assert float(F.cosine_similarity(a.flatten(), b.flatten(), dim=0)) > 0.999
+        bad = ((a - b).abs() > 2e-2 * float(b.abs().max())).float().mean()
+        assert float(bad) < 0.01, float(bad)
+    assert T.STATS.get("stock_fallbacks", 0) == 0
 
 
 def test_amp_train_step_runs_on_f16_mfma_and_tracks_the_fp32_step():
