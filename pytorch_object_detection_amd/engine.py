@@ -316,6 +316,10 @@ def add_conv(plan: Plan, name: str, x: Rows, segs: Segs, conv: torch.nn.Conv2d, 
             key = "f16x3|" + key
         if x2 is not None:
             key += f"|x2s{x2_stride}c{x2.C}"
+        if res_up and key not in ops._tune_table():
+            # a table MISS of a res_up layer is timed with res_mode 2 set, i.e. over the RUP tiles only: that restricted winner gets a key of its own and never
+            # lands under the plain layer's key (which the unfused FD_FPN_UP_FUSED=0 lateral of the same shape reads).  A plain-key HIT is still mapped below.
+            key += "|rup"
         plan.tiles[name] = ops.autotune_conv(call, key, out.rows, co, -(-Cin // 32) * k * k, pair=plan.pair_tuned and tag != 1)
         if res_up:
             t = {1: 8, 2: 8, 3: 9, 4: 4, 7: 8, 8: 8, 9: 9}.get(plan.tiles[name] & 0xFF, 9)

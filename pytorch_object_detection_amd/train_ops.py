@@ -817,24 +817,36 @@ class _BatchNormTrainRows(torch.autograd.Function):
 #             all-reduce flies under conv2's data / weight gradient kernels, bn2's under the SE backward).
 # With RCCL the collective runs on its own stream and wait() is a stream dependency; with gloo (tests) wait() blocks the host after the independent
 # launches were enqueued.  SYNC_TRACE records, per collective, how many HIP launches were enqueued between issue and wait (tests assert on it).
-SYNC_TRACE: list = []
-_PENDING: dict = {}          # data_ptr of an unfinished input gradient -> closure that finishes it
+import collections as _collections
+SYNC_TRACE = _collections.deque(maxlen=4096)      # (bounded: a long multi-rank run appends ~200 entries per step; only tests read it)
+# Unfinished input gradients of deferred SyncBatchNorm backward nodes: data_ptr -> (autograd graph-task id of the backward pass that deferred it, closure that
+# finishes it).  The task id ties an entry to ITS pass: what a pass that raised before its flush left behind is never applied to a later pass's gradient that
+# happens to reuse the address, and is dropped when the next pass defers its first gradient.
+_PENDING: dict = {}
+
+
+def _task_id() -> int:
+    return torch._C._current_graph_task_id()
 
 
 def resolve_pending(g: torch.Tensor) -> torch.Tensor:
-    """Called by the conv nodes' backward on their incoming gradient: finishes it if a SyncBatchNorm node deferred its second phase."""
+    """Called by the conv nodes' backward on their incoming gradient: finishes it if a SyncBatchNorm node of THIS backward pass deferred its second phase."""
     if _PENDING:
-        fin = _PENDING.pop(g.data_ptr(), None)
-        if fin is not None:
-            fin()
+        e = _PENDING.get(g.data_ptr())
+        if e is not None and e[0] == _task_id():
+            del _PENDING[g.data_ptr()]
+            e[1]()
     return g
 
 
 def flush_pending() -> None:
-    """Finish every deferred gradient (safety net, queued at the end of each backward pass that deferred one)."""
+    """Finish every gradient this pass deferred and nobody resolved (safety net, queued at the end of EVERY backward pass that deferred one); entries of other
+    (failed) passes are dropped unfinished."""
+    tid = _task_id()
     while _PENDING:
-        _, fin = _PENDING.popitem()
-        fin()
+        _, (t, fin) = _PENDING.popitem()
+        if t == tid or tid < 0:          # (tid < 0: the engine runs the callback outside the task -- finishing a leftover writes its own, dead tensor: harmless)
+            fin()
 
 
 class _SyncHandle:
@@ -927,9 +939,11 @@ class _SyncBatchNormApply(torch.autograd.Function):
         if defer:
             # the ONLY consumer of gx is one of this module's conv nodes (conv_norm_begin built the chain): it finishes gx on entry (resolve_pending);
             # the nodes autograd runs before it are enqueued under the collective.  flush_pending at the end of the pass is the safety net.
-            if not _PENDING:
-                torch.autograd.Variable._execution_engine.queue_callback(flush_pending)
-            _PENDING[gx.data_ptr()] = finish
+            tid = _task_id()
+            for k in [k for k, e in _PENDING.items() if e[0] != tid]:      # leftovers of a pass that raised before its flush
+                del _PENDING[k]
+            torch.autograd.Variable._execution_engine.queue_callback(flush_pending)      # always: a stale entry must not suppress this pass's flush
+            _PENDING[gx.data_ptr()] = (tid, finish)
         else:
             finish()
         return gx, dgamma, dbeta, None, None, None, None, None, None
