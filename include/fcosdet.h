@@ -118,6 +118,10 @@ const char* fd_last_error(void);
                                 `gate` + `gate_b` (+ gate_act): the preceding GroupNorm's affine + activation applied to the patch on its way to LDS, zero
                                 padding AFTER it as in the reference (any number of levels; coefficient rows as documented at gate_b below).
                                 `w` = [Cin / 16][3 r][4 quads][3 q][4 k][8 couts] fp32: channel 16 chunk + 4 quad + k, filter tap (r, q); zero filters past Cout */
+#define FD_TILE_F16K64 18    /* FD_PREC_F16 only (the AMP training step, train.py:175-181): f16 operands on K-tiles of 64 channels -- twice the matrix work per LDS tile of the
+                                single-plane f16 instantiations of the other tiles, and activation maps stored as f16 (io_f16) go to LDS unconverted, 16 bytes per lane.  `w` = the
+                                fd_pack_conv_weight_f32 mode | 16 packing; Cin % 64 == 0, x_cs / x_co multiples of 8, 4-channel aligned output / residual views; ReLU / SiLU / none;
+                                any stride / dilation / pyramid / scatter; no split-K, gate, gn_stats, x2.  The library picks the block tile. */
 #define FD_TILE_COUNT 17
 
 typedef struct fd_conv_params {
@@ -293,7 +297,8 @@ int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_stream_t stre
  * == 0).  mode 1: weights of the stride-1 data-gradient conv (N = Cin, K = Cout, Cout % 32 == 0):
  * w'[ci][co][r][q] = w[co][ci][KH-1-r][KW-1-q] * (scale ? scale[co] : 1).
  * mode | 4: the same weights in the FD_PREC_F16X3 / FD_PREC_F16 operand format [N][K/32][KH][KW][2][32] f16 (hi = f16(w) round-to-nearest,
- * lo = f16((w - hi) * 2^11)); the output buffer has the same byte size as the fp32 packing. */
+ * lo = f16((w - hi) * 2^11)); the output buffer has the same byte size as the fp32 packing.
+ * mode | 16 (not with | 4): FD_TILE_F16K64's operand -- f16 [N][K/64][KH][KW][64], K % 64 == 0; HALF the byte size of the fp32 packing. */
 int32_t fd_pack_conv_weight_f32(const float* w, const float* scale, float* out, int32_t Cout, int32_t Cin, int32_t KH,
                                 int32_t KW, int32_t mode, fd_stream_t stream);
 
@@ -304,7 +309,7 @@ typedef struct fd_pack_job {
     const float* w;      /* [Cout][Cin][KH][KW] */
     const float* scale;  /* [Cout] or NULL (mode 1 only) */
     float* out;
-    int32_t Cout, Cin, KH, KW, mode, reserved; /* mode: 0 / 1 (| 4) as fd_pack_conv_weight_f32; 2 / 3 = the Winograd packing of fd_wino_pack_weights_f32 (mode 0 / 1), 8 / 9 = that of fd_wino4_pack_weights_f32; 3x3 only */
+    int32_t Cout, Cin, KH, KW, mode, reserved; /* mode: 0 / 1 (| 4 or | 16) as fd_pack_conv_weight_f32; 2 / 3 = the Winograd packing of fd_wino_pack_weights_f32 (mode 0 / 1), 8 / 9 = that of fd_wino4_pack_weights_f32; 3x3 only */
 } fd_pack_job;
 int32_t fd_pack_conv_weights_batch_f32(const fd_pack_job* jobs_dev, int32_t n_jobs, int64_t max_elems, fd_stream_t stream);
 

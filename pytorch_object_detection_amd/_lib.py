@@ -17,6 +17,7 @@ TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (128, 32), 6
 PATCH_TILE = 13
 WAVE_TILE = 15
 NARROW_TILE = 17    # 3x3 stride-1 pad-1 convs with Cout <= 8 on the vector unit (fd_conv_narrow.hip; ops.pack_conv_weight_narrow); not a member of TILES
+F16K64_TILE = 18    # FD_PREC_F16 on K-tiles of 64 channels (fd_conv_f16.hip; ops.pack_conv_weight_f16k64); not a member of TILES
 WINO4_TILE = 16     # Winograd F(4x4, 3x3) kernel (own weight packing: ops.pack_conv_weight_wino4); not a member of TILES
 PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2     # include/fcosdet.h FD_PREC_*
 WINO_TILE = 14      # Winograd F(2x2, 3x3) kernel (own weight packing: ops.pack_conv_weight_wino); not a member of TILES

@@ -565,6 +565,7 @@ extern "C" int32_t fd_conv2d_nhwc_f32(const fd_conv_params* p, fd_stream_t strea
         a.x16 = p->io_f16 & 1; a.y16 = (p->io_f16 >> 1) & 1; a.res16 = (p->io_f16 >> 2) & 1;
         if (a.x16) a.x_bytes = (unsigned)((long)p->in.m_start[p->in.nseg] * p->x_cs * 2);
     }
+    if (p->tile == FD_TILE_F16K64) return fd_launch_conv_f16k64(p, a, stream);      // the AMP step's f16 kernel on K-tiles of 64 channels (own weight packing)
     a.gate = nullptr; a.gate_cs = 0; a.gate_hw = 1; a.gate_b = nullptr; a.gate_act = FD_ACT_NONE; a.gate_batch = p->in.batch;
     a.gn_stats = nullptr; a.gn_G = 1; a.gn_cg = 4;
     if (p->gn_stats) {   // row-group statistics of the stored output (GroupNorm fused into the producer)

@@ -375,13 +375,14 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
                                                            long total) {
     const int taps = KH * KW;
     const int N = (mode & 1) ? Cin : Cout, K = (mode & 1) ? Cout : Cin;
+    const int ksh = (mode & 16) ? 6 : 5;          // mode | 16: K-tiles of 64 channels, f16 only (fd_conv_f16.hip)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c32 = (int)(i & 31);
-        long t = i >> 5;
+        const int cl = (int)(i & ((1 << ksh) - 1));
+        long t = i >> ksh;
         const int tap = (int)(t % taps); t /= taps;
-        const int chunk = (int)(t % (K / 32));
-        const int n = (int)(t / (K / 32));
-        const int k = chunk * 32 + c32;
+        const int chunk = (int)(t % (K >> ksh));
+        const int n = (int)(t / (K >> ksh));
+        const int k = (chunk << ksh) + cl;
         float v;
         if ((mode & 1) == 0) {
             v = w[((long)n * Cin + k) * taps + tap];
@@ -389,17 +390,18 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
             v = w[((long)k * Cin + n) * taps + (taps - 1 - tap)];
             if (scale) v *= scale[k];
         }
-        if (mode & 4) pack_store_f16(out, i, v); else out[i] = v;
+        if (mode & 16) reinterpret_cast<_Float16*>(out)[i] = (_Float16)v;
+        else if (mode & 4) pack_store_f16(out, i, v); else out[i] = v;
     }
     (void)N;
 }
 
 extern "C" int32_t fd_pack_conv_weight_f32(const float* w, const float* scale, float* out, int32_t Cout, int32_t Cin,
                                            int32_t KH, int32_t KW, int32_t mode, fd_stream_t stream) {
-    FD_REQUIRE(w && out && Cout >= 1 && Cin >= 1 && KH >= 1 && KW >= 1 && (mode & ~5) == 0, FD_E_INVAL,
+    FD_REQUIRE(w && out && Cout >= 1 && Cin >= 1 && KH >= 1 && KW >= 1 && (mode & ~21) == 0 && (mode & 20) != 20, FD_E_INVAL,
                "fd_pack_conv_weight: bad arguments");
-    FD_REQUIRE(((mode & 1) == 0 ? Cin : Cout) % 32 == 0, FD_E_UNSUPPORTED,
-               "fd_pack_conv_weight: the reduction width (%d) must be a multiple of 32", (mode & 1) == 0 ? Cin : Cout);
+    FD_REQUIRE(((mode & 1) == 0 ? Cin : Cout) % ((mode & 16) ? 64 : 32) == 0, FD_E_UNSUPPORTED,
+               "fd_pack_conv_weight: the reduction width (%d) must be a multiple of %d", (mode & 1) == 0 ? Cin : Cout, (mode & 16) ? 64 : 32);
     const long total = (long)Cout * Cin * KH * KW;
     long g = (total + 255) / 256;
     if (g > 16384) g = 16384;
@@ -436,13 +438,14 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const fd_pack_jo
     const long total = (long)j.Cout * j.Cin * taps;
     const float* __restrict__ w = j.w;
     const float* __restrict__ scale = j.scale;
+    const int ksh = (j.mode & 16) ? 6 : 5;        // mode | 16: the f16 K-tile-64 packing of fd_conv_f16.hip
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c32 = (int)(i & 31);
-        long t = i >> 5;
+        const int cl = (int)(i & ((1 << ksh) - 1));
+        long t = i >> ksh;
         const int tap = (int)(t % taps); t /= taps;
-        const int chunk = (int)(t % (K / 32));
-        const int n = (int)(t / (K / 32));
-        const int k = chunk * 32 + c32;
+        const int chunk = (int)(t % (K >> ksh));
+        const int n = (int)(t / (K >> ksh));
+        const int k = (chunk << ksh) + cl;
         float v;
         if ((j.mode & 1) == 0) {
             v = w[((long)n * j.Cin + k) * taps + tap];
@@ -450,7 +453,8 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const fd_pack_jo
             v = w[((long)k * j.Cin + n) * taps + (taps - 1 - tap)];
             if (scale) v *= scale[k];
         }
-        if (j.mode & 4) pack_store_f16(j.out, i, v); else j.out[i] = v;
+        if (j.mode & 16) reinterpret_cast<_Float16*>(j.out)[i] = (_Float16)v;
+        else if (j.mode & 4) pack_store_f16(j.out, i, v); else j.out[i] = v;
     }
 }
 

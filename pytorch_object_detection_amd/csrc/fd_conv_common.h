@@ -73,6 +73,8 @@ int fd_wino4_workgroups_live(const fd_conv_params* p, int first, int count);
 int fd_launch_conv_narrow(const fd_conv_params* p, hipStream_t stream);
 // fd_conv_wave.hip: GEMM-addressed layers as wave-autonomous 64 x 64 tiles (FD_TILE_WAVE64); wfrag = fd_pack_conv_weight_wave_f32 packing
 int fd_launch_conv_wave(const ConvArgs& a, const float* wfrag, hipStream_t stream);
+// fd_conv_f16.hip: FD_PREC_F16 convs on K-tiles of 64 channels, f16 or fp32 activation maps (FD_TILE_F16K64; p->w is the fd_pack_conv_weight_f32 mode | 16 packing)
+int fd_launch_conv_f16k64(const fd_conv_params* p, ConvArgs& a, hipStream_t stream);
 // fd_conv.hip: y = act(sum over the nslice slabs of ws (in slice order) * scale + shift (+ | mask) res) -- the split-K combine launch
 // (`orig`: scale / shift / res / y views, Cout, act, act_c0, M, nseg, m_out, seg_param, res_mask, sc_* of the real conv)
 int fd_launch_splitk_reduce(const ConvArgs& orig, const float* ws, int nslice, int ldw, long slab, hipStream_t stream);

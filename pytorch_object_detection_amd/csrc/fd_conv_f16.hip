@@ -1,0 +1,235 @@
+// fd_conv_f16.hip -- dense convolution with f16 operands and fp32 accumulation on K-tiles of 64 channels (FD_TILE_F16K64): the AMP training step's conv kernel
+// (train.py:33,175-181: the reference trains under torch.autocast(float16) + GradScaler; forward and data gradient of every dense conv).
+//
+// The single-plane f16 instantiations of the fp32 kernel (fd_conv.hip, H1) keep that kernel's K-tile of 32 channels: per tile and wave 2 K-steps of
+// v_mfma_f32_32x32x16_f16 -- a quarter of the matrix time the fp32 MFMAs give the same loader, barrier and LDS traffic to hide behind: 0.16 of the f16 peak, feed-bound.
+// Here a K-tile is 64 channels = 128 bytes per row in f16, i.e. exactly the row the fp32 kernel's loader and LDS layout are built for (8 lanes x 16 bytes, chunks
+// XOR-swizzled by the row): twice the matrix work per tile, and with activation maps STORED as f16 (fd_conv_params.io_f16) one 16-byte fetch per lane carries eight
+// channels straight to LDS.  fp32 maps are accepted too (two fetches per lane, one rounding on the way to LDS): every AMP conv can take this kernel.
+//   * weights: fd_pack_conv_weight_f32 mode | 16 -> f16 [N][K / 64][taps][64] (K-tile order (64-channel chunk, tap), as the fp32 packing);
+//   * 1x1 and k x k, any stride / dilation / padding, pyramids, explicit output size + scatter (the parity classes of a strided data gradient);
+//   * epilogue: scale / shift, residual add or ReLU mask (f16 or fp32 map), ReLU / SiLU / none, f16 or fp32 output; 4-channel aligned views.  No split-K, gate, gn_stats.
+#include "fd_conv_common.h"
+
+template <int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs a) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int RPP = NT / 8;                 // rows per loader pass (8 lanes fetch one 128-byte row of the tile)
+    constexpr int AP = BM / RPP, BP = BN / RPP;
+    constexpr int STG = (BM + BN) * 32;         // floats (= 64 halves per row) per buffer
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ls = reinterpret_cast<float*>(smem); // [2][BM + BN rows][32 floats]: A rows first, then B rows; 16-byte chunks swizzled by lds_off()
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order (as conv_igemm_kernel)
+    const int nblk = a.mtiles * a.ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / a.ntiles, nt = bid - mt * a.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int lrow = tid >> 3, chunk = tid & 7;          // this lane: row lrow (+ RPP per pass), channels 8 chunk .. 8 chunk + 7 of the K-tile
+    constexpr unsigned OOB = 0xC0000000u;
+    const int esh = a.x16 ? 1 : 2;                       // (uniform) bytes per input element, as a shift
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, (int)a.w_bytes, 0x00020000);
+    unsigned a_off[AP];
+    int a_wcs[AP], a_hi0[AP], a_wi0[AP], a_H[AP], a_W[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + lrow + RPP * i;
+        if (a.is_gemm) {     // 1x1, stride 1, unpadded: the input row is the output row
+            a_off[i] = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 8)) << esh;
+            a_wcs[i] = 0; a_hi0[i] = 0; a_wi0[i] = 0; a_H[i] = (m < a.M) ? 1 : 0; a_W[i] = 1;
+            continue;
+        }
+        int s = 0;
+#pragma unroll
+        for (int t = 1; t < FD_MAX_SEG; ++t)
+            if (t < a.nseg && m >= a.m_out[t]) s = t;
+        const int Ho = a.Ho[s], Wo = a.Wo[s], H = a.H[s], W = a.W[s];
+        const int local = m - a.m_out[s];
+        const int hw = Ho * Wo;
+        const int n = local / hw;
+        const int rem = local - n * hw;
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        a_hi0[i] = ho * a.stride - a.pad;
+        a_wi0[i] = wo * a.stride - a.pad;
+        a_H[i] = (m < a.M) ? H : 0;
+        a_W[i] = W;
+        a_wcs[i] = (W * a.x_cs) << esh;
+        a_off[i] = ((unsigned)(a.m_in[s] + n * H * W + a_hi0[i] * W + a_wi0[i]) * (unsigned)a.x_cs + (unsigned)(a.x_co + chunk * 8)) << esh;
+    }
+    unsigned b_off[BP];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+        const int n = n0 + lrow + RPP * j;
+        b_off[j] = (n < a.Cout) ? ((unsigned)n * (unsigned)a.KT * 64u + (unsigned)(chunk * 8)) * 2u : OOB;
+    }
+
+    float4 ra[AP], ra2[AP], rb[BP];
+    int ld_cc = 0, ld_r = 0, ld_q = 0;      // K-tile = (64-channel chunk, filter row, filter column), advancing as counters
+    auto load_tile = [&](int kt) {
+        const int dr = ld_r * a.dil, dq = ld_q * a.dil;
+        const unsigned dbytes = (unsigned)(dq * a.x_cs + ld_cc * 64) << esh;
+        const bool c_ok = ld_cc * 64 + chunk * 8 < a.Cin;
+        if (++ld_q == a.KW) { ld_q = 0; if (++ld_r * a.KW == a.ntaps) { ld_r = 0; ++ld_cc; } }
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int hi = a_hi0[i] + dr, wi = a_wi0[i] + dq;
+            const bool ok = (unsigned)hi < (unsigned)a_H[i] && (unsigned)wi < (unsigned)a_W[i] && c_ok;
+            const unsigned off = ok ? a_off[i] + (unsigned)__mul24(dr, a_wcs[i]) + dbytes : OOB;
+            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+            if (!a.x16) ra2[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 16, 0));      // fp32 map: channels 4 .. 7 of the lane's eight
+        }
+        const unsigned kb = (unsigned)kt * 128u;
+#pragma unroll
+        for (int j = 0; j < BP; ++j) rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(b_off[j] + kb), 0, 0));
+    };
+    auto store_tile = [&](int buf) {
+        float* Ab = Ls + buf * STG;
+        float* Bb = Ab + BM * 32;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            float4 v = ra[i];
+            if (!a.x16) {       // (uniform) round the eight fp32 values once, to nearest even
+                const f32x4 lo = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, hi = {ra2[i].x, ra2[i].y, ra2[i].z, ra2[i].w};
+                const h4 l4 = __builtin_convertvector(lo, h4), h4_ = __builtin_convertvector(hi, h4);
+                const h8 p = {l4[0], l4[1], l4[2], l4[3], h4_[0], h4_[1], h4_[2], h4_[3]};
+                v = __builtin_bit_cast(float4, p);
+            }
+            *reinterpret_cast<float4*>(Ab + lds_off(lrow + RPP * i, chunk)) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) *reinterpret_cast<float4*>(Bb + lds_off(lrow + RPP * j, chunk)) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto mfma_tile = [&](int buf) {
+        const float* Ab = Ls + buf * STG + (wm * TM * 32) * 32;
+        const float* Bb = Ls + buf * STG + BM * 32 + (wn * TN * 32) * 32;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {        // four K-steps of 16: lane half lh carries k = 16 ks + 8 lh .. + 7 (one 16-byte chunk)
+            h8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const h8*>(Ab + lds_off(i * 32 + l31, 2 * ks + lh));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const h8*>(Bb + lds_off(j * 32 + l31, 2 * ks + lh));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < a.KT - 1; ++kt) {
+        const int buf = kt & 1;
+        load_tile(kt + 1);
+        mfma_tile(buf);
+        store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    mfma_tile((a.KT - 1) & 1);
+    __syncthreads();
+
+    // ---- epilogue: each 32 x 32 sub-tile through a per-wave LDS stage, a lane then owns 4 consecutive channels of one pixel ----
+    float* stage = reinterpret_cast<float*>(smem) + wave * 1024;
+    const _Float16* res16 = reinterpret_cast<const _Float16*>(a.res);
+    _Float16* y16 = reinterpret_cast<_Float16*>(a.y);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + (wn * TN + j) * 32;
+        const int n = nb + l31;
+        const bool n_ok = n < a.Cout;
+        const float sc = (a.scale && n_ok) ? a.scale[n] : 1.0f, sf = (a.shift && n_ok) ? a.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm * TM + i) * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + l31] = acc[i][j][e] * sc + sf;
+            wave_lds_sync();
+            const int c4 = (lane & 7) * 4, nn = nb + c4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = (lane >> 3) + 8 * p;
+                const int m = mb + row;
+                if (m < a.M && nn < a.Cout) {
+                    float4 v = *reinterpret_cast<const float4*>(stage + row * 32 + c4);
+                    const size_t mo = (size_t)out_row(a, m);
+                    if (a.res) {
+                        const size_t ro = mo * a.res_cs + a.res_co + nn;
+                        const float4 r = a.res16 ? fd_ld_h4(res16 + ro) : *reinterpret_cast<const float4*>(a.res + ro);
+                        if (a.res_mask) {
+                            v.x = r.x > 0.f ? v.x : 0.f; v.y = r.y > 0.f ? v.y : 0.f; v.z = r.z > 0.f ? v.z : 0.f; v.w = r.w > 0.f ? v.w : 0.f;
+                        } else {
+                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        }
+                    }
+                    if (a.act != FD_ACT_NONE) {
+                        if (nn + 0 >= a.act_c0) v.x = fd_act(v.x, a.act, 0.f);
+                        if (nn + 1 >= a.act_c0) v.y = fd_act(v.y, a.act, 0.f);
+                        if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, 0.f);
+                        if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, 0.f);
+                    }
+                    const size_t yo = mo * a.y_cs + a.y_co + nn;
+                    if (a.y16) fd_st_h4(y16 + yo, v);
+                    else *reinterpret_cast<float4*>(a.y + yo) = v;
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+template <int WGM, int WGN, int TM, int TN>
+static int launch_f16k64(const ConvArgs& a, hipStream_t stream) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = WGM * WGN * 64;
+    constexpr int lds = 2 * (BM + BN) * 128;                  // >= the epilogue's 4 KB per wave
+    ConvArgs b = a;
+    b.mtiles = (a.M + BM - 1) / BM;
+    b.ntiles = (a.Cout + BN - 1) / BN;
+    auto kern = conv_f16k64_kernel<WGM, WGN, TM, TN>;
+    static std::atomic<unsigned> attr_mask{0};
+    fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
+    hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles), dim3(NT), lds, stream, b);
+    FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (FD_TILE_F16K64)");
+    return FD_OK;
+}
+
+// `a`: the argument block fd_conv2d_nhwc_f32 has filled (geometry, views, epilogue, io_f16 flags); p->w = the mode | 16 packing
+int fd_launch_conv_f16k64(const fd_conv_params* p, ConvArgs& a, hipStream_t stream) {
+    FD_REQUIRE(p->precision == FD_PREC_F16 && p->mode != FD_CONV_STEM && p->Cin % 64 == 0 && a.vec_epi && p->ksplit <= 1 && !p->gate && !p->gn_stats && !p->x2 &&
+                   (p->act == FD_ACT_NONE || p->act == FD_ACT_RELU || p->act == FD_ACT_SILU),
+               FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_F16K64 needs FD_PREC_F16, Cin %% 64 == 0, 4-channel aligned output / residual views, ReLU / SiLU / no "
+                                 "activation, no split-K / gate / gn_stats / x2");
+    FD_REQUIRE(p->x_cs % 8 == 0 && p->x_co % 8 == 0, FD_E_UNSUPPORTED, "fd_conv2d: FD_TILE_F16K64 fetches eight channels per lane: x_cs and x_co must be multiples of 8");
+    a.ntaps = p->KH * p->KW;
+    a.KT = a.ntaps * (p->Cin / 64);
+    const long wb = (long)p->Cout * a.KT * 128;
+    FD_REQUIRE(wb < 0xC0000000L, FD_E_UNSUPPORTED, "fd_conv2d: weight buffer exceeds 3 GiB");
+    a.w_bytes = (unsigned)wb;
+    auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
+    // the largest tile that still gives >= 2 workgroups per CU; narrow layers take the 64-wide tiles
+    if (a.Cout > 64 && blocks(128, 128) >= 512) return launch_f16k64<2, 2, 2, 2>(a, stream);
+    if (blocks(128, 64) >= 512) return launch_f16k64<2, 2, 2, 1>(a, stream);
+    return launch_f16k64<2, 2, 1, 1>(a, stream);
+}

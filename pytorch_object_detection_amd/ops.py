@@ -605,6 +605,25 @@ def pack_conv_weight_hip(w: torch.Tensor, scale: Optional[torch.Tensor] = None, 
     return out
 
 
+F16K64 = os.environ.get("FD_AMP_K64", "1") != "0"       # "0": AMP convs stay on the K-tile-32 f16 instantiations of the fp32 kernel
+
+
+def f16k64_ok(Cin: int, Cout: int) -> bool:
+    """Shapes FD_TILE_F16K64 covers (reduction width a multiple of 64, 4-channel aligned output)."""
+    return Cin % 64 == 0 and Cout % 4 == 0
+
+
+def pack_conv_weight_f16k64(w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False) -> torch.Tensor:
+    """OIHW fp32 -> FD_TILE_F16K64's operand: f16 [N][K/64][KH][KW][64] (dgrad=True: the flipped / transposed / per-Cout scaled weights of the data-gradient conv),
+    one HIP launch (fd_pack_conv_weight_f32 mode | 16); returned as an fp32-typed buffer of half the element count."""
+    w = w.detach().contiguous()
+    co, ci, kh, kw = w.shape
+    out = torch.empty(co * ci * kh * kw // 2, dtype=torch.float32, device=w.device)
+    check(_lib.lib().fd_pack_conv_weight_f32(w.data_ptr(), scale.data_ptr() if (scale is not None and dgrad) else None,
+                                             out.data_ptr(), co, ci, kh, kw, (1 if dgrad else 0) | 16, _stream()), "fd_pack_conv_weight_f32")
+    return out
+
+
 def pack_conv_weight_wino(w: torch.Tensor, scale: Optional[torch.Tensor] = None, dgrad: bool = False) -> torch.Tensor:
     """OIHW [Cout, Cin, 3, 3] -> the Winograd F(2x2, 3x3) operand of FD_TILE_WINOGRAD: U = G g G^T per (cout, cin), packed
     [ceil(N/32)][K/8][16][32][8] (N = Cout, K = Cin; dgrad=True: the flipped / transposed weights of the data-gradient conv,
@@ -794,11 +813,12 @@ def conv_dgrad_strided(dy: Rows, w: torch.Tensor, scale: Optional[torch.Tensor],
             if Ta == 0 or Tb == 0 or Ia == 0 or Jb == 0:
                 continue
             sub = wd[:, :, r0::stride, q0::stride].contiguous()                      # [Cout, Cin, Ta, Tb]
-            out = torch.empty(Cin, Cout // 32, Ta, Tb, 32, dtype=torch.float32, device=w.device)
+            k64 = bool(precision) and F16K64 and f16k64_ok(Cout, Cin)               # AMP: the class convs on FD_TILE_F16K64 where the widths allow
+            out = torch.empty(Cin * Cout * Ta * Tb // (2 if k64 else 1), dtype=torch.float32, device=w.device)
             check(_lib.lib().fd_pack_conv_weight_f32(sub.data_ptr(), scale.data_ptr() if scale is not None else None, out.data_ptr(),
-                                                     Cout, Cin, Ta, Tb, 1 | (4 if precision else 0), _stream()), "fd_pack_conv_weight_f32")
+                                                     Cout, Cin, Ta, Tb, 1 | (16 if k64 else 4 if precision else 0), _stream()), "fd_pack_conv_weight_f32")
             conv_call(dy, segs, out, dx, Cin=Cout, Cout=Cin, k=Ta, kw=Tb, stride=1, pad=0, res=res, res_mask=res_mask,
-                      out_hw=(Ia, Jb), scatter=(stride, stride, a, b, H, W), precision=precision)()
+                      out_hw=(Ia, Jb), scatter=(stride, stride, a, b, H, W), precision=precision, tile=_lib.F16K64_TILE if k64 else 0)()
     return True
 
 

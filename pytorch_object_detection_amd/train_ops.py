@@ -54,6 +54,17 @@ def amp_prec() -> int:
     return _lib.PREC_F32
 
 
+AMP_K64 = os.environ.get("FD_AMP_K64", "1") != "0"      # "0": AMP convs stay on the single-plane f16 instantiations of the fp32 kernel (K-tiles of 32 channels)
+
+
+def amp_pack(prec: int, K: int, Cout: int = 4):
+    """PACKS.get's `f16` for a dense conv of reduction width K under the current arithmetic: False (fp32), True (the (hi, lo) f16 pair format of the fp32 kernel's f16
+    instantiations) or 2 (FD_TILE_F16K64: K-tiles of 64 channels, fd_conv_f16.hip -- whenever the layer's widths allow)."""
+    if not prec:
+        return False
+    return 2 if (AMP_K64 and ops.f16k64_ok(K, Cout)) else True
+
+
 _STOCK = os.environ.get("FD_TRAIN_STOCK_CONV") == "1"   # diagnostic: route every layer to the stock ops (timing comparisons)
 STATS = {"cl_copies": 0, "stock_fallbacks": 0}           # activation-sized layout copies made on entry / stock-op fallbacks taken (both should stay 0)
 # FD_STRICT=1 (the test suite's default, tests/conftest.py): a layer of the TRAINING forward / backward that the HIP kernels do not cover
@@ -201,13 +212,17 @@ class _PackCache:
         self.table = None           # (signature, device tensor of fd_pack_job, max_elems)
 
     @staticmethod
-    def _key(w, scale, dgrad, wino=0, f16=False):       # wino: 0 = direct kernel's packing, 1 = Winograd F(2x2, 3x3), 2 = Winograd F(4x4, 3x3)
+    def _key(w, scale, dgrad, wino=0, f16=False):       # wino: 0 = direct kernel's packing, 1 = Winograd F(2x2, 3x3), 2 = Winograd F(4x4, 3x3); f16: False / True (hi, lo pair) / 2 (K-tile-64 f16)
         return (w.data_ptr(), tuple(w.shape), bool(dgrad), scale.data_ptr() if (scale is not None and dgrad) else 0,
-                (2 if f16 else 0) + (1 if int(wino) == 1 else 0) + (8 if int(wino) == 2 else 0))
+                (16 if f16 == 2 else 2 if f16 else 0) + (1 if int(wino) == 1 else 0) + (8 if int(wino) == 2 else 0))
 
     @staticmethod
     def _pack_now(w, scale, dgrad, wino, f16=False):
         if not wino:
+            if f16 == 2:       # FD_TILE_F16K64's operand (fd_conv_f16.hip)
+                out = ops.pack_conv_weight_f16k64(w, scale, dgrad)
+                out._fd_prec, out._fd_k64, out._fd_cout = _lib.PREC_F16, True, (w.shape[1] if dgrad else w.shape[0])
+                return out
             out = ops.pack_conv_weight_hip(w, scale, dgrad, f16)
             out._fd_prec = _lib.PREC_F16 if f16 else _lib.PREC_F32
             return out
@@ -245,7 +260,7 @@ class _PackCache:
                 ops.check(_lib.lib().fd_wino_pack_weights_f32(w.data_ptr(), sp, e[3].data_ptr(), co, ci, 1 if dgrad else 0, ops._stream()),
                           "fd_wino_pack_weights_f32")
             else:
-                ops.check(_lib.lib().fd_pack_conv_weight_f32(w.data_ptr(), sp, e[3].data_ptr(), co, ci, kh, kw, (1 if dgrad else 0) | (4 if f16 else 0),
+                ops.check(_lib.lib().fd_pack_conv_weight_f32(w.data_ptr(), sp, e[3].data_ptr(), co, ci, kh, kw, (1 if dgrad else 0) | (16 if f16 == 2 else 4 if f16 else 0),
                                                              ops._stream()), "fd_pack_conv_weight_f32")
             e[4] = w._version
         return e[3]
@@ -274,7 +289,7 @@ class _PackCache:
                 co, ci, kh, kw = key[1]
                 j.w, j.scale, j.out = key[0], (e[1].data_ptr() if (e[1] is not None and e[2]) else None), e[3].data_ptr()
                 j.Cout, j.Cin, j.KH, j.KW, j.mode = co, ci, kh, kw, ((8 if key[4] & 8 else 2 if key[4] & 1 else 0) + (1 if e[2] else 0)
-                                                                     + (4 if key[4] & 2 else 0))
+                                                                     + (4 if key[4] & 2 else 0) + (16 if key[4] & 16 else 0))
                 mx = max(mx, co * ci * kh * kw)
             raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).clone()
             dev = next(iter(live.values()))[3].device
@@ -312,6 +327,10 @@ def _conv_launch(x: torch.Tensor, segs: Segs, w_packed: torch.Tensor, y: torch.T
     if wino_cout:        # the Winograd packing (PACKS.get(..., wino=True)): fd_conv_wino.hip, no tile choice
         ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=x.shape[1], Cout=wino_cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                       shift=shift, res=_r(res) if res is not None else None, act=act, res_mask=res_mask, tile=getattr(w_packed, "_fd_wino_tile", _lib.WINO_TILE))()
+        return
+    if getattr(w_packed, "_fd_k64", False):      # AMP: f16 operands on K-tiles of 64 channels (the library picks the block tile)
+        ops.conv_call(_r(x), segs, w_packed, _r(y), Cin=x.shape[1], Cout=w_packed._fd_cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift,
+                      res=_r(res) if res is not None else None, act=act, res_mask=res_mask, precision=_lib.PREC_F16, tile=_lib.F16K64_TILE)()
         return
     Cin, Cout = x.shape[1], w_packed.shape[0]
     out_rows = y.shape[0]
@@ -387,7 +406,7 @@ class _ConvRows(torch.autograd.Function):
         Cout, _, k, _ = weight.shape
         so = ops.conv_out_segs(segs, k, stride, pad, dil)
         y = torch.empty(so.rows, Cout, dtype=torch.float32, device=x.device)
-        _conv_launch(x, segs, PACKS.get(weight, wino=_wino(x.shape[1], Cout, k, stride, pad, dil, segs, prec), f16=bool(prec)), y, k=k, stride=stride,
+        _conv_launch(x, segs, PACKS.get(weight, wino=_wino(x.shape[1], Cout, k, stride, pad, dil, segs, prec), f16=amp_pack(prec, x.shape[1], Cout)), y, k=k, stride=stride,
                      pad=pad, dil=dil, scale=scale, shift=shift.detach().contiguous() if shift is not None else None,
                      res=residual.contiguous() if residual is not None else None, act=act)
         ctx.save_for_backward(x, weight, scale, y if act == ACT_RELU else None)
@@ -410,7 +429,7 @@ class _ConvRows(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if stride == 1 and Cout % 32 == 0:
                 gx = torch.empty_like(x)
-                _conv_launch(g, so, PACKS.get(weight, scale, dgrad=True, wino=_wino(Cout, Cin, k, stride, dil * (k - 1) - pad, dil, so, prec), f16=bool(prec)),
+                _conv_launch(g, so, PACKS.get(weight, scale, dgrad=True, wino=_wino(Cout, Cin, k, stride, dil * (k - 1) - pad, dil, so, prec), f16=amp_pack(prec, Cout, Cin)),
                              gx, k=k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
             elif segs.nseg == 1 and stride > 1 and dil == 1 and (gx := _strided_dgrad(g, weight, scale, segs, k, stride, pad, prec=prec)) is not None:
                 pass                                   # strided layer: one exact-FLOP launch per parity class (ops.conv_dgrad_strided)
@@ -483,15 +502,15 @@ class _BottleneckRows(torch.autograd.Function):
         y1 = torch.empty(segs.rows, P, dtype=st, device=dev)
         y2 = torch.empty(so.rows, P, dtype=st, device=dev)
         out = torch.empty(so.rows, C4, dtype=st, device=dev)
-        _conv_launch(x, segs, PACKS.get(w1, f16=h), y1, k=1, stride=1, pad=0, dil=1, scale=c1[0], shift=c1[1], act=ACT_RELU)
-        _conv_launch(y1, segs, PACKS.get(w2, wino=_wino(P, P, 3, stride, 1, 1, segs, prec), f16=h), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0],
+        _conv_launch(x, segs, PACKS.get(w1, f16=amp_pack(prec, w1.shape[1], w1.shape[0])), y1, k=1, stride=1, pad=0, dil=1, scale=c1[0], shift=c1[1], act=ACT_RELU)
+        _conv_launch(y1, segs, PACKS.get(w2, wino=_wino(P, P, 3, stride, 1, 1, segs, prec), f16=amp_pack(prec, P, P)), y2, k=3, stride=stride, pad=1, dil=1, scale=c2[0],
                      shift=c2[1], act=ACT_RELU)
         if wd is not None:
             idt = torch.empty(so.rows, C4, dtype=st, device=dev)
-            _conv_launch(x, segs, PACKS.get(wd, f16=h), idt, k=1, stride=stride, pad=0, dil=1, scale=cd[0], shift=cd[1])
+            _conv_launch(x, segs, PACKS.get(wd, f16=amp_pack(prec, wd.shape[1], wd.shape[0])), idt, k=1, stride=stride, pad=0, dil=1, scale=cd[0], shift=cd[1])
         else:
             idt = x
-        _conv_launch(y2, so, PACKS.get(w3, f16=h), out, k=1, stride=1, pad=0, dil=1, scale=c3[0], shift=c3[1], res=idt,
+        _conv_launch(y2, so, PACKS.get(w3, f16=amp_pack(prec, w3.shape[1], w3.shape[0])), out, k=1, stride=1, pad=0, dil=1, scale=c3[0], shift=c3[1], res=idt,
                      act=ACT_RELU)
         ctx.save_for_backward(x, y1, y2, out, w1, w2, w3, wd, c1[0], c2[0], c3[0], cd[0] if wd is not None else None)
         ctx.geom = (segs, so, stride, prec)
@@ -512,12 +531,12 @@ class _BottleneckRows(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             gw3 = wg(y2, g, so, P, C4, 1, 1, 0, s3)
         g2 = torch.empty_like(y2)                                                    # d/d(conv2 output), ReLU-masked in the epilogue
-        _conv_launch(g, so, PACKS.get(w3, s3, dgrad=True, f16=h), g2, k=1, stride=1, pad=0, dil=1, res=y2, res_mask=True)
+        _conv_launch(g, so, PACKS.get(w3, s3, dgrad=True, f16=amp_pack(prec, w3.shape[0], w3.shape[1])), g2, k=1, stride=1, pad=0, dil=1, res=y2, res_mask=True)
         if ctx.needs_input_grad[2]:
             gw2 = wg(y1, g2, segs, P, P, 3, stride, 1, s2)
         if stride == 1:
             g1 = torch.empty_like(y1)
-            _conv_launch(g2, so, PACKS.get(w2, s2, dgrad=True, wino=_wino(w2.shape[0], w2.shape[1], 3, 1, 1, 1, so, prec), f16=h), g1, k=3, stride=1, pad=1,
+            _conv_launch(g2, so, PACKS.get(w2, s2, dgrad=True, wino=_wino(w2.shape[0], w2.shape[1], 3, 1, 1, 1, so, prec), f16=amp_pack(prec, w2.shape[0], w2.shape[1])), g1, k=3, stride=1, pad=1,
                          dil=1, res=y1, res_mask=True)
         elif (g1 := _strided_dgrad(g2, w2, s2, segs, 3, stride, 1, res=y1, res_mask=True, prec=prec)) is not None:
             pass    # strided 3x3: four parity-class launches on the conv kernel, ReLU mask of y1 applied in their epilogues
@@ -536,7 +555,7 @@ class _BottleneckRows(torch.autograd.Function):
                 gid = g                                                             # identity path
             elif stride == 1:
                 gid = torch.empty_like(x)
-                _conv_launch(g, so, PACKS.get(wd, sd, dgrad=True, f16=h), gid, k=1, stride=1, pad=0, dil=1)
+                _conv_launch(g, so, PACKS.get(wd, sd, dgrad=True, f16=amp_pack(prec, wd.shape[0], wd.shape[1])), gid, k=1, stride=1, pad=0, dil=1)
             elif (gid := _strided_dgrad(g, wd, sd, segs, 1, stride, 0, prec=prec)) is not None:
                 pass    # 1x1 stride-2 downsample: the (0, 0) parity class is a plain GEMM scattered into a zeroed dX
             else:
@@ -546,7 +565,7 @@ class _BottleneckRows(torch.autograd.Function):
                                                                    wd.detach() * sd.view(-1, 1, 1, 1), None, [stride, stride], [0, 0],
                                                                    [1, 1], False, [0, 0], 1, [True, False, False])[0])
             gx = torch.empty_like(x)                                                # conv1's data gradient + the identity gradient
-            _conv_launch(g1, segs, PACKS.get(w1, s1, dgrad=True, f16=h), gx, k=1, stride=1, pad=0, dil=1, res=gid)
+            _conv_launch(g1, segs, PACKS.get(w1, s1, dgrad=True, f16=amp_pack(prec, w1.shape[0], w1.shape[1])), gx, k=1, stride=1, pad=0, dil=1, res=gid)
         return gx, gw1, gw2, gw3, gwd, None, None, None, None, None, None, None
 
 

@@ -109,6 +109,70 @@ def test_conv_f16_activation_maps_in_hbm(case, io):
         ops.conv_call(ops.Rows(x.half()), segs, ops.pack_conv_weight(w.to(DEV)), ops.new_rows(so.rows, Cout, DEV), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil)
 
 
+K64_CASES = [
+    # Cin, Cout, k, stride, pad, dil, hw (pyramid), act, residual
+    (64, 256, 1, 1, 0, 1, [(20, 24)], ACT_RELU, True),
+    (256, 64, 1, 1, 0, 1, [(20, 24)], ACT_RELU, False),
+    (128, 128, 3, 2, 1, 1, [(21, 13)], ACT_RELU, False),
+    (256, 256, 3, 1, 2, 2, [(12, 12)], ACT_NONE, False),
+    (256, 512, 3, 1, 1, 1, [(10, 12), (5, 6), (3, 3), (1, 2)], ACT_NONE, False),
+    (512, 128, 1, 2, 0, 1, [(14, 10)], ACT_NONE, False),
+    (2048, 256, 1, 1, 0, 1, [(6, 7)], ACT_RELU, False),
+    (64, 64, 3, 1, 1, 1, [(40, 36)], ACT_RELU, True),           # enough rows for the 128-row tiles
+    (128, 512, 1, 1, 0, 1, [(64, 48)], ACT_RELU, True),         # ... and the 128 x 128 one
+]
+
+
+@pytest.mark.parametrize("case", K64_CASES)
+@pytest.mark.parametrize("io", [(False, False, False), (True, True, True), (True, False, False), (False, True, True)])
+def test_conv_f16_on_k_tiles_of_64_channels(case, io):
+    """FD_TILE_F16K64 (fd_conv_f16.hip): the AMP step's conv kernel -- f16 operands, fp32 accumulation, K-tiles of 64 channels, activation maps in HBM as f16 or fp32.
+    Oracle: the same op on the CPU with operands rounded to f16 and fp32 accumulation (tolerance = summation order); an f16 output is the fp32 result of the same launch
+    rounded once (bit-exact between the two output types); channel views with NaN neighbours; residual as addend and as ReLU mask."""
+    Cin, Cout, k, stride, pad, dil, hw, act, use_res = case
+    x16, y16, r16 = io
+    gen = torch.Generator().manual_seed(Cin + Cout + k + 11)
+    B = 2
+    xs = [h(torch.randn(B, Cin, a, b, generator=gen)) for a, b in hw]
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * k * k)
+    scale, shift = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen)
+    segs = Segs.make(B, hw)
+    so = ops.conv_out_segs(segs, k, stride, pad, dil)
+    rs = [h(torch.randn(B, Cout, a, b, generator=gen)) for a, b in so.level_hw()]
+    x = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cin) for t in xs]).to(DEV)
+    r = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cout) for t in rs]).to(DEV)
+    wp = ops.pack_conv_weight_f16k64(w.to(DEV))
+
+    def buf(t, f16, co, C_):
+        b = torch.full((t.shape[0], C_ + 16), float("nan"), dtype=torch.float16 if f16 else torch.float32, device=DEV)
+        b[:, co:co + C_] = t
+        return b
+    for res_mask in ((False, True) if use_res else (False,)):
+        xb, rb = buf(x, x16, 8, Cin), buf(r, r16, 4, Cout)
+        yb = torch.full((so.rows, Cout + 16), float("nan"), dtype=torch.float16 if y16 else torch.float32, device=DEV)
+        kw = dict(Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale.to(DEV), shift=shift.to(DEV), act=act, precision=_lib.PREC_F16,
+                  res_mask=res_mask, tile=_lib.F16K64_TILE)
+        ops.conv_call(ops.Rows(xb, 8, Cin), segs, wp, ops.Rows(yb, 4, Cout), res=ops.Rows(rb, 4, Cout) if use_res else None, **kw)()
+        assert torch.isnan(yb[:, :4]).all() and torch.isnan(yb[:, 4 + Cout:]).all(), "wrote outside its channel view"
+        got = yb[:, 4:4 + Cout].float().cpu()
+        assert not torch.isnan(got).any()
+        for lv, ((a, b), xl, rl) in enumerate(zip(so.level_hw(), xs, rs)):
+            ref = F.conv2d(xl, h(w), None, stride, pad, dil) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+            if use_res:
+                ref = torch.where(rl > 0, ref, torch.zeros_like(ref)) if res_mask else ref + rl
+            if act == ACT_RELU:
+                ref = F.relu(ref)
+            g = got[so.m_start[lv]:so.m_start[lv + 1]].reshape(B, a, b, Cout).permute(0, 3, 1, 2)
+            tol = 2e-3 if y16 else 2e-5
+            np.testing.assert_allclose(g.numpy(), ref.numpy(), atol=tol, rtol=tol, err_msg=f"level {lv}")
+        if y16:      # ... and exactly the fp32-output launch, rounded once
+            y32 = torch.empty(so.rows, Cout, device=DEV)
+            ops.conv_call(ops.Rows(xb, 8, Cin), segs, wp, ops.Rows(y32), res=ops.Rows(rb, 4, Cout) if use_res else None, **kw)()
+            assert torch.equal(yb[:, 4:4 + Cout], y32.half())
+    with pytest.raises(Exception, match="F16K64"):
+        ops.conv_call(ops.Rows(x), segs, wp, ops.new_rows(so.rows, Cout, DEV), Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, tile=_lib.F16K64_TILE)()
+
+
 def test_pack_f16_pair_format():
     gen = torch.Generator().manual_seed(1)
     w = torch.randn(96, 64, 3, 3, generator=gen)
