@@ -605,7 +605,11 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
         # statistics over all ranks, on the HIP kernels with one fp64 all-reduce per layer and direction (train_ops._SyncBatchNormTrainRows)
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
     net.train()
-    opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    # --amp: the fused SGD (torch.optim.SGD(fused=True): same update, one multi-tensor launch).  It takes GradScaler's found_inf tensor and skips the update ON THE DEVICE,
+    # so scaler.step does not call .item(): with the plain optimizer every step ends in a host synchronisation, and the AMP step -- 21 ms of kernels behind ~20 ms of
+    # Python / autograd enqueue work -- drains its pipeline once per step (tools/train_host_time.py: 25.1 ms synchronized = 25.1 ms on the host).  FD_BENCH_FUSED_OPT=0: plain.
+    fused_opt = bool(getattr(args, "amp", False)) and os.environ.get("FD_BENCH_FUSED_OPT", "1") != "0"
+    opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-3, momentum=0.9, weight_decay=1e-4, **({"fused": True} if fused_opt else {}))
     gen = torch.Generator().manual_seed(1000 + rank)
     x = torch.randn(batch, 3, size, size, generator=gen).to(dev)
     c = torch.rand(batch, 8, 2, generator=gen) * (size - 112) + 50
@@ -667,9 +671,10 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
     if amp:   # the f16 side of the AMP step: the head tower 3x3 forward (256 -> 512, five levels) on v_mfma_f32_32x32x16_f16, against the dense f16 peak
         from pytorch_object_detection_amd import _lib as L
         wt = torch.randn(512, 256, 3, 3, device=dev) / 48.0
-        wp16 = ops.pack_conv_weight_hip(wt, f16=True)
+        k64 = ops.F16K64 and ops.f16k64_ok(256, 512)        # the kernel the AMP step runs this layer on (FD_AMP_K64=0: round 3's K-tile-32 instantiation)
+        wp16 = ops.pack_conv_weight_f16k64(wt) if k64 else ops.pack_conv_weight_hip(wt, f16=True)
         yt = ops.Rows(torch.empty(segs.rows, 512, device=dev))
-        ft = ops.conv_call(xr, segs, wp16, yt, Cin=256, Cout=512, k=3, pad=1, precision=L.PREC_F16)
+        ft = ops.conv_call(xr, segs, wp16, yt, Cin=256, Cout=512, k=3, pad=1, precision=L.PREC_F16, tile=L.F16K64_TILE if k64 else 0)
         for _ in range(3):
             ft()
         e0.record()
@@ -679,7 +684,8 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
         e1.synchronize()
         tms = e0.elapsed_time(e1) / 10
         tfl = 2 * segs.rows * 512 * 256 * 9
-        amp_roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<..., H1> head tower 3x3 forward (cls_conv+reg_conv fused, 5 levels), f16 operands / fp32 accumulate",
+        amp_roof = {"bound": "mfma", "kernel": ("conv_f16k64_kernel (FD_TILE_F16K64: K-tiles of 64 channels)" if k64 else "conv_igemm_kernel<..., H1>") +
+                              " head tower 3x3 forward (cls_conv+reg_conv fused, 5 levels), f16 operands / fp32 accumulate, fp32 activation map in (the head's maps are fp32 in HBM)",
                     "instruction": "v_mfma_f32_32x32x16_f16", "achieved": round(tfl / (tms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                     "frac": round(tfl / (tms * 1e-3) / 1e12 / 2500.0, 4), "traffic": None, "flops_per_launch": tfl, "avg_launch_ms": round(tms, 4)}
     print(json.dumps({
@@ -691,6 +697,8 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
         "config": {"workload": f"HISFCOS-R50 train.py step, {batch} x {size}x{size} images/GPU, {ncls} classes, 8 GT boxes/image, "
                                "HIP forward/backward/target/loss kernels" + (", DDP gradient all-reduce + SyncBatchNorm statistics all-reduces over RCCL" if use_dist else ""),
                    "batchnorm": "backbone frozen (eval); FPN BatchNorms on batch statistics" + (" over all ranks (SyncBatchNorm on the HIP statistics kernels)" if use_dist else ""),
+                   "optimizer": "SGD momentum 0.9" + (", fused=True (GradScaler's found_inf handled on the device: no host synchronisation per step)" if fused_opt else ""),
+                   "amp_activation_maps": ("f16 in HBM inside the ResNet bottlenecks (train_ops.AMP_F16_STORE), fp32 elsewhere" if amp else None),
                    "global_batch": batch * world, "parallelism": f"dp{world} (DistributedDataParallel)"},
         "roofline": {"bound": "mfma", "kernel": ("conv_wgrad_f16_kernel" if wprec else "conv_wgrad_kernel") + " (head tower 3x3 weight gradient, 5 levels) + ordered slab reduce",
                      "instruction": "v_mfma_f32_32x32x16_f16" if wprec else "v_mfma_f32_32x32x2_f32", "achieved": round(ach, 2),
