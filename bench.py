@@ -674,7 +674,10 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
         k64 = ops.F16K64 and ops.f16k64_ok(256, 512)        # the kernel the AMP step runs this layer on (FD_AMP_K64=0: round 3's K-tile-32 instantiation)
         wp16 = ops.pack_conv_weight_f16k64(wt) if k64 else ops.pack_conv_weight_hip(wt, f16=True)
         yt = ops.Rows(torch.empty(segs.rows, 512, device=dev))
-        ft = ops.conv_call(xr, segs, wp16, yt, Cin=256, Cout=512, k=3, pad=1, precision=L.PREC_F16, tile=L.F16K64_TILE if k64 else 0)
+        from pytorch_object_detection_amd import train_ops as TO
+        z16 = bool(k64 and TO.AMP_F16_STORE)                  # the step stores the towers' input z as f16 (HISFCOSHead.train_forward_rows: conv_rows(pw2, ..., out_f16=True))
+        xin = ops.Rows(xr.tensor().half().contiguous()) if z16 else xr
+        ft = ops.conv_call(xin, segs, wp16, yt, Cin=256, Cout=512, k=3, pad=1, precision=L.PREC_F16, tile=L.F16K64_TILE if k64 else 0)
         for _ in range(3):
             ft()
         e0.record()
@@ -685,7 +688,8 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
         tms = e0.elapsed_time(e1) / 10
         tfl = 2 * segs.rows * 512 * 256 * 9
         amp_roof = {"bound": "mfma", "kernel": ("conv_f16k64_kernel (FD_TILE_F16K64: K-tiles of 64 channels)" if k64 else "conv_igemm_kernel<..., H1>") +
-                              " head tower 3x3 forward (cls_conv+reg_conv fused, 5 levels), f16 operands / fp32 accumulate, fp32 activation map in (the head's maps are fp32 in HBM)",
+                              " head tower 3x3 forward (cls_conv + reg_conv as one 256 -> 512 launch, 5 levels), f16 operands / fp32 accumulate, " +
+                              ("f16 activation map in (the step stores the towers' input as f16), fp32 out" if z16 else "fp32 activation map in"),
                     "instruction": "v_mfma_f32_32x32x16_f16", "achieved": round(tfl / (tms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                     "frac": round(tfl / (tms * 1e-3) / 1e12 / 2500.0, 4), "traffic": None, "flops_per_launch": tfl, "avg_launch_ms": round(tms, 4)}
     print(json.dumps({

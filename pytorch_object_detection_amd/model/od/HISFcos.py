@@ -222,7 +222,7 @@ class HISFCOSHead(PlannedModule):
         f, segs = T.pyramid_rows(inputs)
         h = T.groupnorm_rows(self.gn1, T.conv_rows(self.pw1, f, segs), segs, ACT_RELU)
         h = T.groupnorm_rows(self.gn2, T.dw_rows(self.dw1, h, segs), segs, ACT_SILU)
-        z = T.conv_rows(self.pw2, h, segs, residual=f)
+        z = T.conv_rows(self.pw2, h, segs, residual=f, out_f16=True)      # (AMP: z feeds the two tower convs only -- stored as f16, read by them as it is)
         c = T.groupnorm_rows(self.cls_conv[1], T.conv_rows(self.cls_conv[0], z, segs), segs, self.cls_conv[2])
         r = T.groupnorm_rows(self.reg_conv[1], T.conv_rows(self.reg_conv[0], z, segs), segs, self.reg_conv[2])
         cls = T.conv_rows(self.cls_logits, c, segs, pad_out=True)

@@ -398,17 +398,24 @@ class _ConvRows(torch.autograd.Function):
     """y = act(conv(x, w) * scale + shift + residual) on rows; scale is a constant (frozen BN), shift may need a gradient."""
 
     @staticmethod
-    @_fwd32
-    def forward(ctx, x, weight, scale, shift, residual, segs, stride, pad, dil, act, prec=0):
+    @_fwd_keep
+    def forward(ctx, x, weight, scale, shift, residual, segs, stride, pad, dil, act, prec=0, out_f16=False):
+        # (no cast on entry: under AMP with AMP_F16_STORE the FD_PREC_F16 kernels read an f16 or an fp32 map as it is; out_f16 -- set by the caller for an edge whose
+        # consumers are conv nodes too -- stores the output as f16.  Otherwise everything is fp32, as with torch.amp's cast_inputs.)
         if act not in (ACT_NONE, ACT_RELU):
             raise FdError("_ConvRows differentiates ACT_NONE / ACT_RELU epilogues only (use act_rows for SiLU: it keeps the pre-activation)")
+        f16_io = bool(prec) and AMP_F16_STORE
+        if not f16_io or x.dtype not in (torch.float16, torch.float32):
+            x = x.float()
+            residual = residual.float() if residual is not None else None
         x = x.contiguous()
         Cout, _, k, _ = weight.shape
         so = ops.conv_out_segs(segs, k, stride, pad, dil)
-        y = torch.empty(so.rows, Cout, dtype=torch.float32, device=x.device)
+        y = torch.empty(so.rows, Cout, dtype=torch.float16 if (f16_io and out_f16) else torch.float32, device=x.device)
         _conv_launch(x, segs, PACKS.get(weight, wino=_wino(x.shape[1], Cout, k, stride, pad, dil, segs, prec), f16=amp_pack(prec, x.shape[1], Cout)), y, k=k, stride=stride,
-                     pad=pad, dil=dil, scale=scale, shift=shift.detach().contiguous() if shift is not None else None,
+                     pad=pad, dil=dil, scale=scale.float() if scale is not None else None, shift=shift.detach().float().contiguous() if shift is not None else None,
                      res=residual.contiguous() if residual is not None else None, act=act)
+        ctx.res_dtype = residual.dtype if residual is not None else None
         ctx.save_for_backward(x, weight, scale, y if act == ACT_RELU else None)
         ctx.geom = (segs, so, stride, pad, dil, act, prec)
         return y
@@ -420,12 +427,12 @@ class _ConvRows(torch.autograd.Function):
         segs, so, stride, pad, dil, act, prec = ctx.geom
         g = resolve_pending(gy).contiguous()
         if act == ACT_RELU:
-            g = relu_mask(g, y)
+            g = relu_mask(g if g.dtype == y.dtype else g.to(y.dtype), y)
         Cin = x.shape[1]
         Cout, _, k, _ = weight.shape
         gx = gw = gshift = gres = None
         if ctx.needs_input_grad[4]:
-            gres = g
+            gres = g if g.dtype == ctx.res_dtype else g.to(ctx.res_dtype)
         if ctx.needs_input_grad[0]:
             if stride == 1 and Cout % 32 == 0:
                 gx = torch.empty_like(x)
@@ -447,14 +454,15 @@ class _ConvRows(torch.autograd.Function):
             gw = ops.conv_wgrad(_r(x), _r(g), segs, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale,
                                 oihw=True, precision=prec)
         if ctx.needs_input_grad[3]:
-            gshift = g.sum(dim=0)
-        return gx, gw, None, gshift, gres, None, None, None, None, None, None
+            gshift = g.sum(dim=0, dtype=torch.float32)
+        return gx, gw, None, gshift, gres, None, None, None, None, None, None, None
 
 
 def conv_rows(m: nn.Conv2d, x: torch.Tensor, segs: Segs, bn: Optional[nn.Module] = None, act: int = ACT_NONE,
-              residual: Optional[torch.Tensor] = None, pad_out: bool = False) -> torch.Tensor:
+              residual: Optional[torch.Tensor] = None, pad_out: bool = False, out_f16: bool = False) -> torch.Tensor:
     """HIP conv layer on a rows buffer (must be covered: check with `covered(m, bn, x)`).  With pad_out the output
-    channels are zero-padded to a multiple of 32 inside (so the data gradient runs on the HIP kernel) and sliced back."""
+    channels are zero-padded to a multiple of 32 inside (so the data gradient runs on the HIP kernel) and sliced back.
+    out_f16: under AMP (and AMP_F16_STORE) the output map is stored as f16 -- for edges whose consumers are conv nodes (they read f16 maps directly)."""
     scale = shift = None
     if bn is not None:
         scale, shift = _bn_fold(bn)
@@ -468,7 +476,7 @@ def conv_rows(m: nn.Conv2d, x: torch.Tensor, segs: Segs, bn: Optional[nn.Module]
             scale, shift = F.pad(scale, (0, padn), value=1.0), F.pad(shift, (0, padn))
     if b is not None:
         shift = b if scale is None else b * scale + shift
-    y = _ConvRows.apply(x, w, scale, shift, residual, segs, m.stride[0], _pad_of(m), m.dilation[0], act, amp_prec())
+    y = _ConvRows.apply(x, w, scale, shift, residual, segs, m.stride[0], _pad_of(m), m.dilation[0], act, amp_prec(), out_f16)
     return y[:, :Cout] if padn else y
 
 
