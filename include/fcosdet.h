@@ -396,6 +396,21 @@ int32_t fd_dwconv2d_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float
                          const float* shift, float* y, int32_t y_cs, int32_t y_co, int32_t N, int32_t H, int32_t W,
                          int32_t C, int32_t K, int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo,
                          int32_t act, fd_stream_t stream);
+/* MBConv expand -> depthwise in ONE kernel (efficientnet_pytorch 0.7.1 MBConvBlock.forward behind model/backbone/efficientnetv1.py:11-26):
+ *     y = swish(bn1(dwconv_kxk(swish(bn0(conv1x1(x, W_expand))))))   k in {3, 5}, stride in {1, 2}, static "SAME" padding (pad_top / pad_left; zeros on every side)
+ * without the expanded map (six times the block input) ever reaching HBM: a workgroup stages the input patch of one TO x TO output tile in LDS, computes the expand
+ * GEMM of the patch on the fp32 MFMA 32 expanded channels at a time and runs the depthwise conv from LDS.  It also writes the squeeze-excitation pooling's partial
+ * sums -- pool[n][tile][c], fd_mbconv_pool_bytes() bytes -- so fd_se_gate_from_pool needs no pass over y.  Cin % 8 == 0 in 8 .. 48, mid % 4 == 0.
+ * w_expand_frag: [ceil(mid / 32)][Cin / 8][2][32][4] floats, element (cb, g, h, l, jj) = W_expand[32 cb + l][h * (Cin / 2) + 4 g + jj] (rows >= mid zero); w_dw: [K * K][mid].
+ * Results equal the separate launches up to the summation order of the expand GEMM. */
+int64_t fd_mbconv_pool_bytes(int32_t N, int32_t Ho, int32_t Wo, int32_t mid, int32_t K, int32_t stride);
+int32_t fd_mbconv_expand_dw_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w_expand_frag, const float* scale0, const float* shift0,
+                                 const float* w_dw, const float* scale1, const float* shift1, float* y, int32_t y_cs, int32_t y_co, float* pool,
+                                 int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t mid, int32_t K, int32_t stride, int32_t pad_top, int32_t pad_left,
+                                 int32_t Ho, int32_t Wo, fd_stream_t stream);
+/* The SE gates (fd_se_scale_nhwc with y = NULL) from those per-tile partial sums: T = tiles per image; workspace = fd_se_workspace_bytes(N, HW, C). */
+int32_t fd_se_gate_from_pool(const float* pool, int32_t T, const float* w1, const float* b1, const float* w2, const float* b2, int32_t N, int32_t HW,
+                             int32_t C, int32_t Cr, void* workspace, fd_stream_t stream);
 
 /* 3-channel stem convolution (EfficientNet._conv_stem 3x3 stride 2 + _bn0 + swish) on the [N][H][W][4] image layout
  * fd_nchw3_to_nhwc4 / fd_preprocess_u8_nhwc4 / fd_collate_u8_nhwc4 produce: y = act(conv(x)*scale + shift).

@@ -119,6 +119,9 @@ _SIGS = {
     "fd_conv1x1_b2b_f32": (_I, [C.POINTER(B2BParams), _P]),
     "fd_conv_workspace_bytes": (_L, [_L, _I, _I]),
     "fd_conv_sk_workspace_bytes": (_L, [_I]),
+    "fd_mbconv_pool_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
+    "fd_mbconv_expand_dw_nhwc": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fd_se_gate_from_pool": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "fd_conv_wgrad_workspace_bytes": (_L, [_L, _I, _I, _I, _I]),
     "fd_pack_conv_weight_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fd_pack_conv_weights_batch_f32": (_I, [_P, _I, _L, _P]),

@@ -1403,6 +1403,40 @@ extern "C" int32_t fd_se_scale_nhwc(const float* x, int32_t x_cs, int32_t x_co, 
 }
 
 
+// The squeeze-excitation gates of an MBConv block whose depthwise output came out of fd_mbconv_expand_dw_nhwc (fd_mbconv.hip): the pooled sums are the sums of that
+// kernel's per-tile partials -- pool[n][t][c], T tiles, added in tile order: deterministic -- so no pass over the map is needed; then the two FC layers as above.
+// The gates are left where fd_se_scale_nhwc(y = NULL) leaves them (the project conv's loader multiplies them in: fd_conv_params.gate).
+// chunk k of an image = tiles [k * tpc, (k + 1) * tpc): up to SE_MAXCHUNK workgroups per image and channel slice (one workgroup per image over 1 440 tiles was a
+// 0.17 ms latency chain on B3's first fused block); se_fc_kernel then adds the chunks in index order
+__global__ __launch_bounds__(256) void se_pool_reduce_kernel(const float* __restrict__ pool, int T, int tpc, int C, double* __restrict__ part) {
+    const int n = blockIdx.y, k = blockIdx.z;
+    const int t0 = k * tpc, t1 = min(T, t0 + tpc);
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+        const float* p = pool + (size_t)n * T * C + c;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int t = t0;
+        for (; t + 4 <= t1; t += 4) { a0 += p[(size_t)t * C]; a1 += p[(size_t)(t + 1) * C]; a2 += p[(size_t)(t + 2) * C]; a3 += p[(size_t)(t + 3) * C]; }
+        for (; t < t1; ++t) a0 += p[(size_t)t * C];
+        part[((size_t)n * SE_MAXCHUNK + k) * C + c] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+extern "C" int32_t fd_se_gate_from_pool(const float* pool, int32_t T, const float* w1, const float* b1, const float* w2, const float* b2, int32_t N, int32_t HW,
+                                        int32_t C, int32_t Cr, void* workspace, fd_stream_t stream) {
+    FD_REQUIRE(pool && w1 && w2 && workspace && T >= 1 && C % 4 == 0, FD_E_INVAL, "fd_se_gate_from_pool: bad arguments (C=%d T=%d)", C, T);
+    FD_REQUIRE(N >= 1 && N <= 65535 && HW >= 1 && Cr >= 1 && Cr <= SE_MAXCR && C <= SE_MAXC, FD_E_UNSUPPORTED,
+               "fd_se_gate_from_pool: C=%d Cr=%d unsupported (C <= %d, Cr <= %d)", C, Cr, SE_MAXC, SE_MAXCR);
+    FD_REQUIRE(((uintptr_t)workspace & 15) == 0, FD_E_INVAL, "fd_se_gate_from_pool: workspace not 16-byte aligned");
+    double* part = (double*)workspace;
+    float* gate = (float*)((char*)workspace + (size_t)N * SE_MAXCHUNK * C * sizeof(double));
+    const int tpc = (T + SE_MAXCHUNK - 1) / SE_MAXCHUNK, nchunk = (T + tpc - 1) / tpc;
+    hipLaunchKernelGGL(se_pool_reduce_kernel, dim3((C + 255) / 256, N, nchunk), dim3(256), 0, (hipStream_t)stream, pool, T, tpc, C, part);
+    FD_CHECK_LAUNCH("fd_se_gate_from_pool (reduce)");
+    hipLaunchKernelGGL(se_fc_kernel, dim3(N, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)part, nchunk, HW, C, Cr, w1, b1, w2, b2, gate);
+    FD_CHECK_LAUNCH("fd_se_gate_from_pool (fc)");
+    return FD_OK;
+}
+
 // ---- squeeze-excitation backward (train step; HisBlock.conv1_2, HISFcos.py:104, modules.py:107-121)
 //   y = x * g,  g = sigmoid(W2 s + b2),  s = silu(h),  h = W1 m + b1,  m = mean_hw(x)
 //   dgate[n][c] = sum_hw dy * x                     (pass 1, row chunks like the forward's pooling)

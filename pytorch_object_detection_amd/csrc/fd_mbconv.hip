@@ -242,3 +242,268 @@ extern "C" int32_t fd_collate_u8_nhwc4(const uint8_t* const* images_dev, const i
     FD_CHECK_LAUNCH("fd_collate_u8_nhwc4");
     return FD_OK;
 }
+
+// ------------------------------------------------------------------------------ MBConv: expand 1x1 -> depthwise k x k in ONE kernel
+// efficientnet_pytorch 0.7.1 MBConvBlock.forward (behind model/backbone/efficientnetv1.py:11-26): x -> _expand_conv (1x1, Cin -> 6 Cin) -> _bn0 -> swish ->
+// _depthwise_conv (k in {3, 5}, stride 1 / 2, static "SAME" padding) -> _bn1 -> swish -> squeeze-excitation pooling.  As separate launches the expanded map -- six times
+// the block's input, 2.6 GB for B3's first stage-2 block at 16 x 832 x 1344 -- is written by the expand conv and read back by the depthwise conv, and the SE pooling
+// reads the depthwise output once more.  Here one workgroup (8 waves, one per CU) owns a TO x TO tile of the DEPTHWISE OUTPUT of one image:
+//   * the (TO - 1) * stride + k square input patch (at most 16 x 16 = 256 pixels, Cin <= 48 channels) is staged in LDS once (row stride 4 * odd floats: the A-operand
+//     reads are 16 bytes per lane and conflict-free);
+//   * the expanded channels go through in blocks of 32 as a TWO-STAGE PIPELINE over the waves, one barrier per block:
+//       waves 0-3 (matrix pipe): the expand GEMM of block cb -- 64 patch pixels per wave x 32 channels, K = Cin on v_mfma_f32_32x32x2_f32, B = the block's weights staged in
+//         LDS in fragment order (16 bytes per lane; the next block's weights are fetched under the MFMAs) -- then _bn0 + swish, the pixels OUTSIDE the image set to zero (the
+//         depthwise conv pads the EXPANDED map with zeros, not with swish(bn0(0))), written to the expanded tile Es[cb & 1];
+//       waves 4-7 (vector unit / LDS): the depthwise conv of block cb - 1 from Es[(cb - 1) & 1]: a thread owns a channel quad (its k x k taps live in registers, fetched one
+//         block ahead) and strips of adjacent outputs (stride 1: two per strip, sharing their window reads), taps in dwconv_kxk_kernel's order, then _bn1 + swish, 16-byte
+//         stores, and the SE pooling: per-thread sums -> fixed xor-shuffle tree per wave -> four wave partials added in order -> pool[image][tile][channel]
+//         (fd_se_gate_from_pool adds the tiles in index order: deterministic).
+// The expanded map never reaches HBM; the expand GEMM is recomputed on the halo (1.15 - 1.8 x).  Blocks with Cin > 48 (LDS: patch + two expanded tiles = 147 KB at Cin = 48) stay on the separate launches.
+// (First version, same results: every wave did GEMM then depthwise, three barriers per block, taps and weights re-read from LDS per output, the pooling summed by eight
+//  threads over 64 dependent LDS reads: 43 us per tile where the separate launches need the equivalent of 34 -- profiles/r05_mbconv_fused_v1_layer_times.tsv.)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MbFusedArgs {
+    const float* x; int x_cs, x_co;
+    const float* we;                       // [ceil(mid / 32)][Cin / 8][2][32][4]: element (cb, g, h, l, jj) = W_expand[32 cb + l][h * (Cin / 2) + 4 g + jj] (rows >= mid zero)
+    const float* sc0; const float* sf0;    // _bn0 folded, [mid]
+    const float* wd;                       // depthwise weights [K * K][mid]
+    const float* sc1; const float* sf1;    // _bn1 folded, [mid]
+    float* y; int y_cs, y_co;              // depthwise output rows [N][Ho][Wo] x mid
+    float* pool;                           // [N][tiles_y * tiles_x][mid] partial sums of y over the tile's pixels
+    int N, H, W, Ho, Wo, Cin, mid, pad_t, pad_l, tiles_x, tiles_y;
+};
+
+__host__ __device__ static inline int mb_xs(int Cin) { return Cin + (((Cin >> 2) & 1) ? 0 : 4); }      // patch row stride in floats: 4 * odd
+
+template <int K, int STRIDE>
+__global__ __launch_bounds__(512, 1) void mbconv_expand_dw_kernel(MbFusedArgs a) {
+    constexpr int TO = (STRIDE == 1) ? (K == 3 ? 14 : 12) : (K == 3 ? 7 : 6);      // output tile side
+    constexpr int PS = (TO - 1) * STRIDE + K;                                        // patch side: 16 or 15
+    constexpr int ES = 36;                                                           // floats per pixel row of the expanded tile
+    constexpr int SO = (STRIDE == 1) ? 2 : 1;                                        // adjacent outputs per strip
+    constexpr int WIN = (SO - 1) * STRIDE + K;                                       // window columns per filter row
+    constexpr int NSX = TO / SO, NSTRIP = TO * NSX;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int XS = mb_xs(a.Cin);
+    float* Xs = reinterpret_cast<float*>(smem);                                      // [256][XS]
+    float* Es = Xs + 256 * XS;                                                       // [2][256][ES]
+    float* Ws = Es + 2 * 256 * ES;                                                   // [2][Cin * 32]
+    float* Rw = Ws + 2 * a.Cin * 32;                                                 // [2][4 waves][8 quads] float4
+    float* Wd = Rw + 2 * 4 * 8 * 4;                                                  // [2][K * K][32]: depthwise taps of a block, staged one block ahead
+    int* Vm = reinterpret_cast<int*>(Wd + 2 * K * K * 32);                           // [256] 1 = patch pixel inside the image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int n = b / a.tiles_y;
+    const int oy0 = ty * TO, ox0 = tx * TO;
+    const int iy0 = oy0 * STRIDE - a.pad_t, ix0 = ox0 * STRIDE - a.pad_l;
+    const int ncb = (a.mid + 31) >> 5;
+    const int wblk4 = a.Cin * 8;                                 // float4s per weight block
+
+    // ---- prologue: the input patch (256 pixel slots, PS * PS used; zero outside the image) and weight block 0 ----
+    {
+        const int C4 = a.Cin >> 2;
+        for (int i = tid; i < 256 * C4; i += 512) {
+            const int p = i / C4, q = i - p * C4;
+            const int py = p / PS, px = p - py * PS;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool ok = p < PS * PS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            *reinterpret_cast<float4*>(Xs + p * XS + 4 * q) =
+                ok ? *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.x_cs + a.x_co + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q == 0) Vm[p] = ok ? 1 : 0;
+        }
+        for (int i = tid; i < wblk4; i += 512) reinterpret_cast<float4*>(Ws)[i] = reinterpret_cast<const float4*>(a.we)[i];
+    }
+    __syncthreads();
+
+    const bool producer = wave < 4;                              // (wave-uniform)
+    // producer: patch row blocks 2 wave, 2 wave + 1
+    const int nkh = a.Cin >> 1, ng = nkh >> 2;                   // K steps per lane half, groups of four
+    // consumer: channel quad q, strip slot
+    const int ctid = tid - 256, q = ctid & 7, slot = ctid >> 3;
+    float4 kw[K * K];                                            // this block's depthwise taps of quad q (from LDS, where they were staged one block ahead)
+    float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // taps of block cbn -> Wd[cbn & 1]: K * K * 8 float4s, one per consumer thread (K = 5: 200 of the 256)
+    auto fetch_taps = [&](int cbn) -> float4 {
+        const int t = ctid >> 3, c = cbn * 32 + 4 * (ctid & 7);
+        return (ctid < K * K * 8 && c < a.mid) ? *reinterpret_cast<const float4*>(a.wd + (size_t)t * a.mid + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (!producer && ctid < K * K * 8) reinterpret_cast<float4*>(Wd)[ctid] = fetch_taps(0);       // (visible behind the first loop barrier: block 0's taps are read in iteration 1)
+
+    for (int cb = 0; cb <= ncb; ++cb) {
+        if (producer) {
+            if (cb < ncb) {
+                const int buf = cb & 1;
+                // the next block's weights: global -> registers now, -> LDS behind the MFMAs (wblk4 <= 512: at most one float4 per thread ... of the 256 producer threads: two)
+                float4 wn0 = make_float4(0.f, 0.f, 0.f, 0.f), wn1 = wn0;
+                const bool more = cb + 1 < ncb;
+                if (more) {
+                    const float4* src = reinterpret_cast<const float4*>(a.we) + (size_t)(cb + 1) * wblk4;
+                    if (tid < wblk4) wn0 = src[tid];
+                    if (tid + 256 < wblk4) wn1 = src[tid + 256];
+                }
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+                const float* A0 = Xs + (64 * wave + l31) * XS + lh * nkh;
+                const float* A1 = A0 + 32 * XS;
+                const float* Bw = Ws + buf * a.Cin * 32 + (lh * 32 + l31) * 4;
+                for (int g = 0; g < ng; ++g) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(A0 + 4 * g), a1 = *reinterpret_cast<const float4*>(A1 + 4 * g);
+                    const float4 bw = *reinterpret_cast<const float4*>(Bw + g * 256);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bw.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bw.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bw.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bw.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bw.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bw.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bw.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bw.w, acc1, 0, 0, 0);
+                }
+                const int c = cb * 32 + l31;
+                const bool c_ok = c < a.mid;
+                const float s0 = c_ok ? a.sc0[c] : 0.f, t0 = c_ok ? a.sf0[c] : 0.f;
+                float* Eb = Es + buf * 256 * ES;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int p = 64 * wave + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float v0 = fd_act(fmaf(acc0[e], s0, t0), FD_ACT_SILU, 0.f), v1 = fd_act(fmaf(acc1[e], s0, t0), FD_ACT_SILU, 0.f);
+                    Eb[p * ES + l31] = (Vm[p] && c_ok) ? v0 : 0.f;                   // the depthwise conv sees zeros outside the image
+                    Eb[(p + 32) * ES + l31] = (Vm[p + 32] && c_ok) ? v1 : 0.f;
+                }
+                if (more) {
+                    float4* dst = reinterpret_cast<float4*>(Ws + (buf ^ 1) * a.Cin * 32);
+                    if (tid < wblk4) dst[tid] = wn0;
+                    if (tid + 256 < wblk4) dst[tid + 256] = wn1;
+                }
+            }
+        } else {
+            // ---- the pooling partials of block cb - 2 (written into Rw[cb & 1] one iteration ago): four wave sums in wave order ----
+            if (cb >= 2 && ctid < 8) {
+                const int c = (cb - 2) * 32 + 4 * ctid;
+                if (c < a.mid) {
+                    const float4* r = reinterpret_cast<const float4*>(Rw) + (cb & 1) * 32 + ctid;
+                    float4 s = r[0];
+                    const float4 s1 = r[8], s2 = r[16], s3 = r[24];
+                    s.x = ((s.x + s1.x) + s2.x) + s3.x; s.y = ((s.y + s1.y) + s2.y) + s3.y; s.z = ((s.z + s1.z) + s2.z) + s3.z; s.w = ((s.w + s1.w) + s2.w) + s3.w;
+                    *reinterpret_cast<float4*>(a.pool + ((size_t)n * a.tiles_y * a.tiles_x + ty * a.tiles_x + tx) * a.mid + c) = s;
+                }
+            }
+            if (cb >= 1) {
+                const int c0 = (cb - 1) * 32;
+                const int cq = c0 + 4 * q;
+                const float4 tn = (cb < ncb) ? fetch_taps(cb) : make_float4(0.f, 0.f, 0.f, 0.f);      // the next block's taps travel under this block's work
+#pragma unroll
+                for (int t = 0; t < K * K; ++t) kw[t] = reinterpret_cast<const float4*>(Wd + ((cb - 1) & 1) * K * K * 32)[t * 8 + q];
+                float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = s1;
+                if (cq < a.mid) { s1 = *reinterpret_cast<const float4*>(a.sc1 + cq); t1 = *reinterpret_cast<const float4*>(a.sf1 + cq); }
+                const float* Eb = Es + ((cb - 1) & 1) * 256 * ES + 4 * q;
+                psum = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int st = slot; st < NSTRIP; st += 32) {
+                    const int oy = st / NSX, sx = st - oy * NSX;
+                    const int ox = sx * SO;
+                    const float* eb = Eb + ((oy * STRIDE) * PS + ox * STRIDE) * ES;
+                    float4 o[SO];
+#pragma unroll
+                    for (int j = 0; j < SO; ++j) o[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int r = 0; r < K; ++r) {
+                        float4 u[WIN];
+#pragma unroll
+                        for (int c = 0; c < WIN; ++c) u[c] = *reinterpret_cast<const float4*>(eb + (r * PS + c) * ES);
+#pragma unroll
+                        for (int c = 0; c < K; ++c) {
+                            const float4 k = kw[r * K + c];
+#pragma unroll
+                            for (int j = 0; j < SO; ++j) {
+                                const float4 v = u[j * STRIDE + c];
+                                o[j].x = fmaf(v.x, k.x, o[j].x); o[j].y = fmaf(v.y, k.y, o[j].y); o[j].z = fmaf(v.z, k.z, o[j].z); o[j].w = fmaf(v.w, k.w, o[j].w);
+                            }
+                        }
+                    }
+                    const int gy = oy0 + oy;
+#pragma unroll
+                    for (int j = 0; j < SO; ++j) {
+                        const int gx = ox0 + ox + j;
+                        if (gy < a.Ho && gx < a.Wo && cq < a.mid) {
+                            float4 v;
+                            v.x = fd_act(fmaf(o[j].x, s1.x, t1.x), FD_ACT_SILU, 0.f); v.y = fd_act(fmaf(o[j].y, s1.y, t1.y), FD_ACT_SILU, 0.f);
+                            v.z = fd_act(fmaf(o[j].z, s1.z, t1.z), FD_ACT_SILU, 0.f); v.w = fd_act(fmaf(o[j].w, s1.w, t1.w), FD_ACT_SILU, 0.f);
+                            *reinterpret_cast<float4*>(a.y + ((size_t)(n * a.Ho + gy) * a.Wo + gx) * a.y_cs + a.y_co + cq) = v;
+                            psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w;
+                        }
+                    }
+                }
+                // lanes q, q + 8, .., q + 56 of a wave hold channel quad q: a fixed xor tree (8, 16, 32), then one slot per (wave, quad)
+#pragma unroll
+                for (int off = 8; off < 64; off <<= 1) {
+                    psum.x += __shfl_xor(psum.x, off); psum.y += __shfl_xor(psum.y, off); psum.z += __shfl_xor(psum.z, off); psum.w += __shfl_xor(psum.w, off);
+                }
+                if (lane < 8) reinterpret_cast<float4*>(Rw)[((cb - 1) & 1) * 32 + (wave - 4) * 8 + lane] = psum;
+                if (cb < ncb && ctid < K * K * 8) reinterpret_cast<float4*>(Wd + (cb & 1) * K * K * 32)[ctid] = tn;
+            }
+        }
+        __syncthreads();
+    }
+    // the last block's pooling partials (written in the final iteration, behind the loop's last barrier)
+    if (ctid >= 0 && ctid < 8) {
+        const int c = (ncb - 1) * 32 + 4 * ctid;
+        if (c < a.mid) {
+            const float4* r = reinterpret_cast<const float4*>(Rw) + ((ncb - 1) & 1) * 32 + ctid;
+            float4 s = r[0];
+            const float4 s1 = r[8], s2 = r[16], s3 = r[24];
+            s.x = ((s.x + s1.x) + s2.x) + s3.x; s.y = ((s.y + s1.y) + s2.y) + s3.y; s.z = ((s.z + s1.z) + s2.z) + s3.z; s.w = ((s.w + s1.w) + s2.w) + s3.w;
+            *reinterpret_cast<float4*>(a.pool + ((size_t)n * a.tiles_y * a.tiles_x + ty * a.tiles_x + tx) * a.mid + c) = s;
+        }
+    }
+}
+
+static int mb_tile_side(int K, int stride) { return stride == 1 ? (K == 3 ? 14 : 12) : (K == 3 ? 7 : 6); }
+
+extern "C" int64_t fd_mbconv_pool_bytes(int32_t N, int32_t Ho, int32_t Wo, int32_t mid, int32_t K, int32_t stride) {
+    if (N < 1 || Ho < 1 || Wo < 1 || mid < 4 || (K != 3 && K != 5) || (stride != 1 && stride != 2)) return -1;
+    const int to = mb_tile_side(K, stride);
+    return (int64_t)N * ((Ho + to - 1) / to) * ((Wo + to - 1) / to) * mid * 4;
+}
+
+extern "C" int32_t fd_mbconv_expand_dw_nhwc(const float* x, int32_t x_cs, int32_t x_co, const float* w_expand_frag, const float* scale0, const float* shift0,
+                                            const float* w_dw, const float* scale1, const float* shift1, float* y, int32_t y_cs, int32_t y_co, float* pool,
+                                            int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t mid, int32_t K, int32_t stride, int32_t pad_top, int32_t pad_left,
+                                            int32_t Ho, int32_t Wo, fd_stream_t stream) {
+    FD_REQUIRE(view_ok(x, x_cs, x_co, Cin) && view_ok(y, y_cs, y_co, mid) && w_expand_frag && scale0 && shift0 && w_dw && scale1 && shift1 && pool &&
+                   ((((uintptr_t)w_expand_frag | (uintptr_t)scale1 | (uintptr_t)shift1 | (uintptr_t)pool) & 15) == 0), FD_E_INVAL,
+               "fd_mbconv_expand_dw: bad pointer / channel view (Cin=%d mid=%d)", Cin, mid);
+    FD_REQUIRE((K == 3 || K == 5) && (stride == 1 || stride == 2) && Cin >= 8 && Cin <= 48 && Cin % 8 == 0 && mid % 4 == 0, FD_E_UNSUPPORTED,
+               "fd_mbconv_expand_dw: k in {3, 5}, stride in {1, 2}, Cin %% 8 == 0 in 8 .. 48, mid %% 4 == 0 (got k=%d s=%d Cin=%d mid=%d)", K, stride, Cin, mid);
+    FD_REQUIRE(N >= 1 && H >= 1 && W >= 1 && Ho >= 1 && Wo >= 1 && pad_top >= 0 && pad_left >= 0 && pad_top < K && pad_left < K &&
+                   (long)(Ho - 1) * stride - pad_top < H && (long)(Wo - 1) * stride - pad_left < W, FD_E_INVAL, "fd_mbconv_expand_dw: bad geometry");
+    FD_REQUIRE((long)N * H * W * x_cs < (1L << 31) && (long)N * Ho * Wo * y_cs < (1L << 31), FD_E_UNSUPPORTED, "fd_mbconv_expand_dw: tensor too large");
+    MbFusedArgs a;
+    a.x = x; a.x_cs = x_cs; a.x_co = x_co; a.we = w_expand_frag; a.sc0 = scale0; a.sf0 = shift0; a.wd = w_dw; a.sc1 = scale1; a.sf1 = shift1;
+    a.y = y; a.y_cs = y_cs; a.y_co = y_co; a.pool = pool;
+    a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.mid = mid; a.pad_t = pad_top; a.pad_l = pad_left;
+    const int to = mb_tile_side(K, stride);
+    a.tiles_y = (Ho + to - 1) / to; a.tiles_x = (Wo + to - 1) / to;
+    const long blocks = (long)N * a.tiles_y * a.tiles_x;
+    FD_REQUIRE(blocks < (1L << 31), FD_E_UNSUPPORTED, "fd_mbconv_expand_dw: too many tiles");
+    const int lds = (256 * mb_xs(Cin) + 2 * 256 * 36 + 2 * Cin * 32 + 2 * 4 * 8 * 4 + 2 * K * K * 32 + 256) * 4;       // patch + two expanded tiles + two weight blocks + pooling slots + taps + validity: <= 147 KB
+    hipStream_t st = (hipStream_t)stream;
+#define FD_MB_LAUNCH(KK, SS)                                                                                                   \
+    do {                                                                                                                      \
+        static std::atomic<unsigned> m{0};                                                                                    \
+        fd_set_max_lds_once(m, reinterpret_cast<const void*>(mbconv_expand_dw_kernel<KK, SS>), 160 * 1024);                   \
+        hipLaunchKernelGGL((mbconv_expand_dw_kernel<KK, SS>), dim3((unsigned)blocks), dim3(512), lds, st, a);                  \
+    } while (0)
+    if (K == 3 && stride == 1) FD_MB_LAUNCH(3, 1);
+    else if (K == 3) FD_MB_LAUNCH(3, 2);
+    else if (stride == 1) FD_MB_LAUNCH(5, 1);
+    else FD_MB_LAUNCH(5, 2);
+#undef FD_MB_LAUNCH
+    FD_CHECK_LAUNCH("fd_mbconv_expand_dw_nhwc");
+    return FD_OK;
+}
+

@@ -37,6 +37,8 @@ GN_FUSED_TOWER = _os.environ.get("FD_GN_FUSED_TOWER", "0") == "1"   # "1": the t
 # "1": a head-tower F(4x4) launch whose grid is no multiple of the CU count runs as whole rounds of workgroups + a tail launch ("head.tower3x3.tail", after the mark):
 # TwoLanePipeline releases the other lane when the whole rounds are done, so the tail round (60 % of the chip idle at 16 x 640 x 640) has company
 TOWER_TAIL_SPLIT = _os.environ.get("FD_TOWER_TAIL_SPLIT", "1") != "0"
+# "1": an MBConv block's expand conv and depthwise conv run as ONE launch where the shapes allow (fd_mbconv_expand_dw_nhwc: Cin <= 48, k in {3, 5}); "0": separate launches
+MBCONV_FUSED = _os.environ.get("FD_MBCONV_FUSED", "1") != "0"
 FPN_UP_FUSED = _os.environ.get("FD_FPN_UP_FUSED", "1") != "0"   # "0": the top-down path's x2 upsample + add as its own pass over the finer map (else in the lateral conv's epilogue)
 TOWER_GN_SPLIT = _os.environ.get("FD_TOWER_GN_SPLIT", "1") != "0"   # "0": the tower's GroupNorm normalises both halves in its own pass (else the box half in the narrow predictor's loader)
 GN_FUSED = _os.environ.get("FD_GN_FUSED", "1") != "0"       # "0": HISFCOSHead's GroupNorms as three-pass launches (statistics / finalise / normalise)
@@ -553,23 +555,43 @@ def build_efficientnet(plan: Plan, net, batch: int, H: int, W: int, image_ref: L
         segs = Segs.make(batch, [(h, w)])
         inp = x
         mid = blk._depthwise_conv.weight.shape[0]
-        if blk.expand != 1:
-            e = pool.get(segs.rows, mid)
-            add_conv(plan, nm + "._expand_conv", x, segs, blk._expand_conv, e, bn=blk._bn0, act=ACT_SILU)
-        else:
-            e = x
         ho, wo = out_hw(h, w, blk.kernel, blk.stride, blk.pad)
         if ho < 1 or wo < 1:
             raise FdError("EfficientNet: input too small")
         so = Segs.make(batch, [(ho, wo)])
+        # expand 1x1 -> depthwise in ONE launch where the tile's input patch fits LDS (the early, high-resolution stages: the six-fold expanded map never reaches HBM,
+        # and the SE pooling comes out of the same kernel as per-tile partial sums)
+        # (k = 5 at stride 2 stays separate: a 6 x 6 output tile needs a 15 x 15 patch -- 1.56 x the expand GEMM and a depthwise stage that fills 56 % of its threads:
+        #  0.70 ms fused against 0.60 ms for B3's block 5, profiles/r05_layer_times_fcos_b3_mbconv_fused.tsv)
+        fused = (MBCONV_FUSED and blk.expand != 1 and plan.precision == "f32" and blk._expand_conv.bias is None and not (blk.kernel == 5 and blk.stride == 2)
+                 and ops.mbconv_fused_ok(x.C, mid, blk.kernel, blk.stride) and x.C == blk._expand_conv.weight.shape[1])
         d = pool.get(so.rows, mid)
         wd = ops.pack_dwk_weight(_dev(blk._depthwise_conv.weight, dev))
         sc, sf = bn_fold(blk._bn1)
-        plan.add(nm + "._depthwise_conv", lambda e=e, d=d, wd=wd, sc=sc, sf=sf, h=h, w=w, ho=ho, wo=wo, blk=blk:
-                 ops.dwconv2d(e, wd, d, batch, h, w, blk.kernel, blk.stride, blk.pad[0], blk.pad[0], ho, wo, sc, sf, ACT_SILU))
-        plan.flops += 2 * so.rows * mid * blk.kernel * blk.kernel
-        if e is not x:
-            pool.put(e)
+        pool_part = None
+        if fused:
+            wef = ops.pack_mbconv_expand_weight(_dev(blk._expand_conv.weight, dev))
+            sc_e, sf_e = bn_fold(blk._bn0)
+            pool_part, ntile = ops.mbconv_pool_buffer(batch, ho, wo, mid, blk.kernel, blk.stride, dev)
+            plan.keep += [wef, pool_part]
+            plan.add(nm + "._expand+depthwise", lambda x=x, d=d, wef=wef, sc_e=sc_e, sf_e=sf_e, wd=wd, sc=sc, sf=sf, pp=pool_part, h=h, w=w, ho=ho, wo=wo, blk=blk:
+                     ops.mbconv_expand_dw(x, wef, sc_e, sf_e, wd, sc, sf, d, pp, batch, h, w, blk.kernel, blk.stride, blk.pad[0], blk.pad[0], ho, wo))
+            fl = 2 * segs.rows * mid * x.C
+            plan.flops += fl + 2 * so.rows * mid * blk.kernel * blk.kernel
+            plan.step_flops[len(plan.steps) - 1] = fl
+            plan.step_info[len(plan.steps) - 1] = {"k": 1, "stride": 1, "dil": 1, "Cin": x.C, "Cout": mid, "rows": segs.rows,
+                                                   "family": "mbconv expand 1x1 + depthwise (one launch)", "mfma_div": 1.0}
+        else:
+            if blk.expand != 1:
+                e = pool.get(segs.rows, mid)
+                add_conv(plan, nm + "._expand_conv", x, segs, blk._expand_conv, e, bn=blk._bn0, act=ACT_SILU)
+            else:
+                e = x
+            plan.add(nm + "._depthwise_conv", lambda e=e, d=d, wd=wd, sc=sc, sf=sf, h=h, w=w, ho=ho, wo=wo, blk=blk:
+                     ops.dwconv2d(e, wd, d, batch, h, w, blk.kernel, blk.stride, blk.pad[0], blk.pad[0], ho, wo, sc, sf, ACT_SILU))
+            plan.flops += 2 * so.rows * mid * blk.kernel * blk.kernel
+            if e is not x:
+                pool.put(e)
         w1 = _dev(blk._se_reduce.weight, dev).reshape(blk._se_reduce.weight.shape[0], -1).contiguous()
         b1 = _dev(blk._se_reduce.bias, dev)
         w2 = _dev(blk._se_expand.weight, dev).reshape(mid, -1).contiguous()
@@ -579,8 +601,12 @@ def build_efficientnet(plan: Plan, net, batch: int, H: int, W: int, image_ref: L
         out = pool.get(so.rows, blk.cout)
         if SE_GATE_IN_PROJECT and plan.precision in ("f32", "mixed"):
             # the gate is multiplied in by the project conv's loader: no scaling pass (a read and a write of the expanded map) at all
-            plan.add(nm + "._se", lambda d=d, w1=w1, b1=b1, w2=w2, b2=b2, sews=sews, hw=ho * wo:
-                     ops.se_gate(d, w1, b1, w2, b2, batch, hw, w1.shape[0], sews))
+            if pool_part is not None:       # ... and its pooling came out of the fused expand + depthwise launch: no pass over the map at all
+                plan.add(nm + "._se", lambda pp=pool_part, nt=ntile, w1=w1, b1=b1, w2=w2, b2=b2, sews=sews, hw=ho * wo, mid=mid:
+                         ops.se_gate_from_pool(pp, nt, w1, b1, w2, b2, batch, hw, mid, w1.shape[0], sews))
+            else:
+                plan.add(nm + "._se", lambda d=d, w1=w1, b1=b1, w2=w2, b2=b2, sews=sews, hw=ho * wo:
+                         ops.se_gate(d, w1, b1, w2, b2, batch, hw, w1.shape[0], sews))
             add_conv(plan, nm + "._project_conv", d, so, blk._project_conv, out, bn=blk._bn2, res=inp if blk.skip else None,
                      gate=ops.se_gate_view(sews, batch, ho * wo, mid))
         else:

@@ -889,6 +889,42 @@ def dwconv2d(x: Rows, wkc: torch.Tensor, y: Rows, N: int, H: int, W: int, K: int
                                       pad_top, pad_left, Ho, Wo, act, _stream()), "fd_dwconv2d_nhwc")
 
 
+def mbconv_fused_ok(Cin: int, mid: int, K: int, stride: int) -> bool:
+    """Shapes fd_mbconv_expand_dw_nhwc covers (the input patch of a tile and two expanded tiles must fit LDS: Cin <= 48)."""
+    return K in (3, 5) and stride in (1, 2) and 8 <= Cin <= 48 and Cin % 8 == 0 and mid % 4 == 0
+
+
+def pack_mbconv_expand_weight(w: torch.Tensor) -> torch.Tensor:
+    """[mid, Cin, 1, 1] expand weights -> fd_mbconv_expand_dw_nhwc's fragment order [ceil(mid / 32)][Cin / 8][2][32][4]: element (cb, g, h, l, jj) =
+    w[32 cb + l][h * Cin / 2 + 4 g + jj] (a lane's four consecutive K steps are one 16-byte LDS read)."""
+    mid, cin = w.shape[0], w.shape[1]
+    wp = torch.nn.functional.pad(w.detach().float().reshape(mid, cin), (0, 0, 0, (-mid) % 32))
+    return wp.view(-1, 32, 2, cin // 8, 4).permute(0, 3, 2, 1, 4).contiguous()
+
+
+def mbconv_pool_buffer(N: int, Ho: int, Wo: int, mid: int, K: int, stride: int, device) -> Tuple[torch.Tensor, int]:
+    """(per-tile pooling partials buffer, tiles per image) of mbconv_expand_dw."""
+    nb = _lib.lib().fd_mbconv_pool_bytes(N, Ho, Wo, mid, K, stride)
+    if nb < 0:
+        raise FdError("fd_mbconv_pool_bytes: bad arguments")
+    return torch.empty(nb // 4, dtype=torch.float32, device=device), nb // 4 // (N * mid)
+
+
+def mbconv_expand_dw(x: Rows, we_frag: torch.Tensor, sc0, sf0, wkc: torch.Tensor, sc1, sf1, y: Rows, pool: torch.Tensor, N: int, H: int, W: int, K: int, stride: int,
+                     pad_top: int, pad_left: int, Ho: int, Wo: int) -> None:
+    """MBConv expand 1x1 + BN + swish -> depthwise K x K + BN + swish in one launch (the expanded map stays on chip) + the SE pooling's per-tile partial sums."""
+    check(_lib.lib().fd_mbconv_expand_dw_nhwc(x.ptr, x.cs, x.co, we_frag.data_ptr(), sc0.data_ptr(), sf0.data_ptr(), wkc.data_ptr(), sc1.data_ptr(), sf1.data_ptr(),
+                                              y.ptr, y.cs, y.co, pool.data_ptr(), N, H, W, x.C, y.C, K, stride, pad_top, pad_left, Ho, Wo, _stream()),
+          "fd_mbconv_expand_dw_nhwc")
+
+
+def se_gate_from_pool(pool: torch.Tensor, T: int, w1, b1, w2, b2, N: int, HW: int, C_: int, Cr: int, ws: torch.Tensor) -> torch.Tensor:
+    """The SE gates from mbconv_expand_dw's per-tile partial sums (no pass over the map); returns the [N, C] gate view into `ws` like se_gate."""
+    check(_lib.lib().fd_se_gate_from_pool(pool.data_ptr(), T, w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
+                                          b2.data_ptr() if b2 is not None else None, N, HW, C_, Cr, ws.data_ptr(), _stream()), "fd_se_gate_from_pool")
+    return se_gate_view(ws, N, HW, C_)
+
+
 def dwconv_dilated(x: Rows, wkc: torch.Tensor, y: Rows, segs: Segs, K: int, dil: int, scale=None, shift=None, act: int = ACT_NONE) -> None:
     """Dilated depthwise K x K, stride 1, 'same' padding, over a pyramid (MNBlock.DilatedDepthWiseConv + folded BN); w [K*K][C]."""
     _need_gpu(wkc, scale, shift)

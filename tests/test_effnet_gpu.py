@@ -51,6 +51,56 @@ def test_dwconv2d_vs_torch(case):
     np.testing.assert_allclose(from_rows(y, B, Ho, Wo).numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("case", [
+    # Cin, mid, K, stride, (pad_before, pad_after), H, W    (EfficientNet-B3 stage 2: 24 -> 144 k3 s2, 32 -> 192 k3 s1; stage 3: 32 -> 192 k5 s2, 48 -> 288 k5 s1)
+    (24, 144, 3, 2, (0, 1), 52, 84), (32, 192, 3, 1, (1, 1), 30, 45), (32, 192, 5, 2, (1, 2), 26, 42), (48, 288, 5, 1, (2, 2), 13, 25),
+    (16, 20, 3, 1, (1, 1), 5, 7), (40, 100, 5, 2, (2, 2), 9, 33), (8, 48, 3, 2, (0, 1), 64, 8),
+])
+def test_mbconv_expand_depthwise_fused_vs_torch(case):
+    """fd_mbconv_expand_dw_nhwc: MBConvBlock's _expand_conv -> _bn0 -> swish -> _depthwise_conv (static SAME padding) -> _bn1 -> swish (efficientnet_pytorch 0.7.1
+    behind model/backbone/efficientnetv1.py:11-26) in one launch -- the expanded map stays in LDS -- plus the SE pooling's per-tile partial sums.  Against torch in fp64
+    (the padding of the EXPANDED map is zero, not swish(bn0(0)): the kernel must zero the halo pixels outside the image), channel views with NaN neighbours, ragged tile
+    edges, widths that are no multiple of 32; the gates fd_se_gate_from_pool derives from the partials against the pooling of the stored output."""
+    Cin, mid, K, s, pad, H, W = case
+    gen = torch.Generator().manual_seed(Cin + mid + K + s)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    we = torch.randn(mid, Cin, 1, 1, generator=gen) / Cin ** 0.5
+    wd = torch.randn(mid, 1, K, K, generator=gen) / K
+    sc0, sf0 = torch.rand(mid, generator=gen) + 0.5, torch.randn(mid, generator=gen) * 0.3
+    sc1, sf1 = torch.rand(mid, generator=gen) + 0.5, torch.randn(mid, generator=gen) * 0.1
+    e = F.conv2d(x.double(), we.double()) * sc0.double()[None, :, None, None] + sf0.double()[None, :, None, None]
+    e = e * torch.sigmoid(e)
+    ref = F.conv2d(F.pad(e, (pad[0], pad[1], pad[0], pad[1])), wd.double(), None, s, 0, 1, mid) * sc1.double()[None, :, None, None] + sf1.double()[None, :, None, None]
+    ref = (ref * torch.sigmoid(ref)).float()
+    Ho, Wo = ref.shape[2:]
+    xb = torch.full((B * H * W, Cin + 8), float("nan"), device=DEV)
+    xb[:, 4:4 + Cin] = x.permute(0, 2, 3, 1).reshape(-1, Cin).to(DEV)
+    yb = torch.full((B * Ho * Wo, mid + 8), float("nan"), device=DEV)
+    pool, T = ops.mbconv_pool_buffer(B, Ho, Wo, mid, K, s, DEV)
+    pool.fill_(float("nan"))
+    assert ops.mbconv_fused_ok(Cin, mid, K, s)
+    ops.mbconv_expand_dw(ops.Rows(xb, 4, Cin), ops.pack_mbconv_expand_weight(we).to(DEV), sc0.to(DEV), sf0.to(DEV), ops.pack_dwk_weight(wd).to(DEV), sc1.to(DEV), sf1.to(DEV),
+                         ops.Rows(yb, 4, mid), pool, B, H, W, K, s, pad[0], pad[0], Ho, Wo)
+    assert torch.isnan(yb[:, :4]).all() and torch.isnan(yb[:, 4 + mid:]).all(), "wrote outside its channel view"
+    got = yb[:, 4:4 + mid].cpu().reshape(B, Ho, Wo, mid).permute(0, 3, 1, 2)
+    assert not torch.isnan(got).any(), "an output pixel was never written"
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=3e-5, rtol=2e-5)
+    # pooling partials: every (image, tile, channel) written; their sum = the sum of the stored output
+    assert not torch.isnan(pool).any()
+    psum = pool.view(B, T, mid).double().sum(1).cpu()
+    np.testing.assert_allclose(psum.numpy(), got.double().sum((2, 3)).numpy(), rtol=1e-5, atol=1e-4)
+    Cr = max(1, Cin // 4)
+    w1, b1 = (torch.randn(Cr, mid, generator=gen) / mid ** 0.5).to(DEV), torch.randn(Cr, generator=gen).to(DEV)
+    w2, b2 = (torch.randn(mid, Cr, generator=gen) / Cr ** 0.5).to(DEV), torch.randn(mid, generator=gen).to(DEV)
+    ws = ops.se_workspace(B, Ho * Wo, mid, DEV)
+    g1 = ops.se_gate_from_pool(pool, T, w1, b1, w2, b2, B, Ho * Wo, mid, Cr, ws).clone()
+    g0 = ops.se_gate(ops.Rows(yb, 4, mid), w1, b1, w2, b2, B, Ho * Wo, Cr, ops.se_workspace(B, Ho * Wo, mid, DEV)).clone()
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for bad in ((64, mid, K, s), (Cin, mid, 7, s), (20, mid, K, s)):
+        assert not ops.mbconv_fused_ok(*bad)
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 37, 51)])
 def test_stem_conv3_vs_torch(shape):
     B, H, W = shape
