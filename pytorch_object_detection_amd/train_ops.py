@@ -32,7 +32,26 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SILU, Rows
 
 # Under torch.autocast (the reference trains with AMP when cfg['model']['amp'] is set, train.py:175) the HIP nodes keep
 # computing in fp32: inputs are cast up on entry, autocast is off inside, gradients come back in fp32.
-_fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+import functools as _functools
+
+
+def _fwd32(fwd):
+    """torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32) without its recursive argument walk: under autocast the top-level floating-point CUDA
+    tensors are cast to fp32 and the forward runs with autocast off (custom_bwd then runs the backward the same way); otherwise the forward runs as it is.  The nodes'
+    arguments are flat (tensors, Segs tables, ints, tuples of fp32 constants), and torch's generic walk over them -- ~1 100 _cast calls per training step -- was 2 ms of
+    the 20 ms of host work that bound the AMP step (tools/train_host_time.py)."""
+    @_functools.wraps(fwd)
+    def wrapper(ctx, *args):
+        ctx._dtype = torch.get_autocast_dtype("cuda")
+        ctx._fwd_used_autocast = False
+        if torch.is_autocast_enabled("cuda"):
+            args = tuple(a.float() if (isinstance(a, torch.Tensor) and a.is_cuda and a.is_floating_point() and a.dtype is not torch.float32) else a for a in args)
+            with torch.autocast("cuda", enabled=False):
+                return fwd(ctx, *args)
+        return fwd(ctx, *args)
+    return wrapper
+
+
 _bwd = torch.amp.custom_bwd(device_type="cuda")
 _fwd_keep = torch.amp.custom_fwd(device_type="cuda")      # nodes that handle f16 / fp32 inputs themselves (AMP_F16_STORE): no cast on entry
 
