@@ -377,3 +377,43 @@ def test_bench_roofline_object_describes_the_marked_launch():
     for other in ({"model": "FCOS-B3"}, {"batch": 1}, {"height": 512, "width": 512}):
         assert bench.pmc_traffic({**bench.PMC_WORKLOAD, **other}) == (None, None)
     assert bench.pmc_traffic(dict(bench.PMC_WORKLOAD), "igemm") == (None, None)
+
+
+def test_round5_entry_points_validate_on_the_host():
+    """The round-5 additions are host arithmetic / host checks until a launch: workspace and pool sizes, weight packings, rejected argument combinations (no GPU needed)."""
+    lib = _lib.lib()
+    # persistent F(4x4) form: fixed 8 KB header + one 128 KB slot per workgroup; multiples of 8 up to 1024
+    assert lib.fd_conv_sk_workspace_bytes(256) == 8192 + 256 * 16 * 512 * 16 and lib.fd_conv_sk_workspace_bytes(8) == 8192 + 8 * 131072
+    assert lib.fd_conv_sk_workspace_bytes(12) == -1 and lib.fd_conv_sk_workspace_bytes(0) == -1 and lib.fd_conv_sk_workspace_bytes(2048) == -1
+    p = _lib.ConvParams()
+    p.x, p.w, p.y = 16, 16, 16
+    p.segs = _lib.Segs.make(2, [(16, 16)])
+    p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil = 64, 64, 3, 3, 1, 1, 1
+    p.x_cs, p.y_cs = 64, 64
+    p.tile, p.sk_wgs = 4, 64
+    assert lib.fd_conv2d_nhwc_f32(ctypes.byref(p), None) < 0 and b"WINOGRAD4" in lib.fd_last_error()         # sk_wgs on another tile
+    p.tile, p.sk_wgs, p.io_f16 = _lib.WINO4_TILE, 0, 1
+    assert lib.fd_conv2d_nhwc_f32(ctypes.byref(p), None) < 0 and b"io_f16" in lib.fd_last_error()            # f16 maps on a Winograd tile
+    p.tile, p.io_f16 = 0, 2
+    assert lib.fd_conv2d_nhwc_f32(ctypes.byref(p), None) < 0 and b"FD_PREC_F16" in lib.fd_last_error()       # f16 maps need the f16 arithmetic
+    p.tile, p.io_f16, p.precision = _lib.F16K64_TILE, 0, 0
+    assert lib.fd_conv2d_nhwc_f32(ctypes.byref(p), None) < 0 and b"F16K64" in lib.fd_last_error()            # the f16 kernel needs FD_PREC_F16
+    # f16 K-tile-64 weight packing: reduction width % 64, never together with the (hi, lo) pair format
+    assert lib.fd_pack_conv_weight_f32(ctypes.c_void_p(16), None, ctypes.c_void_p(16), 64, 96, 3, 3, 16, None) < 0
+    assert lib.fd_pack_conv_weight_f32(ctypes.c_void_p(16), None, ctypes.c_void_p(16), 64, 64, 3, 3, 16 | 4, None) < 0
+    w = _lib.WgradParams()
+    w.io_f16 = 1
+    assert lib.fd_conv2d_bwd_weight_f32(ctypes.byref(w), None) < 0
+    # fused MBConv: tiles of 14 / 12 / 7 / 6 outputs per side
+    assert lib.fd_mbconv_pool_bytes(16, 208, 336, 192, 3, 1) == 16 * 15 * 24 * 192 * 4 and lib.fd_mbconv_pool_bytes(2, 13, 25, 288, 5, 1) == 2 * 2 * 3 * 288 * 4
+    assert lib.fd_mbconv_pool_bytes(2, 26, 42, 144, 3, 2) == 2 * 4 * 6 * 144 * 4 and lib.fd_mbconv_pool_bytes(1, 8, 8, 64, 7, 1) == -1
+    assert lib.fd_mbconv_expand_dw_nhwc(None, 0, 0, None, None, None, None, None, None, None, 0, 0, None, 1, 8, 8, 24, 144, 3, 1, 1, 1, 8, 8, None) < 0
+    assert ops.mbconv_fused_ok(24, 144, 3, 2) and ops.mbconv_fused_ok(48, 288, 5, 1) and not ops.mbconv_fused_ok(96, 576, 3, 1) and not ops.mbconv_fused_ok(20, 120, 3, 1)
+    we = torch.arange(40 * 16, dtype=torch.float32).reshape(40, 16, 1, 1)        # mid = 40 (padded to 64), Cin = 16: element (cb, g, h, l, jj) = w[32 cb + l][8 h + 4 g + jj]
+    pk = ops.pack_mbconv_expand_weight(we)
+    assert pk.shape == (2, 2, 2, 32, 4)
+    assert float(pk[0, 1, 1, 5, 2]) == float(we[5, 8 + 4 + 2, 0, 0]) and float(pk[1, 0, 0, 7, 3]) == float(we[39, 3, 0, 0]) and float(pk[1, 1, 1, 8, 0]) == 0.0
+    # AMP packing choice
+    from pytorch_object_detection_amd import train_ops as T
+    assert T.amp_pack(0, 256, 256) is False and T.amp_pack(_lib.PREC_F16, 256, 64) == 2 and T.amp_pack(_lib.PREC_F16, 32, 256) is True
+    assert ops.f16k64_ok(128, 80) and not ops.f16k64_ok(96, 64)
