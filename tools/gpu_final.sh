@@ -13,6 +13,8 @@ cd $GRAFT_REPO_ROOT
 export FD_COMMIT=${FD_COMMIT:-unknown}
 O=gpurun_out/$tag; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; }
+PART=${FD_FINAL_PART:-all}     # A: tests, smoke, rocprof, PMC, layer times, the headline line; B: every other line; all: both (needs > 20 min)
+if [ "$PART" != "B" ]; then
 timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 600 > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -6 $O/pytest.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 bash tools/prof.sh $tag 2>&1 | tail -3
@@ -23,6 +25,8 @@ cp profiles/${tag}_pmc_summary.json $O/pmc_summary.json; cp profiles/pmc_traffic
 rm -rf gpurun_out/pmc_$tag/*/pmc_kernel_trace.csv gpurun_out/pmc_$tag/*/pmc_counter_collection.csv
 python bench.py --inflight 1 --layer-times $O/layer_times.tsv > /dev/null 2>&1; tail -1 $O/layer_times.tsv
 timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cut -c1-200 $O/bench.json
+fi
+if [ "$PART" = "A" ]; then du -sh gpurun_out; exit 0; fi
 timeout -k 10 300 python bench.py --model FCOS-B3 --size 832x1344 --steps 10 --warmup 3 --no-fast-mode --no-train-step > $O/bench_fcos_b3_832x1344.json 2> $O/bench_b3.err
 timeout -k 10 300 python bench.py --model FCOS-B3 --size 832x1344 --layer-times $O/layer_times_fcos_b3.tsv > /dev/null 2>&1
 timeout -k 10 300 python bench.py --model FCOS --no-fast-mode --no-train-step > $O/bench_fcos_r50.json 2> $O/bench_fcos.err
