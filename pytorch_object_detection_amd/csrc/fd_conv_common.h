@@ -40,6 +40,7 @@ struct ConvArgs {
     int p_halo;    // patch kernel (fd_conv_patch.hip): input rows staged on either side of an M-tile = dil * (max level width + 1)
     // FD_PREC_F16 (H1 kernels) only -- activations stored as f16 in HBM (fd_conv_params.io_f16): x / y / res hold _Float16 elements; views stay in ELEMENTS
     int x16, y16, res16;
+    int wide8;     // FD_TILE_F16K64: the f16 output / residual views allow 16-byte (eight-channel) accesses
 };
 
 // four fp32 values <-> four consecutive f16 (8 bytes), round to nearest even -- the storage form of AMP activations

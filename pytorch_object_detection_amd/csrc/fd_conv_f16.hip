@@ -112,12 +112,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
     };
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     auto mfma_tile = [&](int buf) {
         const float* Ab = Ls + buf * STG + (wm * TM * 32) * 32;
@@ -138,6 +132,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
         __builtin_amdgcn_s_setprio(0);
     };
 
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -148,62 +148,111 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
         store_tile(buf ^ 1);
         __syncthreads();
     }
+
+    // ---- epilogue: the wave's 32-pixel x (TN * 32)-channel strips through a per-wave LDS stage; a lane then owns EIGHT consecutive channels of one pixel (16 bytes
+    // of an f16 map: 4 TN lanes cover a row's 64 TN bytes per instruction).  The f16 residual / mask values of the whole wave tile are fetched BEFORE the last
+    // K-tile's MFMAs: a K = 64 layer is nothing but epilogue, and fetched inside the store loop they were 16 dependent HBM round trips per wave (1.8 TB/s).
+    constexpr int SW = TN * 32 + 4;                          // stage row pitch in floats
+    constexpr int LPR = TN * 4, RPS = 64 / LPR, NP = 32 / RPS;   // lanes per row, rows per pass, passes per 32-row strip
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * SW);
+    const _Float16* res16 = reinterpret_cast<const _Float16*>(a.res);
+    _Float16* y16 = reinterpret_cast<_Float16*>(a.y);
+    const int c8 = (lane % LPR) * 8, prow = lane / LPR;
+    const int nn = n0 + wn * TN * 32 + c8;
+    const bool ok0 = nn < a.Cout, ok1 = nn + 4 < a.Cout;     // (Cout % 4 == 0: the lane's channels are valid in fours)
+    const bool pre = a.res && a.res16;                       // (uniform)
+    h8 rr[TM][NP];
+    if (pre) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int m = m0 + (wm * TM + i) * 32 + prow + RPS * p;
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < a.M && ok0) {
+                    const _Float16* q = res16 + (size_t)out_row(a, m) * a.res_cs + a.res_co + nn;
+                    if (a.wide8) v = *reinterpret_cast<const h8*>(q);
+                    else {
+                        const h4 lo = *reinterpret_cast<const h4*>(q);
+                        h4 hi = {0, 0, 0, 0};
+                        if (ok1) hi = *reinterpret_cast<const h4*>(q + 4);
+                        v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+                rr[i][p] = v;
+            }
+    }
     mfma_tile((a.KT - 1) & 1);
     __syncthreads();
 
-    // ---- epilogue: each 32 x 32 sub-tile through a per-wave LDS stage, a lane then owns 4 consecutive channels of one pixel ----
-    float* stage = reinterpret_cast<float*>(smem) + wave * 1024;
-    const _Float16* res16 = reinterpret_cast<const _Float16*>(a.res);
-    _Float16* y16 = reinterpret_cast<_Float16*>(a.y);
+    float sc[TN], sf[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + (wn * TN + j) * 32;
-        const int n = nb + l31;
+        const int n = n0 + (wn * TN + j) * 32 + l31;
         const bool n_ok = n < a.Cout;
-        const float sc = (a.scale && n_ok) ? a.scale[n] : 1.0f, sf = (a.shift && n_ok) ? a.shift[n] : 0.0f;
+        sc[j] = (a.scale && n_ok) ? a.scale[n] : 1.0f;
+        sf[j] = (a.shift && n_ok) ? a.shift[n] : 0.0f;
+    }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm * TM + i) * 32;
+    for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + (wm * TM + i) * 32;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + l31] = acc[i][j][e] * sc + sf;
-            wave_lds_sync();
-            const int c4 = (lane & 7) * 4, nn = nb + c4;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int row = (lane >> 3) + 8 * p;
-                const int m = mb + row;
-                if (m < a.M && nn < a.Cout) {
-                    float4 v = *reinterpret_cast<const float4*>(stage + row * 32 + c4);
-                    const size_t mo = (size_t)out_row(a, m);
-                    if (a.res) {
-                        const size_t ro = mo * a.res_cs + a.res_co + nn;
-                        const float4 r = a.res16 ? fd_ld_h4(res16 + ro) : *reinterpret_cast<const float4*>(a.res + ro);
-                        if (a.res_mask) {
-                            v.x = r.x > 0.f ? v.x : 0.f; v.y = r.y > 0.f ? v.y : 0.f; v.z = r.z > 0.f ? v.z : 0.f; v.w = r.w > 0.f ? v.w : 0.f;
-                        } else {
-                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                        }
+            for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * SW + j * 32 + l31] = acc[i][j][e] * sc[j] + sf[j];
+        wave_lds_sync();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int row = prow + RPS * p;
+            const int m = mb + row;
+            if (m < a.M && ok0) {
+                const float4 v0 = *reinterpret_cast<const float4*>(stage + row * SW + c8), v1 = *reinterpret_cast<const float4*>(stage + row * SW + c8 + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                const size_t mo = (size_t)out_row(a, m);
+                if (a.res) {
+                    float r[8];
+                    if (pre) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) r[c] = (float)rr[i][p][c];
+                    } else {         // fp32 residual map
+                        const float* q = a.res + mo * a.res_cs + a.res_co + nn;
+                        const float4 r0 = *reinterpret_cast<const float4*>(q);
+                        float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok1) r1 = *reinterpret_cast<const float4*>(q + 4);
+                        r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
                     }
-                    if (a.act != FD_ACT_NONE) {
-                        if (nn + 0 >= a.act_c0) v.x = fd_act(v.x, a.act, 0.f);
-                        if (nn + 1 >= a.act_c0) v.y = fd_act(v.y, a.act, 0.f);
-                        if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, 0.f);
-                        if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, 0.f);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = a.res_mask ? (r[c] > 0.f ? v[c] : 0.f) : v[c] + r[c];
+                }
+                if (a.act != FD_ACT_NONE) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (nn + c >= a.act_c0) v[c] = fd_act(v[c], a.act, 0.f);
+                }
+                const size_t yo = mo * a.y_cs + a.y_co + nn;
+                if (a.y16) {
+                    const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+                    const h4 l4 = __builtin_convertvector(lo, h4), u4 = __builtin_convertvector(hi, h4);
+                    if (a.wide8) *reinterpret_cast<h8*>(y16 + yo) = __builtin_shufflevector(l4, u4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    else {
+                        *reinterpret_cast<h4*>(y16 + yo) = l4;
+                        if (ok1) *reinterpret_cast<h4*>(y16 + yo + 4) = u4;
                     }
-                    const size_t yo = mo * a.y_cs + a.y_co + nn;
-                    if (a.y16) fd_st_h4(y16 + yo, v);
-                    else *reinterpret_cast<float4*>(a.y + yo) = v;
+                } else {
+                    *reinterpret_cast<float4*>(a.y + yo) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (ok1) *reinterpret_cast<float4*>(a.y + yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 }
             }
-            wave_lds_sync();
         }
+        wave_lds_sync();
     }
 }
 
 template <int WGM, int WGN, int TM, int TN>
 static int launch_f16k64(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = WGM * WGN * 64;
-    constexpr int lds = 2 * (BM + BN) * 128;                  // >= the epilogue's 4 KB per wave
+    constexpr int lds = 2 * (BM + BN) * 128;                  // >= the epilogue's 32 x (32 TN + 4) floats per wave
+    static_assert(lds >= NT / 64 * 32 * (TN * 32 + 4) * 4, "epilogue stage");
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
@@ -227,8 +276,14 @@ int fd_launch_conv_f16k64(const fd_conv_params* p, ConvArgs& a, hipStream_t stre
     const long wb = (long)p->Cout * a.KT * 128;
     FD_REQUIRE(wb < 0xC0000000L, FD_E_UNSUPPORTED, "fd_conv2d: weight buffer exceeds 3 GiB");
     a.w_bytes = (unsigned)wb;
+    // 16-byte f16 accesses in the epilogue (eight channels per lane): the f16 views must be 8-channel aligned
+    a.wide8 = p->Cout % 8 == 0 && (!a.y16 || (p->y_cs % 8 == 0 && p->y_co % 8 == 0)) && (!(a.res && a.res16) || (p->res_cs % 8 == 0 && p->res_co % 8 == 0 && ((uintptr_t)p->res & 15) == 0));
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
     // the largest tile that still gives >= 2 workgroups per CU; narrow layers take the 64-wide tiles
+    static const int force = getenv("FD_F16K64_FORCE") ? atoi(getenv("FD_F16K64_FORCE")) : -1;     // EXPERIMENT
+    if (force == 0) return launch_f16k64<2, 2, 2, 2>(a, stream);
+    if (force == 1) return launch_f16k64<2, 2, 2, 1>(a, stream);
+    if (force == 2) return launch_f16k64<2, 2, 1, 1>(a, stream);
     if (a.Cout > 64 && blocks(128, 128) >= 512) return launch_f16k64<2, 2, 2, 2>(a, stream);
     if (blocks(128, 64) >= 512) return launch_f16k64<2, 2, 2, 1>(a, stream);
     return launch_f16k64<2, 2, 1, 1>(a, stream);

@@ -18,6 +18,7 @@ from . import _lib
 from ._lib import ACT_EXP, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ConvParams, FdError, Segs, check  # noqa: F401
 
 
+CONV_LOG = None     # a list: conv_call appends (closure, description) of every launch it builds (tools/time_train_convs.py replays them); None = off
 LAUNCHES = [0]      # C-ABI launches enqueued by this process (every wrapper asks for the stream once per launch): train_ops.SYNC_TRACE differences it
 
 
@@ -270,6 +271,12 @@ def conv_call(x: Rows, segs: Segs, w_packed: torch.Tensor, y: Rows, *, Cin: int,
         check(fn(ref, _stream()), "fd_conv2d_nhwc_f32")
 
     run.params = p  # type: ignore[attr-defined]   (autotuning rewrites p.tile in place)
+    if CONV_LOG is not None:
+        eb = lambda r: 2 if r.f16 else 4
+        rows_in = sum(segs.batch * segs.H[i] * segs.W[i] for i in range(segs.nseg))
+        CONV_LOG.append((run, dict(Cin=Cin, Cout=Cout, k=k, stride=stride, dil=dil, rows_in=rows_in, rows_out=y.rows, io=io, precision=precision, res=res is not None,
+                                   bytes=rows_in * Cin * eb(x) + y.rows * Cout * eb(y) + (y.rows * Cout * eb(res) if res is not None and not res_up else 0)
+                                   + w_packed.numel() * w_packed.element_size(), flops=2 * y.rows * Cout * Cin * k * (k if kw is None else kw))))
     return run
 
 
