@@ -10,8 +10,15 @@
 //   * 1x1 and k x k, any stride / dilation / padding, pyramids, explicit output size + scatter (the parity classes of a strided data gradient);
 //   * epilogue: scale / shift, residual add or ReLU mask (f16 or fp32 map), ReLU / SiLU / none, f16 or fp32 output; 4-channel aligned views.  No split-K, gate, gn_stats.
 #include "fd_conv_common.h"
+#include <type_traits>
+#ifndef FD_F16_DBG
+#define FD_F16_DBG 0     /* timing builds only (tools/_ab): 1 no MFMAs, 16 no residual fetch, 32 no output stores, 2 fetch only the first two K-tiles, 4 park only the first K-tile in LDS, 8 no LDS fragment reads */
+#endif
 
-template <int WGM, int WGN, int TM, int TN>
+// SIMPLE: the epilogue of most AMP layers -- f16 output in 16-byte accesses, no activation or ReLU on every channel, no output scatter, residual / mask (if any) an f16 map
+// in 16-byte accesses -- as its own instantiation: the general epilogue's code (per-channel activation start, SiLU, fp32 maps, 8-byte accesses, scatter) costs
+// instruction-cache misses even where no wave executes it (64 > 256 + residual: 128 us with the whole activation switch inlined, 88 us without, on the same bytes).
+template <int WGM, int WGN, int TM, int TN, bool SIMPLE>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs a) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NT = WGM * WGN * 64;
@@ -74,9 +81,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
         b_off[j] = (n < a.Cout) ? ((unsigned)n * (unsigned)a.KT * 64u + (unsigned)(chunk * 8)) * 2u : OOB;
     }
 
-    float4 ra[AP], ra2[AP], rb[BP];
+    // TWO register sets: the fetches of K-tile kt + 2 are issued while K-tile kt is multiplied (a K-tile's MFMAs are 0.25 us of work, a fetch takes 1 - 2 us: one tile
+    // ahead, every K-tile cost a whole memory latency -- 1.6 us per tile and workgroup on the 3x3 layers)
+    float4 ra[2][AP], ra2[2][AP], rb[2][BP];
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    int st_n = 0;
     int ld_cc = 0, ld_r = 0, ld_q = 0;      // K-tile = (64-channel chunk, filter row, filter column), advancing as counters
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, auto set) {
+        constexpr int S = decltype(set)::value;
+        if ((FD_F16_DBG & 2) && kt >= 2) return;
         const int dr = ld_r * a.dil, dq = ld_q * a.dil;
         const unsigned dbytes = (unsigned)(dq * a.x_cs + ld_cc * 64) << esh;
         const bool c_ok = ld_cc * 64 + chunk * 8 < a.Cin;
@@ -86,21 +100,23 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
             const int hi = a_hi0[i] + dr, wi = a_wi0[i] + dq;
             const bool ok = (unsigned)hi < (unsigned)a_H[i] && (unsigned)wi < (unsigned)a_W[i] && c_ok;
             const unsigned off = ok ? a_off[i] + (unsigned)__mul24(dr, a_wcs[i]) + dbytes : OOB;
-            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
-            if (!a.x16) ra2[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 16, 0));      // fp32 map: channels 4 .. 7 of the lane's eight
+            ra[S][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+            if (!a.x16) ra2[S][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 16, 0));      // fp32 map: channels 4 .. 7 of the lane's eight
         }
         const unsigned kb = (unsigned)kt * 128u;
 #pragma unroll
-        for (int j = 0; j < BP; ++j) rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(b_off[j] + kb), 0, 0));
+        for (int j = 0; j < BP; ++j) rb[S][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(b_off[j] + kb), 0, 0));
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, auto set) {
+        constexpr int S = decltype(set)::value;
+        if ((FD_F16_DBG & 4) && st_n++ > 0) return;
         float* Ab = Ls + buf * STG;
         float* Bb = Ab + BM * 32;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            float4 v = ra[i];
+            float4 v = ra[S][i];
             if (!a.x16) {       // (uniform) round the eight fp32 values once, to nearest even
-                const f32x4 lo = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, hi = {ra2[i].x, ra2[i].y, ra2[i].z, ra2[i].w};
+                const f32x4 lo = {ra[S][i].x, ra[S][i].y, ra[S][i].z, ra[S][i].w}, hi = {ra2[S][i].x, ra2[S][i].y, ra2[S][i].z, ra2[S][i].w};
                 const h4 l4 = __builtin_convertvector(lo, h4), h4_ = __builtin_convertvector(hi, h4);
                 const h8 p = {l4[0], l4[1], l4[2], l4[3], h4_[0], h4_[1], h4_[2], h4_[3]};
                 v = __builtin_bit_cast(float4, p);
@@ -108,12 +124,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
             *reinterpret_cast<float4*>(Ab + lds_off(lrow + RPP * i, chunk)) = v;
         }
 #pragma unroll
-        for (int j = 0; j < BP; ++j) *reinterpret_cast<float4*>(Bb + lds_off(lrow + RPP * j, chunk)) = rb[j];
+        for (int j = 0; j < BP; ++j) *reinterpret_cast<float4*>(Bb + lds_off(lrow + RPP * j, chunk)) = rb[S][j];
     };
 
     f32x16 acc[TM][TN];
 
     auto mfma_tile = [&](int buf) {
+        if (FD_F16_DBG & 1) return;
         const float* Ab = Ls + buf * STG + (wm * TM * 32) * 32;
         const float* Bb = Ls + buf * STG + BM * 32 + (wn * TN * 32) * 32;
         __builtin_amdgcn_s_setprio(1);
@@ -121,9 +138,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
         for (int ks = 0; ks < 4; ++ks) {        // four K-steps of 16: lane half lh carries k = 16 ks + 8 lh .. + 7 (one 16-byte chunk)
             h8 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const h8*>(Ab + lds_off(i * 32 + l31, 2 * ks + lh));
+            for (int i = 0; i < TM; ++i) fa[i] = (FD_F16_DBG & 8) ? h8{(_Float16)l31, 1, 1, 1, 1, 1, 1, 1} : *reinterpret_cast<const h8*>(Ab + lds_off(i * 32 + l31, 2 * ks + lh));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const h8*>(Bb + lds_off(j * 32 + l31, 2 * ks + lh));
+            for (int j = 0; j < TN; ++j) fb[j] = (FD_F16_DBG & 8) ? h8{(_Float16)lh, 1, 1, 1, 1, 1, 1, 1} : *reinterpret_cast<const h8*>(Bb + lds_off(j * 32 + l31, 2 * ks + lh));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -138,15 +155,22 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    load_tile(0);
-    store_tile(0);
+    load_tile(0, S0{});
+    if (a.KT > 1) load_tile(1, S1{});
+    store_tile(0, S0{});
     __syncthreads();
-    for (int kt = 0; kt < a.KT - 1; ++kt) {
-        const int buf = kt & 1;
-        load_tile(kt + 1);
-        mfma_tile(buf);
-        store_tile(buf ^ 1);
+    // step kt (parity P): fetch K-tile kt + 2 into register set P (emptied into LDS by step kt - 1), multiply buffer P, park K-tile kt + 1 (set 1 - P) in buffer 1 - P
+    for (int kt = 0; kt < a.KT - 1; kt += 2) {
+        if (kt + 2 < a.KT) load_tile(kt + 2, S0{});
+        mfma_tile(0);
+        store_tile(1, S1{});
         __syncthreads();
+        if (kt + 1 < a.KT - 1) {
+            if (kt + 3 < a.KT) load_tile(kt + 3, S1{});
+            mfma_tile(1);
+            store_tile(0, S0{});
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: the wave's 32-pixel x (TN * 32)-channel strips through a per-wave LDS stage; a lane then owns EIGHT consecutive channels of one pixel (16 bytes
@@ -161,6 +185,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
     const int nn = n0 + wn * TN * 32 + c8;
     const bool ok0 = nn < a.Cout, ok1 = nn + 4 < a.Cout;     // (Cout % 4 == 0: the lane's channels are valid in fours)
     const bool pre = a.res && a.res16;                       // (uniform)
+    const bool relu_all = a.act == FD_ACT_RELU && a.act_c0 <= n0;      // (uniform) ReLU on every channel of this tile
     h8 rr[TM][NP];
     if (pre) {
 #pragma unroll
@@ -169,9 +194,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
             for (int p = 0; p < NP; ++p) {
                 const int m = m0 + (wm * TM + i) * 32 + prow + RPS * p;
                 h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (m < a.M && ok0) {
-                    const _Float16* q = res16 + (size_t)out_row(a, m) * a.res_cs + a.res_co + nn;
-                    if (a.wide8) v = *reinterpret_cast<const h8*>(q);
+                if (m < a.M && ok0 && !(FD_F16_DBG & 16)) {
+                    const _Float16* q = res16 + (size_t)(SIMPLE ? m : out_row(a, m)) * a.res_cs + a.res_co + nn;
+                    if (SIMPLE || a.wide8) v = *reinterpret_cast<const h8*>(q);
                     else {
                         const h4 lo = *reinterpret_cast<const h4*>(q);
                         h4 hi = {0, 0, 0, 0};
@@ -208,10 +233,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
             if (m < a.M && ok0) {
                 const float4 v0 = *reinterpret_cast<const float4*>(stage + row * SW + c8), v1 = *reinterpret_cast<const float4*>(stage + row * SW + c8 + 4);
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                const size_t mo = (size_t)out_row(a, m);
+                const size_t mo = (size_t)(SIMPLE ? m : out_row(a, m));
                 if (a.res) {
                     float r[8];
-                    if (pre) {
+                    if (SIMPLE || pre) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c) r[c] = (float)rr[i][p][c];
                     } else {         // fp32 residual map
@@ -224,16 +249,29 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
 #pragma unroll
                     for (int c = 0; c < 8; ++c) v[c] = a.res_mask ? (r[c] > 0.f ? v[c] : 0.f) : v[c] + r[c];
                 }
-                if (a.act != FD_ACT_NONE) {
+                if (relu_all) {          // (uniform) the common case as eight v_max: no per-channel compare, no activation switch
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        if (nn + c >= a.act_c0) v[c] = fd_act(v[c], a.act, 0.f);
+                    for (int c = 0; c < 8; ++c) v[c] = fd_act(v[c], FD_ACT_RELU, 0.f);
+                } else if (SIMPLE) {
+                } else if (a.act == FD_ACT_SILU) {      // (the launcher admits ReLU, SiLU, none; selects, not branches: with fd_act's whole switch behind a branch per
+#pragma unroll                                  // channel the epilogue was 11 000 instructions, past the instruction cache)
+                    for (int c = 0; c < 8; ++c) {
+                        const float t = fd_act(v[c], FD_ACT_SILU, 0.f);
+                        v[c] = nn + c >= a.act_c0 ? t : v[c];
+                    }
+                } else if (a.act == FD_ACT_RELU) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float t = fd_act(v[c], FD_ACT_RELU, 0.f);
+                        v[c] = nn + c >= a.act_c0 ? t : v[c];
+                    }
                 }
                 const size_t yo = mo * a.y_cs + a.y_co + nn;
-                if (a.y16) {
+                if ((FD_F16_DBG & 32) && v[0] != 123.25f) continue;
+                if (SIMPLE || a.y16) {
                     const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
                     const h4 l4 = __builtin_convertvector(lo, h4), u4 = __builtin_convertvector(hi, h4);
-                    if (a.wide8) *reinterpret_cast<h8*>(y16 + yo) = __builtin_shufflevector(l4, u4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (SIMPLE || a.wide8) *reinterpret_cast<h8*>(y16 + yo) = __builtin_shufflevector(l4, u4, 0, 1, 2, 3, 4, 5, 6, 7);
                     else {
                         *reinterpret_cast<h4*>(y16 + yo) = l4;
                         if (ok1) *reinterpret_cast<h4*>(y16 + yo + 4) = u4;
@@ -248,20 +286,26 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
     }
 }
 
-template <int WGM, int WGN, int TM, int TN>
-static int launch_f16k64(const ConvArgs& a, hipStream_t stream) {
+template <int WGM, int WGN, int TM, int TN, bool SIMPLE>
+static int launch_f16k64_e(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = WGM * WGN * 64;
     constexpr int lds = 2 * (BM + BN) * 128;                  // >= the epilogue's 32 x (32 TN + 4) floats per wave
     static_assert(lds >= NT / 64 * 32 * (TN * 32 + 4) * 4, "epilogue stage");
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    auto kern = conv_f16k64_kernel<WGM, WGN, TM, TN>;
+    auto kern = conv_f16k64_kernel<WGM, WGN, TM, TN, SIMPLE>;
     static std::atomic<unsigned> attr_mask{0};
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles), dim3(NT), lds, stream, b);
     FD_CHECK_LAUNCH("fd_conv2d_nhwc_f32 (FD_TILE_F16K64)");
     return FD_OK;
+}
+
+template <int WGM, int WGN, int TM, int TN>
+static int launch_f16k64(const ConvArgs& a, hipStream_t stream) {
+    const bool simple = (a.act == FD_ACT_NONE || (a.act == FD_ACT_RELU && a.act_c0 <= 0)) && !a.sc_on && a.y16 && a.wide8 && (!a.res || a.res16);
+    return simple ? launch_f16k64_e<WGM, WGN, TM, TN, true>(a, stream) : launch_f16k64_e<WGM, WGN, TM, TN, false>(a, stream);
 }
 
 // `a`: the argument block fd_conv2d_nhwc_f32 has filled (geometry, views, epilogue, io_f16 flags); p->w = the mode | 16 packing
