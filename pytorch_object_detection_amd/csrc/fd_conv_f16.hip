@@ -12,13 +12,13 @@
 #include "fd_conv_common.h"
 #include <type_traits>
 #ifndef FD_F16_DBG
-#define FD_F16_DBG 0     /* timing builds only (tools/_ab): 1 no MFMAs, 16 no residual fetch, 32 no output stores, 2 fetch only the first two K-tiles, 4 park only the first K-tile in LDS, 8 no LDS fragment reads */
+#define FD_F16_DBG 0     /* timing builds only (tools/_ab): 1 no MFMAs, 16 no residual fetch, 32 no output stores, 2 fetch only the first two K-tiles */
 #endif
 
 // SIMPLE: the epilogue of most AMP layers -- f16 output in 16-byte accesses, no activation or ReLU on every channel, no output scatter, residual / mask (if any) an f16 map
 // in 16-byte accesses -- as its own instantiation: the general epilogue's code (per-channel activation start, SiLU, fp32 maps, 8-byte accesses, scatter) costs
 // instruction-cache misses even where no wave executes it (64 > 256 + residual: 128 us with the whole activation switch inlined, 88 us without, on the same bytes).
-template <int WGM, int WGN, int TM, int TN, bool SIMPLE>
+template <int WGM, int WGN, int TM, int TN, bool SIMPLE, bool X16>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs a) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NT = WGM * WGN * 64;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
 
     const int lrow = tid >> 3, chunk = tid & 7;          // this lane: row lrow (+ RPP per pass), channels 8 chunk .. 8 chunk + 7 of the K-tile
     constexpr unsigned OOB = 0xC0000000u;
-    const int esh = a.x16 ? 1 : 2;                       // (uniform) bytes per input element, as a shift
+    constexpr int esh = X16 ? 1 : 2;                     // bytes per input element, as a shift (X16: the input map is stored as f16)
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, (int)a.w_bytes, 0x00020000);
     unsigned a_off[AP];
@@ -83,10 +83,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
 
     // TWO register sets: the fetches of K-tile kt + 2 are issued while K-tile kt is multiplied (a K-tile's MFMAs are 0.25 us of work, a fetch takes 1 - 2 us: one tile
     // ahead, every K-tile cost a whole memory latency -- 1.6 us per tile and workgroup on the 3x3 layers)
-    float4 ra[2][AP], ra2[2][AP], rb[2][BP];
+    float4 ra[2][AP], ra2[2][X16 ? 1 : AP], rb[2][BP];
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
-    int st_n = 0;
     int ld_cc = 0, ld_r = 0, ld_q = 0;      // K-tile = (64-channel chunk, filter row, filter column), advancing as counters
     auto load_tile = [&](int kt, auto set) {
         constexpr int S = decltype(set)::value;
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
             const bool ok = (unsigned)hi < (unsigned)a_H[i] && (unsigned)wi < (unsigned)a_W[i] && c_ok;
             const unsigned off = ok ? a_off[i] + (unsigned)__mul24(dr, a_wcs[i]) + dbytes : OOB;
             ra[S][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
-            if (!a.x16) ra2[S][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 16, 0));      // fp32 map: channels 4 .. 7 of the lane's eight
+            if constexpr (!X16) ra2[S][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 16, 0));      // fp32 map: channels 4 .. 7 of the lane's eight
         }
         const unsigned kb = (unsigned)kt * 128u;
 #pragma unroll
@@ -109,13 +108,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
     };
     auto store_tile = [&](int buf, auto set) {
         constexpr int S = decltype(set)::value;
-        if ((FD_F16_DBG & 4) && st_n++ > 0) return;
         float* Ab = Ls + buf * STG;
         float* Bb = Ab + BM * 32;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             float4 v = ra[S][i];
-            if (!a.x16) {       // (uniform) round the eight fp32 values once, to nearest even
+            if constexpr (!X16) {       // round the eight fp32 values once, to nearest even
                 const f32x4 lo = {ra[S][i].x, ra[S][i].y, ra[S][i].z, ra[S][i].w}, hi = {ra2[S][i].x, ra2[S][i].y, ra2[S][i].z, ra2[S][i].w};
                 const h4 l4 = __builtin_convertvector(lo, h4), h4_ = __builtin_convertvector(hi, h4);
                 const h8 p = {l4[0], l4[1], l4[2], l4[3], h4_[0], h4_[1], h4_[2], h4_[3]};
@@ -129,25 +127,61 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
 
     f32x16 acc[TM][TN];
 
-    auto mfma_tile = [&](int buf) {
+    // one parked row: element idx of the AP + BP (A rows first) of register set S into buffer `buf`
+    auto store_one = [&](int buf, auto set, int idx) {
+        constexpr int S = decltype(set)::value;
+        float* Ab = Ls + buf * STG;
+        float* Bb = Ab + BM * 32;
+        if (idx < AP) {
+            float4 v = ra[S][idx];
+            if constexpr (!X16) {
+                const f32x4 lo = {ra[S][idx].x, ra[S][idx].y, ra[S][idx].z, ra[S][idx].w}, hi = {ra2[S][idx].x, ra2[S][idx].y, ra2[S][idx].z, ra2[S][idx].w};
+                const h4 l4 = __builtin_convertvector(lo, h4), h4_ = __builtin_convertvector(hi, h4);
+                const h8 p = {l4[0], l4[1], l4[2], l4[3], h4_[0], h4_[1], h4_[2], h4_[3]};
+                v = __builtin_bit_cast(float4, p);
+            }
+            *reinterpret_cast<float4*>(Ab + lds_off(lrow + RPP * idx, chunk)) = v;
+        } else {
+            *reinterpret_cast<float4*>(Bb + lds_off(lrow + RPP * (idx - AP), chunk)) = rb[S][idx - AP];
+        }
+    };
+    // multiply buffer `buf`; PARK: meanwhile park register set S (K-tile kt + 1) in the other buffer, a quarter of its rows behind each K-step's MFMAs -- parked after
+    // the last MFMA, the 13-cycle ds_write_b128s and the fragment reads of the next step ran with the matrix pipe idle (MFMA-only 83 us, + reads 112, + fetch / park 159).
+    // Fragments of K-step ks + 1 are read before the MFMAs of ks.
+    auto mfma_tile = [&](int buf, auto set, auto park) {
+        constexpr bool PARK = decltype(park)::value;
         if (FD_F16_DBG & 1) return;
         const float* Ab = Ls + buf * STG + (wm * TM * 32) * 32;
         const float* Bb = Ls + buf * STG + BM * 32 + (wn * TN * 32) * 32;
+        h8 fa[2][TM], fb[2][TN];
+        auto frags = [&](int ks, int q) {       // four K-steps of 16: lane half lh carries k = 16 ks + 8 lh .. + 7 (one 16-byte chunk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const h8*>(Ab + lds_off(i * 32 + l31, 2 * ks + lh));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const h8*>(Bb + lds_off(j * 32 + l31, 2 * ks + lh));
+        };
+        frags(0, 0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {        // four K-steps of 16: lane half lh carries k = 16 ks + 8 lh .. + 7 (one 16-byte chunk)
-            h8 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = (FD_F16_DBG & 8) ? h8{(_Float16)l31, 1, 1, 1, 1, 1, 1, 1} : *reinterpret_cast<const h8*>(Ab + lds_off(i * 32 + l31, 2 * ks + lh));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = (FD_F16_DBG & 8) ? h8{(_Float16)lh, 1, 1, 1, 1, 1, 1, 1} : *reinterpret_cast<const h8*>(Bb + lds_off(j * 32 + l31, 2 * ks + lh));
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) frags(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);        // (the scheduler sinks these reads below the MFMAs otherwise: the matrix pipe then waits for them every K-step)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+                    if constexpr (PARK) {       // this K-step's share of the parked rows, one behind each MFMA
+                        const int idx = ks * (AP + BP) / 4 + i * TN + j;
+                        if (idx < (ks + 1) * (AP + BP) / 4) store_one(buf ^ 1, set, idx);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
     };
+    typedef std::integral_constant<bool, true> PK;
+    typedef std::integral_constant<bool, false> NPK;
 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -162,13 +196,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
     // step kt (parity P): fetch K-tile kt + 2 into register set P (emptied into LDS by step kt - 1), multiply buffer P, park K-tile kt + 1 (set 1 - P) in buffer 1 - P
     for (int kt = 0; kt < a.KT - 1; kt += 2) {
         if (kt + 2 < a.KT) load_tile(kt + 2, S0{});
-        mfma_tile(0);
-        store_tile(1, S1{});
+        mfma_tile(0, S1{}, PK{});
         __syncthreads();
         if (kt + 1 < a.KT - 1) {
             if (kt + 3 < a.KT) load_tile(kt + 3, S1{});
-            mfma_tile(1);
-            store_tile(0, S0{});
+            mfma_tile(1, S0{}, PK{});
             __syncthreads();
         }
     }
@@ -207,7 +239,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
                 rr[i][p] = v;
             }
     }
-    mfma_tile((a.KT - 1) & 1);
+    mfma_tile((a.KT - 1) & 1, S0{}, NPK{});
     __syncthreads();
 
     float sc[TN], sf[TN];
@@ -286,7 +318,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, bool SIMPLE>
+template <int WGM, int WGN, int TM, int TN, bool SIMPLE, bool X16>
 static int launch_f16k64_e(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = WGM * WGN * 64;
     constexpr int lds = 2 * (BM + BN) * 128;                  // >= the epilogue's 32 x (32 TN + 4) floats per wave
@@ -294,7 +326,7 @@ static int launch_f16k64_e(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.mtiles = (a.M + BM - 1) / BM;
     b.ntiles = (a.Cout + BN - 1) / BN;
-    auto kern = conv_f16k64_kernel<WGM, WGN, TM, TN, SIMPLE>;
+    auto kern = conv_f16k64_kernel<WGM, WGN, TM, TN, SIMPLE, X16>;
     static std::atomic<unsigned> attr_mask{0};
     fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(b.mtiles * b.ntiles), dim3(NT), lds, stream, b);
@@ -305,7 +337,8 @@ static int launch_f16k64_e(const ConvArgs& a, hipStream_t stream) {
 template <int WGM, int WGN, int TM, int TN>
 static int launch_f16k64(const ConvArgs& a, hipStream_t stream) {
     const bool simple = (a.act == FD_ACT_NONE || (a.act == FD_ACT_RELU && a.act_c0 <= 0)) && !a.sc_on && a.y16 && a.wide8 && (!a.res || a.res16);
-    return simple ? launch_f16k64_e<WGM, WGN, TM, TN, true>(a, stream) : launch_f16k64_e<WGM, WGN, TM, TN, false>(a, stream);
+    if (a.x16) return simple ? launch_f16k64_e<WGM, WGN, TM, TN, true, true>(a, stream) : launch_f16k64_e<WGM, WGN, TM, TN, false, true>(a, stream);
+    return simple ? launch_f16k64_e<WGM, WGN, TM, TN, true, false>(a, stream) : launch_f16k64_e<WGM, WGN, TM, TN, false, false>(a, stream);
 }
 
 // `a`: the argument block fd_conv2d_nhwc_f32 has filled (geometry, views, epilogue, io_f16 flags); p->w = the mode | 16 packing
