@@ -12,7 +12,7 @@
 #include "fd_conv_common.h"
 #include <type_traits>
 #ifndef FD_F16_DBG
-#define FD_F16_DBG 0     /* timing builds only (tools/_ab): 1 no MFMAs, 16 no residual fetch, 32 no output stores, 2 fetch only the first two K-tiles */
+#define FD_F16_DBG 0     /* timing builds only (tools/_ab): 1 no MFMAs, 16 no residual fetch, 32 no output stores, 2 fetch only the first two K-tiles, 4 park nothing in the loop, 8 no fragment reads */
 #endif
 
 // SIMPLE: the epilogue of most AMP layers -- f16 output in 16-byte accesses, no activation or ReLU on every channel, no output scatter, residual / mask (if any) an f16 map
@@ -87,24 +87,34 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
     int ld_cc = 0, ld_r = 0, ld_q = 0;      // K-tile = (64-channel chunk, filter row, filter column), advancing as counters
-    auto load_tile = [&](int kt, auto set) {
-        constexpr int S = decltype(set)::value;
-        if ((FD_F16_DBG & 2) && kt >= 2) return;
-        const int dr = ld_r * a.dil, dq = ld_q * a.dil;
-        const unsigned dbytes = (unsigned)(dq * a.x_cs + ld_cc * 64) << esh;
-        const bool c_ok = ld_cc * 64 + chunk * 8 < a.Cin;
+    struct LdCtx { int dr, dq; unsigned dbytes, kb; bool c_ok; };
+    auto load_begin = [&](int kt, bool live) {           // the K-tile the counters point at; live = false: every fetch of it is out of range (no memory traffic)
+        LdCtx c;
+        c.dr = ld_r * a.dil; c.dq = ld_q * a.dil;
+        c.dbytes = (unsigned)(c.dq * a.x_cs + ld_cc * 64) << esh;
+        c.c_ok = live & (ld_cc * 64 + chunk * 8 < a.Cin);
+        c.kb = live ? (unsigned)kt * 128u : OOB;
+        if ((FD_F16_DBG & 2) && kt >= 2) { c.c_ok = false; c.kb = OOB; }
         if (++ld_q == a.KW) { ld_q = 0; if (++ld_r * a.KW == a.ntaps) { ld_r = 0; ++ld_cc; } }
-#pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            const int hi = a_hi0[i] + dr, wi = a_wi0[i] + dq;
-            const bool ok = (unsigned)hi < (unsigned)a_H[i] && (unsigned)wi < (unsigned)a_W[i] && c_ok;
-            const unsigned off = ok ? a_off[i] + (unsigned)__mul24(dr, a_wcs[i]) + dbytes : OOB;
-            ra[S][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
-            if constexpr (!X16) ra2[S][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 16, 0));      // fp32 map: channels 4 .. 7 of the lane's eight
+        return c;
+    };
+    auto load_one = [&](const LdCtx& c, auto set, int idx) {      // row idx of the AP + BP (A rows first) of that K-tile into register set S
+        constexpr int S = decltype(set)::value;
+        if (idx < AP) {
+            const int hi = a_hi0[idx] + c.dr, wi = a_wi0[idx] + c.dq;
+            const bool ok = ((unsigned)hi < (unsigned)a_H[idx]) & ((unsigned)wi < (unsigned)a_W[idx]) & c.c_ok;      // (&, not &&: no branches between the MFMAs)
+            const unsigned off = ok ? a_off[idx] + (unsigned)__mul24(c.dr, a_wcs[idx]) + c.dbytes : OOB;
+            ra[S][idx] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+            if constexpr (!X16) ra2[S][idx] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 16, 0));      // fp32 map: channels 4 .. 7 of the lane's eight
+        } else {
+            const unsigned bo = b_off[idx - AP];
+            rb[S][idx - AP] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(((bo == OOB) | (c.kb == OOB)) ? OOB : bo + c.kb), 0, 0));
         }
-        const unsigned kb = (unsigned)kt * 128u;
+    };
+    auto load_tile = [&](int kt, auto set) {
+        const LdCtx c = load_begin(kt, true);
 #pragma unroll
-        for (int j = 0; j < BP; ++j) rb[S][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(b_off[j] + kb), 0, 0));
+        for (int idx = 0; idx < AP + BP; ++idx) load_one(c, set, idx);
     };
     auto store_tile = [&](int buf, auto set) {
         constexpr int S = decltype(set)::value;
@@ -130,6 +140,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
     // one parked row: element idx of the AP + BP (A rows first) of register set S into buffer `buf`
     auto store_one = [&](int buf, auto set, int idx) {
         constexpr int S = decltype(set)::value;
+        if (FD_F16_DBG & 4) return;
         float* Ab = Ls + buf * STG;
         float* Bb = Ab + BM * 32;
         if (idx < AP) {
@@ -148,17 +159,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
     // multiply buffer `buf`; PARK: meanwhile park register set S (K-tile kt + 1) in the other buffer, a quarter of its rows behind each K-step's MFMAs -- parked after
     // the last MFMA, the 13-cycle ds_write_b128s and the fragment reads of the next step ran with the matrix pipe idle (MFMA-only 83 us, + reads 112, + fetch / park 159).
     // Fragments of K-step ks + 1 are read before the MFMAs of ks.
-    auto mfma_tile = [&](int buf, auto set, auto park) {
-        constexpr bool PARK = decltype(park)::value;
+    auto mfma_tile = [&](int buf, auto set, auto park, auto lset, int kt_load, bool live) {
+        constexpr bool PARK = decltype(park)::value;      // (PARK steps also FETCH K-tile kt_load into register set lset, a row behind every other MFMA)
         if (FD_F16_DBG & 1) return;
+        LdCtx lc{};
+        if constexpr (PARK) lc = load_begin(kt_load, live);
+        constexpr int NS = 4 * TM * TN, NI = 2 * (AP + BP);        // MFMA slots; rows to park + rows to fetch, taken alternately
         const float* Ab = Ls + buf * STG + (wm * TM * 32) * 32;
         const float* Bb = Ls + buf * STG + BM * 32 + (wn * TN * 32) * 32;
         h8 fa[2][TM], fb[2][TN];
         auto frags = [&](int ks, int q) {       // four K-steps of 16: lane half lh carries k = 16 ks + 8 lh .. + 7 (one 16-byte chunk)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const h8*>(Ab + lds_off(i * 32 + l31, 2 * ks + lh));
+            for (int i = 0; i < TM; ++i) fa[q][i] = (FD_F16_DBG & 8) ? h8{(_Float16)l31, 1, 1, 1, 1, 1, 1, 1} : *reinterpret_cast<const h8*>(Ab + lds_off(i * 32 + l31, 2 * ks + lh));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const h8*>(Bb + lds_off(j * 32 + l31, 2 * ks + lh));
+            for (int j = 0; j < TN; ++j) fb[q][j] = (FD_F16_DBG & 8) ? h8{(_Float16)lh, 1, 1, 1, 1, 1, 1, 1} : *reinterpret_cast<const h8*>(Bb + lds_off(j * 32 + l31, 2 * ks + lh));
         };
         frags(0, 0);
         __builtin_amdgcn_s_setprio(1);
@@ -171,9 +185,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
-                    if constexpr (PARK) {       // this K-step's share of the parked rows, one behind each MFMA
-                        const int idx = ks * (AP + BP) / 4 + i * TN + j;
-                        if (idx < (ks + 1) * (AP + BP) / 4) store_one(buf ^ 1, set, idx);
+                    if constexpr (PARK) {       // this slot's share of the rows: item t even = park row t / 2, odd = fetch row t / 2
+                        const int slot = ks * TM * TN + i * TN + j;
+#pragma unroll
+                        for (int t = slot * NI / NS; t < (slot + 1) * NI / NS; ++t) {
+                            if (t & 1) load_one(lc, lset, t >> 1);
+                            else store_one(buf ^ 1, set, t >> 1);
+                        }
                     }
                 }
             __builtin_amdgcn_sched_barrier(0);
@@ -193,16 +211,18 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
     if (a.KT > 1) load_tile(1, S1{});
     store_tile(0, S0{});
     __syncthreads();
-    // step kt (parity P): fetch K-tile kt + 2 into register set P (emptied into LDS by step kt - 1), multiply buffer P, park K-tile kt + 1 (set 1 - P) in buffer 1 - P
-    for (int kt = 0; kt < a.KT - 1; kt += 2) {
-        if (kt + 2 < a.KT) load_tile(kt + 2, S0{});
-        mfma_tile(0, S1{}, PK{});
+    // step kt (parity P): multiply buffer P; behind its MFMAs fetch K-tile kt + 2 into register set P (emptied into LDS by step kt - 1) and park K-tile kt + 1 (set 1 - P)
+    // in buffer 1 - P.  (The fetches' address arithmetic ahead of the first MFMA left the matrix pipe idle for ~400 cycles per K-tile.)
+    int kt = 0;
+    for (; kt + 2 <= a.KT - 1; kt += 2) {          // (two steps per trip, nothing conditional inside: one basic block, so the waits on the fetches stay counted)
+        mfma_tile(0, S1{}, PK{}, S0{}, kt + 2, kt + 2 < a.KT);
         __syncthreads();
-        if (kt + 1 < a.KT - 1) {
-            if (kt + 3 < a.KT) load_tile(kt + 3, S1{});
-            mfma_tile(1, S0{}, PK{});
-            __syncthreads();
-        }
+        mfma_tile(1, S0{}, PK{}, S1{}, kt + 3, kt + 3 < a.KT);
+        __syncthreads();
+    }
+    if (kt < a.KT - 1) {
+        mfma_tile(0, S1{}, PK{}, S0{}, kt + 2, false);
+        __syncthreads();
     }
 
     // ---- epilogue: the wave's 32-pixel x (TN * 32)-channel strips through a per-wave LDS stage; a lane then owns EIGHT consecutive channels of one pixel (16 bytes
@@ -239,7 +259,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_f16k64_kernel(ConvArgs
                 rr[i][p] = v;
             }
     }
-    mfma_tile((a.KT - 1) & 1, S0{}, NPK{});
+    mfma_tile((a.KT - 1) & 1, S0{}, NPK{}, S0{}, 0, false);
     __syncthreads();
 
     float sc[TN], sf[TN];
