@@ -199,10 +199,13 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 __device__ __forceinline__ int wg16_off(int row, int chunk) { return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-__global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(WgradArgs a) {
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WAVES_N = 2;
-    __shared__ __attribute__((aligned(16))) char As[32 * 256];      // [32 pixels][128 co] f16
-    __shared__ __attribute__((aligned(16))) char Bs[32 * 256];      // [32 pixels][128 ci] f16
+// Round 5: K-tiles of 64 pixels in two LDS buffers (one barrier per 16 MFMAs; the first form had 32-pixel tiles, one buffer, two barriers per 8 MFMAs), 16-byte
+// fetches (eight channels per lane) and, as in fd_conv_f16.hip, the parking stores of tile t + 1 and the fetches of tile t + 2 one behind each MFMA of tile t.
+template <bool X16, bool DY16, bool GEMM>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(WgradArgs a) {
+    constexpr int TM = 2, TN = 2, WAVES_N = 2, BM = 128, BN = 128;
+    constexpr int BUF = 2 * 64 * 256;                                 // bytes per buffer: [64 pixels][128 co] f16, then [64 pixels][128 ci] f16
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -213,66 +216,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(WgradArgs a) {
     const int cot = t / a.ntaps;
     const int co0 = cot * BM, ci0 = cit * BN;
     const int fr = tap / a.KW, fq = tap - fr * a.KW;
-    const int m_begin = a.is_gemm ? blockIdx.y * a.rows_per_split : a.r_begin[blockIdx.y];
-    const int m_end = a.is_gemm ? min(a.M, m_begin + a.rows_per_split) : a.r_end[blockIdx.y];
+    const int m_begin = GEMM ? blockIdx.y * a.rows_per_split : a.r_begin[blockIdx.y];
+    const int m_end = GEMM ? min(a.M, m_begin + a.rows_per_split) : a.r_end[blockIdx.y];
 
     constexpr unsigned OOB = 0xC0000000u;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, (short)0, (int)a.dy_bytes, 0x00020000);
 
-    // staging: 32 threads per pixel row (4 channels each), 8 rows per pass, 4 passes for the 32 pixels of a K-tile
-    const int srow = tid >> 5, sc4 = tid & 31;
-    const bool a_col_ok = co0 + sc4 * 4 < a.Cout, b_col_ok = ci0 + sc4 * 4 < a.Cin;
-    const int gs = a.is_gemm ? 0 : a.r_seg[blockIdx.y];
+    // staging: 16 threads per pixel row (8 channels each: 16 bytes of an f16 map, 2 x 16 of an fp32 one), 16 rows per pass, 4 passes for the 64 pixels of a K-tile.
+    // Channels past Cout / Cin inside a lane's eight are fetched as they lie (the descriptor bounds the buffer): they only reach rows / columns of the tile that
+    // are never stored.
+    const int srow = tid >> 4, sc8 = tid & 15;
+    const bool a_col_ok = co0 + sc8 * 8 < a.Cout, b_col_ok = ci0 + sc8 * 8 < a.Cin;
+    const int gs = GEMM ? 0 : a.r_seg[blockIdx.y];
     const int g_Wo = a.Wo[gs], g_hw = a.Ho[gs] * a.Wo[gs], g_H = a.H[gs], g_W = a.W[gs], g_mout = a.m_out[gs], g_min = a.m_in[gs];
     const unsigned g_mgh = a.mg_hw[gs], g_mgw = a.mg_w[gs];
     const int g_shh = a.sh_hw[gs], g_shw = a.sh_w[gs];
+    const unsigned a_c = (unsigned)(a.dy_co + co0 + sc8 * 8), b_c = (unsigned)(a.x_co + ci0 + sc8 * 8);
 
-    float4 ra[4], rb[4];
-    const int xsh = a.x16 ? 1 : 2, ysh = a.dy16 ? 1 : 2;        // (uniform) element size of the operand maps: f16 maps are fetched 8 bytes per lane and staged unconverted
-    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, bool f16) -> float4 {
-        if (f16) {
-            const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0));      // (whole-vector cast: see fd_conv.hip)
-            return make_float4(v.x, v.y, 0.f, 0.f);
-        }
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+    float4 ra[4], ra2[DY16 ? 1 : 4], rb[4], rb2[X16 ? 1 : 4];
+    auto load_a = [&](int m0, int i) {
+        const int m = m0 + srow + 16 * i;
+        const unsigned off = ((unsigned)m * (unsigned)a.dy_cs + a_c) << (DY16 ? 1 : 2);
+        const unsigned o = ((m < m_end) & a_col_ok) ? off : OOB;
+        ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(yrsrc, (int)o, 0, 0));
+        if constexpr (!DY16) ra2[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(yrsrc, (int)o, 16, 0));
     };
-    auto load_tile = [&](int m0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + srow + 8 * i;
-            const unsigned off = ((unsigned)m * (unsigned)a.dy_cs + (unsigned)(a.dy_co + co0 + sc4 * 4)) << ysh;
-            ra[i] = ld4(yrsrc, (m < m_end && a_col_ok) ? off : OOB, a.dy16 != 0);
-            unsigned xo = OOB;
-            if (m < m_end && b_col_ok) {
-                if (a.is_gemm) {
-                    xo = ((unsigned)m * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + sc4 * 4)) << xsh;
-                } else {
-                    const int local = m - g_mout;
-                    const int n = fast_div(local, g_mgh, g_shh);
-                    const int rem = local - n * g_hw;
-                    const int ho = fast_div(rem, g_mgw, g_shw), wo = rem - ho * g_Wo;
-                    const int hi = ho * a.stride - a.pad + fr * a.dil, wi = wo * a.stride - a.pad + fq * a.dil;
-                    if ((unsigned)hi < (unsigned)g_H && (unsigned)wi < (unsigned)g_W)
-                        xo = ((unsigned)(g_min + (n * g_H + hi) * g_W + wi) * (unsigned)a.x_cs + (unsigned)(a.x_co + ci0 + sc4 * 4)) << xsh;
-                }
-            }
-            rb[i] = ld4(xrsrc, xo, a.x16 != 0);
-        }
+    auto fdiv = [](int n, unsigned mg, int sh) {      // fast_div() without its branch (magic 0 = divisor 1): nothing may split the MFMA block
+        const int q = (int)(__umulhi((unsigned)n, mg) >> sh);
+        return __builtin_amdgcn_readfirstlane((int)(mg != 0)) ? q : n;
     };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = srow + 8 * i;
-            const int off = wg16_off(row, sc4 >> 1) + 8 * (sc4 & 1);
-            const f32x4 va = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, vb = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
-            h4 ha = __builtin_convertvector(va, h4), hb = __builtin_convertvector(vb, h4);       // round to nearest
-            if (a.dy16) ha = fd_h4_bits(ra[i].x, ra[i].y);               // (already f16: the bits as loaded)
-            if (a.x16) hb = fd_h4_bits(rb[i].x, rb[i].y);
-            *reinterpret_cast<h4*>(As + off) = ha;
-            *reinterpret_cast<h4*>(Bs + off) = hb;
+    auto load_b = [&](int m0, int i) {
+        const int m = m0 + srow + 16 * i;
+        unsigned row = (unsigned)m;
+        bool ok = (m < m_end) & b_col_ok;
+        if constexpr (!GEMM) {
+            const int local = m - g_mout;
+            const int n = fdiv(local, g_mgh, g_shh);
+            const int rem = local - n * g_hw;
+            const int ho = fdiv(rem, g_mgw, g_shw), wo = rem - ho * g_Wo;
+            const int hi = ho * a.stride - a.pad + fr * a.dil, wi = wo * a.stride - a.pad + fq * a.dil;
+            ok = ok & ((unsigned)hi < (unsigned)g_H) & ((unsigned)wi < (unsigned)g_W);
+            row = (unsigned)(g_min + (n * g_H + hi) * g_W + wi);
         }
+        const unsigned o = ok ? (row * (unsigned)a.x_cs + b_c) << (X16 ? 1 : 2) : OOB;
+        rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)o, 0, 0));
+        if constexpr (!X16) rb2[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)o, 16, 0));
     };
+    auto h8_of = [&](const float4& lo4, const float4& hi4, bool is16) -> float4 {      // the lane's eight channels as f16 (fp32 maps: rounded to nearest even)
+        if (is16) return lo4;
+        const f32x4 lo = {lo4.x, lo4.y, lo4.z, lo4.w}, hi = {hi4.x, hi4.y, hi4.z, hi4.w};
+        const h4 l4 = __builtin_convertvector(lo, h4), u4 = __builtin_convertvector(hi, h4);
+        const h8 p = __builtin_shufflevector(l4, u4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(float4, p);
+    };
+    auto park_a = [&](char* buf, int i) { *reinterpret_cast<float4*>(buf + wg16_off(srow + 16 * i, sc8)) = h8_of(ra[i], ra2[DY16 ? 0 : i], DY16); };
+    auto park_b = [&](char* buf, int i) { *reinterpret_cast<float4*>(buf + 64 * 256 + wg16_off(srow + 16 * i, sc8)) = h8_of(rb[i], rb2[X16 ? 0 : i], X16); };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -297,26 +296,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(WgradArgs a) {
     };
 
     if (m_begin < m_end) {
-        load_tile(m_begin);
-        for (int m0 = m_begin; m0 < m_end; m0 += 32) {
-            __syncthreads();                 // previous tile fully consumed
-            store_tile();
-            __syncthreads();
-            if (m0 + 32 < m_end) load_tile(m0 + 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { load_a(m_begin, i); load_b(m_begin, i); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { park_a(wsm, i); park_b(wsm, i); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { load_a(m_begin + 64, i); load_b(m_begin + 64, i); }
+        __syncthreads();
+        int cur = 0;
+        for (int m0 = m_begin; m0 < m_end; m0 += 64) {
+            // multiply the tile at m0 (buffer cur); behind its MFMAs park the registers (tile m0 + 64) in the other buffer and refill them with the tile at m0 + 128
+            const char* Ab = wsm + cur * BUF;
+            const char* Bb = Ab + 64 * 256;
+            char* Pw = wsm + (cur ^ 1) * BUF;
+            h8 fa[2][TM], fb[2][TN];
+            auto frags = [&](int ks, int q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[q][i] = tr_read(Ab, (wm * TM + i) * 4, ks);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[q][j] = tr_read(Bb, (wn * TN + j) * 4, ks);
+            };
+            frags(0, 0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                h8 fa[TM], fb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = tr_read(As, (wm * TM + i) * 4, ks);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = tr_read(Bs, (wn * TN + j) * 4, ks);
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) frags(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+                        const int item = i * TN + j;          // row ks of the four: park A, refill A, park B, refill B
+                        if (item == 0) park_a(Pw, ks);
+                        else if (item == 1) load_a(m0 + 128, ks);
+                        else if (item == 2) park_b(Pw, ks);
+                        else load_b(m0 + 128, ks);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+            cur ^= 1;
         }
     }
 
@@ -332,6 +353,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(WgradArgs a) {
                 if (co < a.Cout && ci < a.Cin) out[(size_t)co * a.Ktot + tap * a.Cin + ci] = acc[i][j][e];
             }
         }
+}
+
+template <bool X16, bool DY16, bool GEMM>
+static void launch_wgrad_f16_g(const WgradArgs& a, dim3 grid, hipStream_t stream) {
+    constexpr int lds = 2 * 2 * 64 * 256;
+    auto kern = conv_wgrad_f16_kernel<X16, DY16, GEMM>;
+    static std::atomic<unsigned> attr_mask{0};
+    fd_set_max_lds_once(attr_mask, reinterpret_cast<const void*>(kern), lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+}
+
+template <bool X16, bool DY16>
+static void launch_wgrad_f16(const WgradArgs& a, dim3 grid, hipStream_t stream) {
+    if (a.is_gemm) launch_wgrad_f16_g<X16, DY16, true>(a, grid, stream);
+    else launch_wgrad_f16_g<X16, DY16, false>(a, grid, stream);
 }
 
 // ordered sum of the split slabs (+ optional per-output-channel scale) written as OHWI (layout 0) or OIHW (layout 1)
@@ -604,7 +640,12 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
     const bool need_reduce = nsplit > 1 || p->layout != 0 || p->scale != nullptr;
     a.out = need_reduce ? (float*)p->workspace : p->dw;
     const dim3 grid(tiles, ny);
-    if (h16) hipLaunchKernelGGL(conv_wgrad_f16_kernel, grid, dim3(256), 0, stream, a);
+    if (h16) {
+        if (a.x16 && a.dy16) launch_wgrad_f16<true, true>(a, grid, stream);
+        else if (a.x16) launch_wgrad_f16<true, false>(a, grid, stream);
+        else if (a.dy16) launch_wgrad_f16<false, true>(a, grid, stream);
+        else launch_wgrad_f16<false, false>(a, grid, stream);
+    }
     else if (bm == 32) hipLaunchKernelGGL((conv_wgrad_kernel<128, 32>), grid, dim3(256), 0, stream, a);
     else if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, stream, a);

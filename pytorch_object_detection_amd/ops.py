@@ -597,6 +597,13 @@ def conv_wgrad(x: Rows, dy: Rows, segs_in: Segs, *, Cin: int, Cout: int, k: int,
     p.precision = precision
     p.io_f16 = (1 if x.f16 else 0) | (2 if dy.f16 else 0)       # (f16 operand maps: FD_PREC_F16, Cout > 32 -- the library rejects anything else)
     check(_lib.lib().fd_conv2d_bwd_weight_f32(C.byref(p), _stream()), "fd_conv2d_bwd_weight_f32")
+    if CONV_LOG is not None:
+        def rerun(_keep=(x, dy, dw, ws, scale, p)):
+            check(_lib.lib().fd_conv2d_bwd_weight_f32(C.byref(p), _stream()), "fd_conv2d_bwd_weight_f32")
+        rerun.params = p  # type: ignore[attr-defined]
+        CONV_LOG.append((rerun, dict(kind="wgrad", Cin=Cin, Cout=Cout, k=k, stride=stride, dil=dil, rows_in=segs_in.rows, rows_out=out_rows, io=p.io_f16, precision=precision,
+                                     res=False, bytes=segs_in.rows * Cin * (2 if x.f16 else 4) + out_rows * Cout * (2 if dy.f16 else 4) + dw.numel() * 4,
+                                     flops=2 * out_rows * Cout * Cin * k * k)))
     return dw
 
 

@@ -47,16 +47,16 @@ for run, d in log:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    key = (d["Cin"], d["Cout"], d["k"], d["stride"], d["dil"], d["rows_in"], d["rows_out"], d["io"], d["precision"], d["res"], run.params.tile)
+    key = (d.get("kind", "conv"), d["Cin"], d["Cout"], d["k"], d["stride"], d["dil"], d["rows_in"], d["rows_out"], d["io"], d["precision"], d["res"], getattr(run.params, "tile", -1))
     g = groups.setdefault(key, [0, 0.0, d])
     g[0] += 1
     g[1] += ms
 peak_tf = 2500.0 if AMP else 157.3
-print(f"# {'AMP f16' if AMP else 'fp32'} training step: {len(log)} conv launches, {sum(g[1] for g in groups.values()):.2f} ms replayed one by one")
-print("# Cin Cout k s d rows_in rows_out io prec res tile | n  ms_total  us_each  GB/s  frac_hbm  TFLOP/s  frac_mfma  bound_us(max of the two)  us_each/bound")
+print(f"# {'AMP f16' if AMP else 'fp32'} training step: {len(log)} conv + weight-gradient launches, conv {sum(g[1] for k, g in groups.items() if k[0] == 'conv'):.2f} ms, weight gradients {sum(g[1] for k, g in groups.items() if k[0] == 'wgrad'):.2f} ms replayed one by one")
+print("# kind Cin Cout k s d rows_in rows_out io prec res tile | n  ms_total  us_each  GB/s  frac_hbm  TFLOP/s  frac_mfma  bound_us(max of the two)  us_each/bound")
 for key, (n, ms, d) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
     us = ms / n * 1e3
     gbs = d["bytes"] / us / 1e3
     tf = d["flops"] / us / 1e6
     bound = max(d["bytes"] / 8e6, d["flops"] / (peak_tf * 1e6))
-    print(" ".join(str(int(v)) for v in key), f"| {n} {ms:.3f} {us:.1f} {gbs:.0f} {gbs / 8000:.2f} {tf:.1f} {tf / peak_tf:.3f} {bound:.1f} {us / bound:.2f}")
+    print(key[0], " ".join(str(int(v)) for v in key[1:]), f"| {n} {ms:.3f} {us:.1f} {gbs:.0f} {gbs / 8000:.2f} {tf:.1f} {tf / peak_tf:.3f} {bound:.1f} {us / bound:.2f}")
