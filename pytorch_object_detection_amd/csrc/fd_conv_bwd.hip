@@ -377,7 +377,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int Ktot = Cin * ntaps;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 v = reinterpret_cast<const float4*>(ws)[i];
-        for (int s = 1; s < nsplit; ++s) {
+        int s = 1;
+        for (; s + 8 <= nsplit; s += 8) {             // eight slabs in flight, added in slab order (a plain loop waited for every slab in turn)
+            float4 u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) u[q] = reinterpret_cast<const float4*>(ws + (s + q) * slab)[i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { v.x += u[q].x; v.y += u[q].y; v.z += u[q].z; v.w += u[q].w; }
+        }
+        for (; s < nsplit; ++s) {
             const float4 u = reinterpret_cast<const float4*>(ws + s * slab)[i];
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
@@ -537,6 +545,18 @@ static int wgrad_splits(long M, int tiles, bool gemm) {
     return best;
 }
 
+// FD_PREC_F16 (round 5's kernel: 64-pixel K-tiles at ~0.3 us each): the slab write + ordered reduce of a split cost as much as ~20 K-tiles, so ranges of
+// ~2048 pixels (32 K-tiles) per workgroup, shortened to no less than 512 only while fewer than 128 workgroups would run (tools/time_wgrad.py F16=1 sweep:
+// 128>512 1x1 at 64k pixels 58 -> 37 us, 256>128 1x1 at 262k pixels 106 -> 74, 128>128 3x3 75 -> 63; the 3x3 256-wide layers unchanged).
+static int wgrad_splits_f16(long M, int tiles) {
+    long s = M / 2048;
+    if ((long)tiles * s > 1024) s = 1024 / tiles;          // (four rounds of 256 workgroups are enough: the 3x3 256-wide layers, as the fp32 rule has them)
+    if (s < 1) s = 1;
+    while ((long)tiles * s < 128 && M / (s * 2) >= 512) s *= 2;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
 extern "C" int64_t fd_conv_wgrad_workspace_bytes(int64_t out_rows, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW) {
     if (out_rows < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1) return -1;
     const int bn = (Cin % 128 == 0) ? 128 : 64;
@@ -544,8 +564,8 @@ extern "C" int64_t fd_conv_wgrad_workspace_bytes(int64_t out_rows, int32_t Cin, 
     const int tiles = ((Cout + bm - 1) / bm) * KH * KW * ((Cin + bn - 1) / bn);
     const int tiles16 = ((Cout + 127) / 128) * KH * KW * ((Cin + 127) / 128);      // FD_PREC_F16: 128 x 128 tiles whatever the widths
     // upper bound over both split rules (the launcher knows stride / padding, this query does not) and both precisions
-    const int ns = std::max(std::max(wgrad_splits(out_rows, tiles, false), wgrad_splits(out_rows, tiles, true)),
-                            std::max(wgrad_splits(out_rows, tiles16, false), wgrad_splits(out_rows, tiles16, true)));
+    const int ns = std::max(std::max(std::max(wgrad_splits(out_rows, tiles, false), wgrad_splits(out_rows, tiles, true)),
+                                     std::max(wgrad_splits(out_rows, tiles16, false), wgrad_splits(out_rows, tiles16, true))), wgrad_splits_f16(out_rows, tiles16));
     // + FD_MAX_SEG: level-aligned ranges give every pyramid level at least one slab of its own
     return (int64_t)(ns + FD_MAX_SEG) * Cout * KH * KW * Cin * 4;
 }
@@ -600,7 +620,7 @@ extern "C" int32_t fd_conv2d_bwd_weight_f32(const fd_conv_wgrad_params* p, fd_st
     a.co_tiles = (p->Cout + bm - 1) / bm;
     a.ci_tiles = (p->Cin + bn - 1) / bn;
     const int tiles = a.co_tiles * a.ntaps * a.ci_tiles;
-    int nsplit = p->nsplit > 0 ? p->nsplit : wgrad_splits(mo, tiles, a.is_gemm != 0);
+    int nsplit = p->nsplit > 0 ? p->nsplit : h16 ? wgrad_splits_f16(mo, tiles) : wgrad_splits(mo, tiles, a.is_gemm != 0);
     FD_REQUIRE(nsplit <= 65535, FD_E_INVAL, "fd_conv2d_bwd_weight: nsplit too large");
     a.rows_per_split = (int)(((mo + nsplit - 1) / nsplit + 31) / 32 * 32);
     unsigned ny = (unsigned)((mo + a.rows_per_split - 1) / a.rows_per_split);

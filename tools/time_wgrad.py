@@ -1,5 +1,5 @@
 """Time the weight-gradient kernel on the train step's layer shapes (diagnostic).
-usage: python tools/time_wgrad.py [nsplit,nsplit,...]   (0 = library choice)"""
+usage: python tools/time_wgrad.py [nsplit,nsplit,...]   (0 = library choice); F16=1: the AMP form (f16 maps, FD_PREC_F16)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_object_detection_amd import ops
@@ -26,12 +26,13 @@ for Cin, Cout, k, stride, dil, H, W in SHAPES:
     pad = dil * (k - 1) // 2
     segs = Segs.make(B, [(H, W)])
     so = ops.conv_out_segs(segs, k, stride, pad, dil)
-    x = ops.Rows(torch.randn(segs.rows, Cin, device=dev))
-    dy = ops.Rows(torch.randn(so.rows, Cout, device=dev))
+    F16 = os.environ.get('F16') == '1'
+    x = ops.Rows(torch.randn(segs.rows, Cin, device=dev).to(torch.float16 if F16 else torch.float32))
+    dy = ops.Rows(torch.randn(so.rows, Cout, device=dev).to(torch.float16 if F16 else torch.float32))
     flops = 2 * so.rows * Cout * Cin * k * k
     line = f"{Cin:4d}->{Cout:4d} k{k} s{stride} d{dil} {H:3d}x{W:<3d} M={so.rows:6d}:"
     for ns in splits:
-        f = lambda: ops.conv_wgrad(x, dy, segs, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, nsplit=ns)
+        f = lambda: ops.conv_wgrad(x, dy, segs, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, nsplit=ns, precision=2 if F16 else 0)
         for _ in range(2):
             f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
