@@ -377,10 +377,6 @@ int fd_launch_conv_f16k64(const fd_conv_params* p, ConvArgs& a, hipStream_t stre
     a.wide8 = p->Cout % 8 == 0 && (!a.y16 || (p->y_cs % 8 == 0 && p->y_co % 8 == 0)) && (!(a.res && a.res16) || (p->res_cs % 8 == 0 && p->res_co % 8 == 0 && ((uintptr_t)p->res & 15) == 0));
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
     // the largest tile that still gives >= 2 workgroups per CU; narrow layers take the 64-wide tiles
-    static const int force = getenv("FD_F16K64_FORCE") ? atoi(getenv("FD_F16K64_FORCE")) : -1;     // EXPERIMENT
-    if (force == 0) return launch_f16k64<2, 2, 2, 2>(a, stream);
-    if (force == 1) return launch_f16k64<2, 2, 2, 1>(a, stream);
-    if (force == 2) return launch_f16k64<2, 2, 1, 1>(a, stream);
     if (a.Cout > 64 && blocks(128, 128) >= 512) return launch_f16k64<2, 2, 2, 2>(a, stream);
     if (blocks(128, 64) >= 512) return launch_f16k64<2, 2, 2, 1>(a, stream);
     return launch_f16k64<2, 2, 1, 1>(a, stream);
