@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from pytorch_object_detection_amd import _lib, ops, train_ops as T
-from pytorch_object_detection_amd._lib import ACT_NONE, ACT_RELU, Segs
+from pytorch_object_detection_amd._lib import ACT_NONE, ACT_RELU, ACT_SILU, Segs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -120,6 +120,8 @@ K64_CASES = [
     (2048, 256, 1, 1, 0, 1, [(6, 7)], ACT_RELU, False),
     (64, 64, 3, 1, 1, 1, [(40, 36)], ACT_RELU, True),           # enough rows for the 128-row tiles
     (128, 512, 1, 1, 0, 1, [(64, 48)], ACT_RELU, True),         # ... and the 128 x 128 one
+    (64, 20, 3, 1, 1, 1, [(9, 11), (5, 6)], ACT_NONE, True),    # Cout % 8 != 0: the epilogue's 8-byte accesses (general instantiation)
+    (128, 72, 1, 1, 0, 1, [(30, 34)], ACT_SILU, False),         # SiLU
 ]
 
 
@@ -162,8 +164,10 @@ def test_conv_f16_on_k_tiles_of_64_channels(case, io):
                 ref = torch.where(rl > 0, ref, torch.zeros_like(ref)) if res_mask else ref + rl
             if act == ACT_RELU:
                 ref = F.relu(ref)
+            elif act == ACT_SILU:
+                ref = F.silu(ref)
             g = got[so.m_start[lv]:so.m_start[lv + 1]].reshape(B, a, b, Cout).permute(0, 3, 1, 2)
-            tol = 2e-3 if y16 else 2e-5
+            tol = 2e-3 if y16 else (1e-4 if act == ACT_SILU else 2e-5)      # (SiLU on v_exp_f32 / v_rcp_f32)
             np.testing.assert_allclose(g.numpy(), ref.numpy(), atol=tol, rtol=tol, err_msg=f"level {lv}")
         if y16:      # ... and exactly the fp32-output launch, rounded once
             y32 = torch.empty(so.rows, Cout, device=DEV)
@@ -349,3 +353,58 @@ def test_conv_weight_gradient_f16_operands(case):
     assert float((got - ref32).abs().max()) > float((got - ref).abs().max())          # the operands really were rounded to f16
     again = ops.conv_wgrad(xr, dr, segs, Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, scale=scale.to(DEV), oihw=True, precision=_lib.PREC_F16).cpu()
     assert torch.equal(got, again)                                                      # ordered slab reduce: bitwise reproducible
+
+
+def test_conv_f16k64_relu_from_a_channel_on():
+    """act_c0 on FD_TILE_F16K64: channels below it pass through, the rest take the ReLU (a fused layer whose first outputs are linear); with act_c0 = 0 the kernel takes
+    its uniform path, with act_c0 inside a lane's eight channels the per-channel selects."""
+    gen = torch.Generator().manual_seed(5)
+    B, Cin, Cout, hw = 2, 64, 48, [(17, 19)]
+    segs = Segs.make(B, hw)
+    x = h(torch.randn(segs.rows, Cin, generator=gen)).to(DEV)
+    w = torch.randn(Cout, Cin, 1, 1, generator=gen) / 8
+    wp = ops.pack_conv_weight_f16k64(w.to(DEV))
+    lin = x @ h(w).view(Cout, Cin).t().to(DEV)
+    for c0 in (0, 12, 32, 48):
+        y = torch.empty(segs.rows, Cout, device=DEV, dtype=torch.float16)
+        ops.conv_call(ops.Rows(x.half()), segs, wp, ops.Rows(y), Cin=Cin, Cout=Cout, k=1, act=ACT_RELU, act_c0=c0, precision=_lib.PREC_F16, tile=_lib.F16K64_TILE)()
+        want = lin.clone()
+        want[:, c0:] = want[:, c0:].clamp_min(0)
+        np.testing.assert_allclose(y.float().cpu().numpy(), want.cpu().numpy(), atol=2e-3, rtol=2e-3, err_msg=f"act_c0 {c0}")
+        assert bool((y[:, c0:] >= 0).all()) and (c0 == 0 or bool((y[:, :c0] < 0).any()))
+
+
+@pytest.mark.parametrize("case", [
+    # Cin, Cout, k, stride, pad, dil, hw, nsplit
+    (64, 256, 1, 1, 0, 1, [(20, 24)], 0),
+    (72, 40, 3, 1, 1, 1, [(10, 12), (5, 6), (3, 3), (1, 2)], 0),      # widths that end inside a lane's eight channels
+    (128, 136, 3, 2, 1, 1, [(21, 13)], 3),
+    (256, 64, 1, 1, 0, 1, [(33, 31)], 5),                             # ranges that are no multiple of the 64-pixel K-tile
+])
+@pytest.mark.parametrize("io", [(True, True), (True, False), (False, True)])
+def test_conv_weight_gradient_f16_maps(case, io):
+    """fd_conv_wgrad_params.io_f16: x and / or dy stored as f16 (the AMP step's activation and gradient maps).  Must equal, BIT FOR BIT, the fp32-map launch on the same
+    f16-valued data (same ranges, same order); channel views with NaN neighbours (the 16-byte fetches read past a view's last channels: only rows / columns of the tile
+    that are never stored may see them)."""
+    Cin, Cout, k, stride, pad, dil, hw, nsplit = case
+    x16, d16 = io
+    gen = torch.Generator().manual_seed(Cin + Cout + k + nsplit)
+    B = 2
+    segs = Segs.make(B, hw)
+    so = ops.conv_out_segs(segs, k, stride, pad, dil)
+    x = h(torch.randn(segs.rows, Cin, generator=gen)).to(DEV)
+    dy = h(torch.randn(so.rows, Cout, generator=gen)).to(DEV)
+    kw = dict(Cin=Cin, Cout=Cout, k=k, stride=stride, pad=pad, dil=dil, nsplit=nsplit, oihw=True, precision=_lib.PREC_F16)
+    want = ops.conv_wgrad(ops.Rows(x), ops.Rows(dy), segs, **kw)
+
+    def buf(t, f16, co, C_):
+        b = torch.full((t.shape[0], C_ + 20), float("nan"), dtype=torch.float16 if f16 else torch.float32, device=DEV)
+        b[:, co:co + C_] = t
+        return b
+    got = ops.conv_wgrad(ops.Rows(buf(x, x16, 8, Cin), 8, Cin), ops.Rows(buf(dy, d16, 4, Cout), 4, Cout), segs, **kw)
+    assert not bool(torch.isnan(got).any())
+    assert torch.equal(got, want), float((got - want).abs().max())
+    xs = [x[segs.m_start[i]:segs.m_start[i + 1]].reshape(B, a, b, Cin).permute(0, 3, 1, 2).cpu() for i, (a, b) in enumerate(hw)]
+    ds = [dy[so.m_start[i]:so.m_start[i + 1]].reshape(B, a, b, Cout).permute(0, 3, 1, 2).cpu() for i, (a, b) in enumerate(so.level_hw())]
+    ref = sum(torch.nn.grad.conv2d_weight(a, (Cout, Cin, k, k), b, stride, pad, dil) for a, b in zip(xs, ds))
+    assert float((got.cpu() - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-5
