@@ -480,34 +480,48 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                         }
                 }
             }
+            // The eight stores of this thread as TWO copies of the loop: FAST = no residual, no activation or ReLU on every channel of the tile -- a dozen instructions
+            // per store, contiguous; the general copy carries the residual fetch and fd_act's whole switch (ScaleExp, SiLU, sigmoid) per channel.  As ONE loop the
+            // ReLU layers hopped through ~8 000 instructions of mostly skipped code per output pass (the finding of DESIGN 4.3c on the AMP kernel: 40 % there).
+            auto store_sites = [&](auto fast_c) {
+                constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const int hh = (ep.h0 + 2 * eh + x) * a.dil + ep.ph;
-                if (hh >= eH) continue;
+                for (int x = 0; x < 2; ++x) {
+                    const int hh = (ep.h0 + 2 * eh + x) * a.dil + ep.ph;
+                    if (hh >= eH) continue;
 #pragma unroll
-                for (int y = 0; y < 4; ++y) {
-                    const int w = (ep.w0 + y) * a.dil + ep.pw;
-                    if (w >= eW) continue;
-                    const size_t m_ = (size_t)(a.m0[ep.s] + (ep.n * eH + hh) * eW + w);
-                    float4 v = make_float4(Y[x][y].x * sc.x + sf.x, Y[x][y].y * sc.y + sf.y, Y[x][y].z * sc.z + sf.z, Y[x][y].w * sc.w + sf.w);
-                    if (a.res) {
-                        const float4 rr = *reinterpret_cast<const float4*>(a.res + m_ * a.res_cs + a.res_co + nn);
-                        if (a.res_mask) {
-                            v.x = rr.x > 0.f ? v.x : 0.f; v.y = rr.y > 0.f ? v.y : 0.f; v.z = rr.z > 0.f ? v.z : 0.f; v.w = rr.w > 0.f ? v.w : 0.f;
+                    for (int y = 0; y < 4; ++y) {
+                        const int w = (ep.w0 + y) * a.dil + ep.pw;
+                        if (w >= eW) continue;
+                        const size_t m_ = (size_t)(a.m0[ep.s] + (ep.n * eH + hh) * eW + w);
+                        float4 v = make_float4(Y[x][y].x * sc.x + sf.x, Y[x][y].y * sc.y + sf.y, Y[x][y].z * sc.z + sf.z, Y[x][y].w * sc.w + sf.w);
+                        if constexpr (FAST) {
+                            if (a.act == FD_ACT_RELU) {        // (uniform)
+                                v.x = fd_act(v.x, FD_ACT_RELU, 0.f); v.y = fd_act(v.y, FD_ACT_RELU, 0.f); v.z = fd_act(v.z, FD_ACT_RELU, 0.f); v.w = fd_act(v.w, FD_ACT_RELU, 0.f);
+                            }
                         } else {
-                            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                            if (a.res) {
+                                const float4 rr = *reinterpret_cast<const float4*>(a.res + m_ * a.res_cs + a.res_co + nn);
+                                if (a.res_mask) {
+                                    v.x = rr.x > 0.f ? v.x : 0.f; v.y = rr.y > 0.f ? v.y : 0.f; v.z = rr.z > 0.f ? v.z : 0.f; v.w = rr.w > 0.f ? v.w : 0.f;
+                                } else {
+                                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                                }
+                            }
+                            if (a.act != FD_ACT_NONE) {
+                                if (nn + 0 >= a.act_c0) v.x = fd_act(v.x, a.act, eprm);
+                                if (nn + 1 >= a.act_c0) v.y = fd_act(v.y, a.act, eprm);
+                                if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, eprm);
+                                if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, eprm);
+                            }
                         }
+                        if ((W4_DBG(a) & 8) && v.x != 12345.678f) continue;          // (timing builds: the epilogue without its global stores)
+                        *reinterpret_cast<float4*>(a.y + (size_t)blockIdx.y * a.slice_stride + m_ * a.y_cs + a.y_co + nn) = v;
                     }
-                    if (a.act != FD_ACT_NONE) {
-                        if (nn + 0 >= a.act_c0) v.x = fd_act(v.x, a.act, eprm);
-                        if (nn + 1 >= a.act_c0) v.y = fd_act(v.y, a.act, eprm);
-                        if (nn + 2 >= a.act_c0) v.z = fd_act(v.z, a.act, eprm);
-                        if (nn + 3 >= a.act_c0) v.w = fd_act(v.w, a.act, eprm);
-                    }
-                    if ((W4_DBG(a) & 8) && v.x != 12345.678f) continue;          // (timing builds: the epilogue without its global stores)
-                    *reinterpret_cast<float4*>(a.y + (size_t)blockIdx.y * a.slice_stride + m_ * a.y_cs + a.y_co + nn) = v;
                 }
-            }
+            };
+            if (!a.res && (a.act == FD_ACT_NONE || (a.act == FD_ACT_RELU && a.act_c0 <= n0))) store_sites(std::integral_constant<bool, true>{});       // (uniform)
+            else store_sites(std::integral_constant<bool, false>{});
         }
     }
     if constexpr (!SK) break;

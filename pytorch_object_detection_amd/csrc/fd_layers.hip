@@ -482,8 +482,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const float* __res
         for (int j = 0; j < S; ++j) {
             if (w0 + j >= W) break;
             float4 o;
-            o.x = fd_act(acc[j].x * sc.x + sf.x, act, 0.f); o.y = fd_act(acc[j].y * sc.y + sf.y, act, 0.f);
-            o.z = fd_act(acc[j].z * sc.z + sf.z, act, 0.f); o.w = fd_act(acc[j].w * sc.w + sf.w, act, 0.f);
+            o = fd_act4(make_float4(acc[j].x * sc.x + sf.x, acc[j].y * sc.y + sf.y, acc[j].z * sc.z + sf.z, acc[j].w * sc.w + sf.w), act, 0.f);
             const long mo = r0 + (long)h * W + w0 + j;
             *reinterpret_cast<float4*>(y + mo * y_cs + y_co + 4 * q) = o;
             if (FUSE && gn_stats) {
@@ -599,7 +598,7 @@ __global__ __launch_bounds__(256) void dwconv_dilated_kernel(const float* __rest
             const float4 sf = *reinterpret_cast<const float4*>(shift + 4 * q);
             acc.x += sf.x; acc.y += sf.y; acc.z += sf.z; acc.w += sf.w;
         }
-        acc.x = fd_act(acc.x, act, 0.f); acc.y = fd_act(acc.y, act, 0.f); acc.z = fd_act(acc.z, act, 0.f); acc.w = fd_act(acc.w, act, 0.f);
+        acc = fd_act4(acc, act, 0.f);
         *reinterpret_cast<float4*>(y + m * y_cs + y_co + 4 * q) = acc;
     }
 }
@@ -866,10 +865,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     for (int r = r_begin + rt; r < r_end; r += RT, xp += xs, yp += ys) {
         const float4 v = *reinterpret_cast<const float4*>(xp);
         float4 o;
-        o.x = fd_act(v.x * sa.x + sb.x, act, 0.f);
-        o.y = fd_act(v.y * sa.y + sb.y, act, 0.f);
-        o.z = fd_act(v.z * sa.z + sb.z, act, 0.f);
-        o.w = fd_act(v.w * sa.w + sb.w, act, 0.f);
+        o = fd_act4(make_float4(v.x * sa.x + sb.x, v.y * sa.y + sb.y, v.z * sa.z + sb.z, v.w * sa.w + sb.w), act, 0.f);
         *reinterpret_cast<float4*>(yp) = o;
     }
 }
@@ -1032,10 +1028,7 @@ __global__ __launch_bounds__(256) void coef_apply_kernel(const float* __restrict
     for (int r = r_begin + rt; r < r_end; r += RT, xp += xs, yp += ys) {
         const float4 v = *reinterpret_cast<const float4*>(xp);
         float4 o;
-        o.x = fd_act(v.x * sa.x + sb.x, act, 0.f);
-        o.y = fd_act(v.y * sa.y + sb.y, act, 0.f);
-        o.z = fd_act(v.z * sa.z + sb.z, act, 0.f);
-        o.w = fd_act(v.w * sa.w + sb.w, act, 0.f);
+        o = fd_act4(make_float4(v.x * sa.x + sb.x, v.y * sa.y + sb.y, v.z * sa.z + sb.z, v.w * sa.w + sb.w), act, 0.f);
         *reinterpret_cast<float4*>(yp) = o;
     }
 }

@@ -78,8 +78,7 @@ __global__ __launch_bounds__(256) void dwconv_kxk_kernel(const float* __restrict
         for (int j = 0; j < S; ++j) {
             if (wo0 + j >= Wo) break;
             float4 o;
-            o.x = fd_act(acc[j].x * sc.x + sf.x, act, 0.f); o.y = fd_act(acc[j].y * sc.y + sf.y, act, 0.f);
-            o.z = fd_act(acc[j].z * sc.z + sf.z, act, 0.f); o.w = fd_act(acc[j].w * sc.w + sf.w, act, 0.f);
+            o = fd_act4(make_float4(acc[j].x * sc.x + sf.x, acc[j].y * sc.y + sf.y, acc[j].z * sc.z + sf.z, acc[j].w * sc.w + sf.w), act, 0.f);
             *reinterpret_cast<float4*>(yb + (long)(wo0 + j) * y_cs) = o;
         }
     }
@@ -177,8 +176,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float4* __restrict
         for (int j = 0; j < S; ++j) {
             if (wo0 + j >= Wo) break;
             float4 o;
-            o.x = fd_act(acc[j].x * sc.x + sf.x, act, 0.f); o.y = fd_act(acc[j].y * sc.y + sf.y, act, 0.f);
-            o.z = fd_act(acc[j].z * sc.z + sf.z, act, 0.f); o.w = fd_act(acc[j].w * sc.w + sf.w, act, 0.f);
+            o = fd_act4(make_float4(acc[j].x * sc.x + sf.x, acc[j].y * sc.y + sf.y, acc[j].z * sc.z + sf.z, acc[j].w * sc.w + sf.w), act, 0.f);
             *reinterpret_cast<float4*>(yb + (long)(wo0 + j) * y_cs) = o;
         }
     }

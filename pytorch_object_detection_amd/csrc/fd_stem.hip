@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(StemArgs a) {
                 const int ho = ho0 + 2 * wave + i;
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + l31] = fd_act(acc[i][j][e] * sc + sf, a.act, 0.f);
+                    stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + l31] = fd_act1(acc[i][j][e] * sc + sf, a.act, 0.f);
                 wave_lds_sync();
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
