@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                         }
                 }
             }
-            // The eight stores of this thread as TWO copies of the loop: FAST = no residual, no activation or ReLU on every channel of the tile -- a dozen instructions
+            // The eight stores of this thread as TWO copies of the loop: FAST = no residual, no activation or ReLU / SiLU on every channel of the tile -- a dozen instructions
             // per store, contiguous; the general copy carries the residual fetch and fd_act's whole switch (ScaleExp, SiLU, sigmoid) per channel.  As ONE loop the
             // ReLU layers hopped through ~8 000 instructions of mostly skipped code per output pass (the finding of DESIGN 4.3c on the AMP kernel: 40 % there).
             auto store_sites = [&](auto fast_c) {
@@ -498,6 +498,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                         if constexpr (FAST) {
                             if (a.act == FD_ACT_RELU) {        // (uniform)
                                 v.x = fd_act(v.x, FD_ACT_RELU, 0.f); v.y = fd_act(v.y, FD_ACT_RELU, 0.f); v.z = fd_act(v.z, FD_ACT_RELU, 0.f); v.w = fd_act(v.w, FD_ACT_RELU, 0.f);
+                            } else if (a.act == FD_ACT_SILU) {
+                                v.x = fd_act(v.x, FD_ACT_SILU, 0.f); v.y = fd_act(v.y, FD_ACT_SILU, 0.f); v.z = fd_act(v.z, FD_ACT_SILU, 0.f); v.w = fd_act(v.w, FD_ACT_SILU, 0.f);
                             }
                         } else {
                             if (a.res) {
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                     }
                 }
             };
-            if (!a.res && (a.act == FD_ACT_NONE || (a.act == FD_ACT_RELU && a.act_c0 <= n0))) store_sites(std::integral_constant<bool, true>{});       // (uniform)
+            if (!a.res && (a.act == FD_ACT_NONE || ((a.act == FD_ACT_RELU || a.act == FD_ACT_SILU) && a.act_c0 <= n0))) store_sites(std::integral_constant<bool, true>{});       // (uniform)
             else store_sites(std::integral_constant<bool, false>{});
         }
     }
