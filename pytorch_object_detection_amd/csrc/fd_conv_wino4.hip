@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                         }
                 }
             }
-            // The eight stores of this thread as TWO copies of the loop: FAST = no residual, no activation or ReLU / SiLU on every channel of the tile -- a dozen instructions
+            // The eight stores of this thread as TWO copies of the loop: FAST = no activation or ReLU / SiLU on every channel of the tile -- a dozen instructions
             // per store, contiguous; the general copy carries the residual fetch and fd_act's whole switch (ScaleExp, SiLU, sigmoid) per channel.  As ONE loop the
             // ReLU layers hopped through ~8 000 instructions of mostly skipped code per output pass (the finding of DESIGN 4.3c on the AMP kernel: 40 % there).
             auto store_sites = [&](auto fast_c) {
@@ -496,6 +496,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                         const size_t m_ = (size_t)(a.m0[ep.s] + (ep.n * eH + hh) * eW + w);
                         float4 v = make_float4(Y[x][y].x * sc.x + sf.x, Y[x][y].y * sc.y + sf.y, Y[x][y].z * sc.z + sf.z, Y[x][y].w * sc.w + sf.w);
                         if constexpr (FAST) {
+                            if (a.res) {                       // (uniform) the training step's data gradients: ReLU mask of the layer below, or an addend
+                                const float4 rr = *reinterpret_cast<const float4*>(a.res + m_ * a.res_cs + a.res_co + nn);
+                                if (a.res_mask) {
+                                    v.x = rr.x > 0.f ? v.x : 0.f; v.y = rr.y > 0.f ? v.y : 0.f; v.z = rr.z > 0.f ? v.z : 0.f; v.w = rr.w > 0.f ? v.w : 0.f;
+                                } else {
+                                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                                }
+                            }
                             if (a.act == FD_ACT_RELU) {        // (uniform)
                                 v.x = fd_act(v.x, FD_ACT_RELU, 0.f); v.y = fd_act(v.y, FD_ACT_RELU, 0.f); v.z = fd_act(v.z, FD_ACT_RELU, 0.f); v.w = fd_act(v.w, FD_ACT_RELU, 0.f);
                             } else if (a.act == FD_ACT_SILU) {
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino4_kernel(Wino4Args a) {
                     }
                 }
             };
-            if (!a.res && (a.act == FD_ACT_NONE || ((a.act == FD_ACT_RELU || a.act == FD_ACT_SILU) && a.act_c0 <= n0))) store_sites(std::integral_constant<bool, true>{});       // (uniform)
+            if (a.act == FD_ACT_NONE || ((a.act == FD_ACT_RELU || a.act == FD_ACT_SILU) && a.act_c0 <= n0)) store_sites(std::integral_constant<bool, true>{});       // (uniform)
             else store_sites(std::integral_constant<bool, false>{});
         }
     }
