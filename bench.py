@@ -632,6 +632,29 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
         scaler.update()
         return losses[-1]
 
+    # One process, one GPU: the whole step (forward, loss, backward, optimizer, GradScaler) is captured once as a HIP graph and replayed (train_graph.GraphedStep):
+    # under AMP the eager step is bound by the host (16 ms of kernels behind 15 - 20 ms of Python / autograd / ctypes enqueue work).  Each replay copies the batch
+    # into the captured tensors and runs every launch of the step.  FD_BENCH_TRAIN_GRAPH=0 (and every multi-rank run): eager, as the reference's loop.
+    step_mode = "eager"
+    if not use_dist and os.environ.get("FD_BENCH_TRAIN_GRAPH", "1") != "0" and (not amp or fused_opt):
+        from pytorch_object_detection_amd.train_graph import GraphedStep
+
+        def one_g(x_, gt_, labels_):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp, cache_enabled=False):
+                out = net(x_)
+                losses = crit([out, gen_t([out, gt_, labels_])])
+            scaler.scale(losses[-1]).backward()
+            scaler.step(opt)
+            scaler.update()
+            return losses[-1].detach()
+        try:
+            graphed = GraphedStep(one_g, [x, gt, labels], warmup=max(3, args.warmup))
+            xb, gtb, lb = x.clone(), gt.clone(), labels.clone()          # (the "loader's" batch: copied into the captured tensors by every step)
+            one = lambda: graphed(xb, gtb, lb)  # noqa: E731
+            step_mode = "hip graph (whole step captured once, replayed)"
+        except Exception as e:  # noqa: BLE001
+            print(f"bench: training step not captured as a graph ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
     for _ in range(args.warmup):
         one()
     if use_dist:
@@ -701,6 +724,7 @@ def train_mode(args, rank, world, dev, use_dist, out=sys.stdout):
         "config": {"workload": f"HISFCOS-R50 train.py step, {batch} x {size}x{size} images/GPU, {ncls} classes, 8 GT boxes/image, "
                                "HIP forward/backward/target/loss kernels" + (", DDP gradient all-reduce + SyncBatchNorm statistics all-reduces over RCCL" if use_dist else ""),
                    "batchnorm": "backbone frozen (eval); FPN BatchNorms on batch statistics" + (" over all ranks (SyncBatchNorm on the HIP statistics kernels)" if use_dist else ""),
+                   "step_enqueue": step_mode,
                    "optimizer": "SGD momentum 0.9" + (", fused=True (GradScaler's found_inf handled on the device: no host synchronisation per step)" if fused_opt else ""),
                    "amp_activation_maps": ("f16 in HBM inside the ResNet bottlenecks (train_ops.AMP_F16_STORE), fp32 elsewhere" if amp else None),
                    "global_batch": batch * world, "parallelism": f"dp{world} (DistributedDataParallel)"},

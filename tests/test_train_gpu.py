@@ -547,3 +547,50 @@ def test_strict_mode_raises_instead_of_falling_back():
         assert out[0][0].requires_grad and T.STATS["stock_fallbacks"] == n0 + 1
     finally:
         T.STRICT = True
+
+
+@pytest.mark.parametrize("amp", [False, True], ids=["fp32", "amp"])
+def test_whole_step_as_one_hip_graph_trains_like_the_eager_loop(amp):
+    """train_graph.GraphedStep: forward + loss + backward + fused SGD (+ GradScaler) recorded once and replayed.  Every node of the HIP training path must be
+    capture-safe (no host synchronisation, no data-dependent shapes); the replayed steps must leave the same weights as the same steps enqueued eagerly -- the
+    kernels and their order are the same, so the bar is tight (fp32: 1e-6 of the weight scale; AMP: the f16 rounding is the same too)."""
+    import copy
+    from pytorch_object_detection_amd.train_graph import GraphedStep
+    torch.manual_seed(0)
+    base = HalfInvertedStageFCOS([512, 1024, 2048], 20, 256).to(DEV).train()
+    x = torch.randn(2, 3, 128, 128, device=DEV)
+    gt = torch.tensor([[[10., 12., 60., 70.], [30., 30., 120., 110.], [-1, -1, -1, -1]],
+                       [[5., 5., 25., 30.], [0., 0., 127., 127.], [64., 20., 100., 90.]]], device=DEV)
+    labels = torch.tensor([[3, 7, -1], [1, 20, 12]], device=DEV)
+    gen_t = FCOSGenTargets([8, 16, 32, 64, 128], [[-1, 32], [32, 96], [96, 192], [192, 384], [384, 9999999]])
+    crit = FCOSLoss("giou")
+
+    def make(model):
+        opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3, momentum=0.9, weight_decay=1e-4, fused=True)
+        scaler = torch.amp.GradScaler("cuda", enabled=amp)
+
+        def step(x_, gt_, labels_):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp, cache_enabled=False):
+                out = model(x_)
+                losses = crit([out, gen_t([out, gt_, labels_])])
+            scaler.scale(losses[-1]).backward()
+            scaler.step(opt)
+            scaler.update()
+            return losses[-1].detach()
+        return step
+
+    N = 3                                           # GraphedStep's warm-up steps (eager, they train too)
+    m_eager, m_graph = copy.deepcopy(base), copy.deepcopy(base)
+    s_eager = make(m_eager)
+    losses_e = [float(s_eager(x, gt, labels)) for _ in range(N + 1 + 3)]            # warm-up + the captured step's own run + three replays
+    graphed = GraphedStep(make(m_graph), [x, gt, labels], warmup=N)                 # N eager steps, then ONE step while capturing (recorded, not executed)
+    losses_g = [float(graphed(x, gt, labels).clone()) for _ in range(4)]
+    # a capture records the step without running it: the graph model has made N + 4 steps as well
+    assert all(np.isfinite(v) for v in losses_e + losses_g)
+    np.testing.assert_allclose(losses_g, losses_e[N:], rtol=2e-3 if amp else 1e-5)
+    for (n, a), (_, b) in zip(m_eager.named_parameters(), m_graph.named_parameters()):
+        scale = float(a.detach().abs().max()) + 1e-12
+        assert float((a.detach() - b.detach()).abs().max()) <= (2e-3 if amp else 1e-5) * scale, n
+    with pytest.raises(ValueError):
+        graphed(x[:1], gt, labels)
