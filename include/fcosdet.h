@@ -286,7 +286,7 @@ typedef struct fd_conv_wgrad_params {
     fd_segs in;      /* forward INPUT geometry */
     int32_t precision; /* FD_PREC_F32 (exact, default) | FD_PREC_F16: x and dy rounded to f16 on their way to LDS, v_mfma_f32_32x32x16_f16, fp32
                           accumulation -- the weight gradient of a convolution under torch.autocast(float16) (train.py:175-181) */
-    int32_t io_f16;    /* FD_PREC_F16 with Cout > 32 only: bit 0: `x` holds _Float16 elements, bit 1: `dy` (AMP activations / gradients stored as f16: fetched as 8 bytes
+    int32_t io_f16;    /* FD_PREC_F16 only: bit 0: `x` holds _Float16 elements, bit 1: `dy` (AMP activations / gradients stored as f16: fetched as 8 bytes
                           per lane and staged without conversion; strides / offsets stay in elements).  0: fp32 maps */
 } fd_conv_wgrad_params;
 

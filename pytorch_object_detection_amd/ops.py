@@ -595,7 +595,7 @@ def conv_wgrad(x: Rows, dy: Rows, segs_in: Segs, *, Cin: int, Cout: int, k: int,
     p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     p.segs = segs_in
     p.precision = precision
-    p.io_f16 = (1 if x.f16 else 0) | (2 if dy.f16 else 0)       # (f16 operand maps: FD_PREC_F16, Cout > 32 -- the library rejects anything else)
+    p.io_f16 = (1 if x.f16 else 0) | (2 if dy.f16 else 0)       # (f16 operand maps: FD_PREC_F16 -- the library rejects anything else)
     check(_lib.lib().fd_conv2d_bwd_weight_f32(C.byref(p), _stream()), "fd_conv2d_bwd_weight_f32")
     if CONV_LOG is not None:
         def rerun(_keep=(x, dy, dw, ws, scale, p)):

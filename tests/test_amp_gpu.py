@@ -331,6 +331,8 @@ def test_amp_train_step_runs_on_f16_mfma_and_tracks_the_fp32_step():
     (128, 128, 3, 2, 1, 1, [(21, 13)]),
     (256, 256, 3, 1, 2, 2, [(12, 12)]),
     (512, 2048, 1, 1, 0, 1, [(5, 5)]),
+    (256, 32, 3, 1, 1, 1, [(10, 12), (5, 6), (3, 3)]),              # a narrow predictor (Cout <= 32: on the f16 kernel too since round 5)
+    (64, 8, 1, 1, 0, 1, [(9, 7)]),
 ])
 def test_conv_weight_gradient_f16_operands(case):
     """fd_conv2d_bwd_weight_f32 with precision = FD_PREC_F16 (the transposing LDS reads of gfx950 feed v_mfma_f32_32x32x16_f16): dW of the
