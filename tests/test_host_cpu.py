@@ -417,3 +417,13 @@ def test_round5_entry_points_validate_on_the_host():
     from pytorch_object_detection_amd import train_ops as T
     assert T.amp_pack(0, 256, 256) is False and T.amp_pack(_lib.PREC_F16, 256, 64) == 2 and T.amp_pack(_lib.PREC_F16, 32, 256) is True
     assert ops.f16k64_ok(128, 80) and not ops.f16k64_ok(96, 64)
+
+
+def test_graphed_step_refuses_host_tensors():
+    """train_graph.GraphedStep records a training step as a HIP graph: without CUDA tensors there is nothing to record -- it must say so before touching a stream."""
+    import torch
+    from pytorch_object_detection_amd.train_graph import GraphedStep
+    with pytest.raises(ValueError, match="CUDA tensors"):
+        GraphedStep(lambda x: x.sum(), [torch.zeros(2, 3)])
+    with pytest.raises(ValueError, match="CUDA tensors"):
+        GraphedStep(lambda: torch.zeros(()), [])
