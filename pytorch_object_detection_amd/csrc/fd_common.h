@@ -76,7 +76,7 @@ __device__ __forceinline__ float fd_act(float v, int act, float p) {
     }
 }
 // fd_act with the common cases (`act` is uniform in every caller) decided by compares BEFORE the switch: at a site inside an unrolled epilogue the switch's exp /
-// sigmoid bodies between the sites cost instruction-cache misses (40 % of the AMP conv kernel, 8-12 % of the F(4x4) ReLU layers)
+// sigmoid bodies and the branches around them cost instruction fetch and scalar work (40 % of the AMP conv kernel, 8-12 % of the F(4x4) ReLU layers)
 __device__ __forceinline__ float fd_act1(float v, int act, float p) {
     if (act == FD_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == FD_ACT_NONE) return v;
